@@ -1,0 +1,127 @@
+"""ctypes binding of libctgn.so (include/ctgn.h). The library is the product: there is no Python/CPU fallback —
+loading fails loudly when the in-tree libctgn.so is missing, and every device entry point fails with
+CTGN_ERR_NO_DEVICE when no gfx950 GPU is present."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctgn.so")
+
+CTGN_MAX_RESOLUTIONS = 8
+CTGN_SYSTEM_DOUBLES = 96
+CTGN_MAX_NEIGHBORS = 32
+CTGN_MIN_KEYPOINTS_USED = 100
+CTGN_F32, CTGN_F64 = 0, 1
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3, -4
+ERR_TIMESTAMP_RANGE, ERR_VOXEL_RANGE, ERR_UNSUPPORTED = -5, -6, -7
+
+
+class CtgnError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libctgn status {status}: {message}")
+        self.status = status
+
+
+class ResolutionParam(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("min_distance_between_points", C.c_double),
+                ("max_num_points", C.c_int32), ("_pad", C.c_int32)]
+
+
+class MapOptions(C.Structure):
+    _fields_ = [("num_resolutions", C.c_int32), ("device", C.c_int32), ("default_radius", C.c_double),
+                ("resolutions", ResolutionParam * CTGN_MAX_RESOLUTIONS), ("initial_voxel_capacity", C.c_uint64)]
+
+
+class Options(C.Structure):
+    _fields_ = [("num_iters_icp", C.c_int32), ("min_number_neighbors", C.c_int32),
+                ("max_number_neighbors", C.c_int32), ("debug_print", C.c_int32),
+                ("max_dist_to_plane_ct_icp", C.c_double), ("threshold_orientation_norm", C.c_double)]
+
+
+class MotionPrior(C.Structure):
+    _fields_ = [("beta_location_consistency", C.c_double), ("beta_constant_velocity", C.c_double),
+                ("previous_begin_tr", C.c_double * 3), ("previous_end_tr", C.c_double * 3)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("success", C.c_int32), ("num_residuals_used", C.c_int32), ("num_iters", C.c_int32),
+                ("_pad", C.c_int32), ("duration_total_ms", C.c_double), ("duration_device_ms", C.c_double),
+                ("last_step_norm", C.c_double), ("error_log", C.c_char * 256)]
+
+
+class View(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("stride_bytes", C.c_size_t), ("dtype", C.c_int32), ("_pad", C.c_int32)]
+
+
+# every symbol include/ctgn.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_H = C.c_void_p
+SYMBOLS = {
+    "ctgn_abi_version": (C.c_int32, []),
+    "ctgn_status_string": (C.c_char_p, [C.c_int]),
+    "ctgn_last_error": (C.c_char_p, [_H]),
+    "ctgn_map_options_default": (None, [C.POINTER(MapOptions)]),
+    "ctgn_options_default": (None, [C.POINTER(Options)]),
+    "ctgn_create": (C.c_int, [C.POINTER(MapOptions), C.POINTER(_H)]),
+    "ctgn_destroy": (None, [_H]),
+    "ctgn_map_insert": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_uint8)]),
+    "ctgn_map_remove_far": (C.c_int, [_H, _dp, C.c_double]),
+    "ctgn_map_clear": (C.c_int, [_H]),
+    "ctgn_map_num_points": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "ctgn_map_num_voxels": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint64)]),
+    "ctgn_map_search_params": (C.c_int, [_H, C.c_double, C.POINTER(C.c_int32), _dp, C.POINTER(C.c_int32)]),
+    "ctgn_map_export": (C.c_int, [_H, C.c_int32, _dp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ctgn_map_sync": (C.c_int, [_H]),
+    "ctgn_map_radius_search": (C.c_int, [_H, _dp, C.c_size_t, C.c_double, C.c_int32, _dp, C.POINTER(C.c_int32)]),
+    "ctgn_set_keypoints": (C.c_int, [_H, View, View, View, C.c_size_t]),
+    "ctgn_solve": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_get_world_points": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
+    "ctgn_register": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
+                                C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_gn_begin": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior)]),
+    "ctgn_gn_accumulate": (C.c_int, [_H]),
+    "ctgn_gn_system_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "ctgn_gn_solve_update": (C.c_int, [_H]),
+    "ctgn_gn_end": (C.c_int, [_H, _dp, C.POINTER(Summary)]),
+    "ctgn_gn_done": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "ctgn_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "ctgn_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "ctgn_set_debug": (C.c_int, [_H, C.c_int32]),
+    "ctgn_get_debug": (C.c_int, [_H, C.POINTER(C.c_int32), _dp, _dp, _dp, C.POINTER(C.c_uint8), C.c_size_t]),
+    "ctgn_get_system": (C.c_int, [_H, _dp]),
+    "ctgn_count_traffic": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ctgn_set_profiling": (C.c_int, [_H, C.c_int32]),
+    "ctgn_kernel_timing": (C.c_int, [_H, _dp, C.POINTER(C.c_int32), C.c_int32]),
+    "ctgn_set_variant": (C.c_int, [_H, C.c_int32]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the in-tree libctgn.so. Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). ct_icp_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(handle, status: int):
+    if status != OK:
+        L = lib()
+        msg = L.ctgn_last_error(handle).decode() if handle else L.ctgn_status_string(status).decode()
+        if not msg:
+            msg = L.ctgn_status_string(status).decode()
+        raise CtgnError(status, msg)

@@ -1,0 +1,828 @@
+// ctgn_api.hip — the C ABI of libctgn.so (include/ctgn.h) over the gfx950 kernels in ctgn_kernels.hpp.
+// Host side only: context, device residency of the voxel map (full / delta upload), keypoint staging, launch
+// sequencing of the GN loop on one HIP stream. No CPU fallback exists for any query or solve entry point.
+#include "../../include/ctgn.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctgn_kernels.hpp"
+
+using namespace ctgn;
+
+namespace {
+
+struct DeviceLevel {
+    Slot *slots = nullptr;
+    double *blocks = nullptr;
+    size_t slots_cap = 0;    // in slots
+    size_t blocks_cap = 0;   // in doubles
+    bool resident = false;
+};
+
+struct EventPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+}  // namespace
+
+struct ctgn_context {
+    int device = -1;                    // -1: host-only map mirror, every device entry point fails
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ctgn_map_options opts{};
+    std::vector<VoxelLevel> levels;
+    std::vector<DeviceLevel> dlevels;
+
+    // keypoints: one device allocation of 7 arrays [rx ry rz t wx wy wz] x cap_kp
+    int n_kp = 0, cap_kp = 0;
+    double *d_kp = nullptr;
+    double *h_kp = nullptr;             // pinned staging, same layout
+    double t_min = 0, t_max = 0;
+
+    // solver
+    GnState *d_state = nullptr;
+    GnState *h_state = nullptr;         // pinned
+    double *d_sys = nullptr;
+    double *d_partials = nullptr;
+    double *d_pose_in = nullptr;
+    double *h_pose_in = nullptr;        // pinned
+    GnParams prm{};
+    ctgn_options gn_opts{};
+    int launched_iters = 0;
+    int last_grid = 0;
+    bool gn_active = false;
+    std::chrono::steady_clock::time_point gn_t0;
+    hipEvent_t ev_loop_start = nullptr, ev_loop_stop = nullptr;
+
+    // debug / introspection
+    bool debug = false;
+    int dbg_cap = 0;
+    int *d_nnb = nullptr;
+    double *d_normal = nullptr, *d_a2d = nullptr, *d_far = nullptr;
+    uint8_t *d_used = nullptr;
+    Counters *d_counters = nullptr;
+
+    // edit staging
+    void *d_edit = nullptr;
+    void *h_edit = nullptr;             // pinned
+    size_t edit_cap = 0;
+
+    // kernel timing
+    bool profiling = false;
+    std::vector<EventPair> events;
+    int events_used = 0;
+    double acc_ms = 0.0;
+    int acc_launches = 0;
+
+    int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist
+    std::string last_error;
+};
+
+namespace {
+
+const char *status_str(ctgn_status s) {
+    switch (s) {
+        case CTGN_OK: return "ok";
+        case CTGN_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case CTGN_ERR_NO_DEVICE: return "no gfx950 HIP device (libctgn has no CPU fallback)";
+        case CTGN_ERR_HIP: return "HIP runtime error";
+        case CTGN_ERR_OUT_OF_MEMORY: return "out of memory";
+        case CTGN_ERR_TIMESTAMP_RANGE: return "The timestamp cannot be interpolated between the two poses";
+        case CTGN_ERR_VOXEL_RANGE: return "voxel coordinate out of range";
+        case CTGN_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown";
+}
+
+ctgn_status fail(ctgn_handle h, ctgn_status s, const std::string &msg) {
+    if (h) h->last_error = std::string(status_str(s)) + ": " + msg;
+    return s;
+}
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(h, e_ == hipErrorOutOfMemory ? CTGN_ERR_OUT_OF_MEMORY : CTGN_ERR_HIP,        \
+                        std::string("[HIP] ") + #call + " -> " + hipGetErrorString(e_));             \
+    } while (0)
+
+#define NEED_DEVICE(h)                                                                               \
+    do {                                                                                             \
+        if (!(h)) return CTGN_ERR_INVALID_ARGUMENT;                                                  \
+        if ((h)->device < 0) return fail(h, CTGN_ERR_NO_DEVICE, "context was created host-only");    \
+        HIPCHK(h, hipSetDevice((h)->device));                                                        \
+    } while (0)
+
+inline double read_elem(const void *base, size_t stride, ctgn_dtype dt, size_t i, int c) {
+    const char *p = static_cast<const char *>(base) + i * stride;
+    return dt == CTGN_F64 ? reinterpret_cast<const double *>(p)[c] : (double) reinterpret_cast<const float *>(p)[c];
+}
+
+ctgn_status ensure_edit_buffer(ctgn_handle h, size_t bytes) {
+    if (bytes <= h->edit_cap) return CTGN_OK;
+    size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
+    if (h->d_edit) HIPCHK(h, hipFree(h->d_edit));
+    if (h->h_edit) HIPCHK(h, hipHostFree(h->h_edit));
+    h->d_edit = nullptr; h->h_edit = nullptr; h->edit_cap = 0;
+    HIPCHK(h, hipMalloc(&h->d_edit, cap));
+    HIPCHK(h, hipHostMalloc(&h->h_edit, cap, hipHostMallocDefault));
+    h->edit_cap = cap;
+    return CTGN_OK;
+}
+
+// Bring level `li` up to date on the device: full copy after (re)allocation / rehash, else scatter the edit log.
+ctgn_status sync_level(ctgn_handle h, int li) {
+    VoxelLevel &L = h->levels[li];
+    DeviceLevel &D = h->dlevels[li];
+    const size_t nslots = (size_t) L.mask + 1;
+    const size_t nblk_doubles = (size_t) L.nblocks_cap * 3 * L.blk;
+    bool full = L.need_full_upload || !D.resident;
+    if (!full && L.slot_edits.size() * 4 > nslots) full = true;
+    if (full) {
+        if (D.slots_cap < nslots) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (D.slots) HIPCHK(h, hipFree(D.slots));
+            D.slots = nullptr; D.slots_cap = 0;
+            HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&D.slots), nslots * sizeof(Slot)));
+            D.slots_cap = nslots;
+        }
+        if (D.blocks_cap < nblk_doubles) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (D.blocks) HIPCHK(h, hipFree(D.blocks));
+            D.blocks = nullptr; D.blocks_cap = 0;
+            HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&D.blocks), nblk_doubles * sizeof(double)));
+            D.blocks_cap = nblk_doubles;
+        }
+        HIPCHK(h, hipMemcpyAsync(D.slots, L.slots.data(), nslots * sizeof(Slot), hipMemcpyHostToDevice, h->stream));
+        const size_t used_doubles = (size_t) L.nblocks_used * 3 * L.blk;
+        if (used_doubles)
+            HIPCHK(h, hipMemcpyAsync(D.blocks, L.blocks.data(), used_doubles * sizeof(double), hipMemcpyHostToDevice,
+                                     h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // the source vectors are pageable and may change next
+    } else if (!L.slot_edits.empty() || !L.point_edits.empty()) {
+        // delta: re-read the CURRENT host value of every logged location, so duplicates in the log agree
+        const size_t ns = L.slot_edits.size(), np = L.point_edits.size();
+        const size_t bytes = ns * sizeof(SlotEdit) + np * sizeof(PointEdit);
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // previous use of the staging buffer
+        ctgn_status st = ensure_edit_buffer(h, bytes);
+        if (st != CTGN_OK) return st;
+        SlotEdit *hs = static_cast<SlotEdit *>(h->h_edit);
+        PointEdit *hp = reinterpret_cast<PointEdit *>(hs + ns);
+        for (size_t i = 0; i < ns; ++i) {
+            hs[i].slot = L.slot_edits[i].slot;
+            hs[i]._pad = 0;
+            hs[i].value = L.slots[L.slot_edits[i].slot];
+        }
+        for (size_t i = 0; i < np; ++i) {
+            const PointEdit &e = L.point_edits[i];
+            const double *bx = L.bx(e.block);
+            hp[i] = PointEdit{e.block, e.index, bx[e.index], bx[L.blk + e.index], bx[2 * L.blk + e.index]};
+        }
+        HIPCHK(h, hipMemcpyAsync(h->d_edit, h->h_edit, bytes, hipMemcpyHostToDevice, h->stream));
+        SlotEdit *ds = static_cast<SlotEdit *>(h->d_edit);
+        PointEdit *dp = reinterpret_cast<PointEdit *>(ds + ns);
+        if (np) hipLaunchKernelGGL(k_scatter_points, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, h->stream, D.blocks,
+                                   L.blk, dp, (int) np);
+        if (ns) hipLaunchKernelGGL(k_scatter_slots, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, h->stream, D.slots,
+                                   ds, (int) ns);
+        HIPCHK(h, hipGetLastError());
+    }
+    L.slot_edits.clear();
+    L.point_edits.clear();
+    L.need_full_upload = false;
+    L.log_edits = true;
+    D.resident = true;
+    return CTGN_OK;
+}
+
+ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
+    if (radius <= 0) radius = h->opts.default_radius;
+    int map_id, nb;
+    double res;
+    search_params(h->levels, radius, &map_id, &res, &nb);
+    ctgn_status st = sync_level(h, map_id);
+    if (st != CTGN_OK) return st;
+    const VoxelLevel &L = h->levels[map_id];
+    const DeviceLevel &D = h->dlevels[map_id];
+    mv->slots = D.slots;
+    mv->blocks = D.blocks;
+    mv->mask = L.mask;
+    mv->blk = L.blk;
+    mv->nb = nb;
+    mv->resolution = res;
+    mv->r2thr = radius_sq_threshold(radius);
+    return CTGN_OK;
+}
+
+KpView kp_view(ctgn_handle h) {
+    KpView v;
+    const size_t c = (size_t) h->cap_kp;
+    v.rx = h->d_kp; v.ry = h->d_kp + c; v.rz = h->d_kp + 2 * c; v.t = h->d_kp + 3 * c;
+    v.wx = h->d_kp + 4 * c; v.wy = h->d_kp + 5 * c; v.wz = h->d_kp + 6 * c;
+    v.n = h->n_kp;
+    return v;
+}
+
+DebugView dbg_view(ctgn_handle h) {
+    DebugView d{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (h->debug) { d.n_nb = h->d_nnb; d.normal = h->d_normal; d.a2d = h->d_a2d; d.farthest = h->d_far; d.used = h->d_used; }
+    return d;
+}
+
+ctgn_status ensure_debug(ctgn_handle h) {
+    if (!h->debug || h->dbg_cap >= h->cap_kp) return CTGN_OK;
+    if (h->d_nnb) { hipFree(h->d_nnb); hipFree(h->d_normal); hipFree(h->d_a2d); hipFree(h->d_far); hipFree(h->d_used); }
+    h->d_nnb = nullptr; h->dbg_cap = 0;
+    const size_t c = (size_t) h->cap_kp;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_nnb), c * sizeof(int)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_normal), c * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_a2d), c * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_far), c * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_used), c));
+    h->dbg_cap = h->cap_kp;
+    return CTGN_OK;
+}
+
+// How many keypoints one wave owns per tile (4 rows x rounds): large tiles for large N (fewer, fuller waves),
+// small tiles for the latency regime so that a 1-3 k keypoint frame still spreads over the 256 CUs.
+int pick_rounds(int n) {
+    int rounds = 16;
+    while (rounds > 1 && (long long) n < (long long) 4 * rounds * 2048) rounds >>= 1;
+    return rounds;
+}
+
+ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter) {
+    KpView kv = kp_view(h);
+    DebugView dv = dbg_view(h);
+    EventPair *ev = nullptr;
+    if (h->profiling) {
+        if (h->events_used == (int) h->events.size()) {
+            EventPair p;
+            HIPCHK(h, hipEventCreate(&p.start));
+            HIPCHK(h, hipEventCreate(&p.stop));
+            h->events.push_back(p);
+        }
+        ev = &h->events[h->events_used++];
+        HIPCHK(h, hipEventRecord(ev->start, h->stream));
+    }
+    int grid;
+    const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
+    if (h->variant == 1 || !rows_ok) {
+        const int ntiles = (h->n_kp + LANE_BLOCK - 1) / LANE_BLOCK;
+        grid = std::max(1, std::min(ntiles, MAX_PARTIAL_BLOCKS));
+        hipLaunchKernelGGL(k_accumulate_lane, dim3(grid), dim3(LANE_BLOCK), lane_kernel_smem(), h->stream, mv, kv,
+                           h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0);
+    } else {
+        const int rounds = pick_rounds(h->n_kp);
+        const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
+        grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, MAX_PARTIAL_BLOCKS));
+        const bool hist = h->variant != 2;
+        if (mv.nb == 1) {
+            if (hist) hipLaunchKernelGGL((k_accumulate_rows<1, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
+                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+            else hipLaunchKernelGGL((k_accumulate_rows<1, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
+                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+        } else {
+            if (hist) hipLaunchKernelGGL((k_accumulate_rows<2, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
+                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+            else hipLaunchKernelGGL((k_accumulate_rows<2, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
+                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    if (ev) HIPCHK(h, hipEventRecord(ev->stop, h->stream));
+    h->last_grid = grid;
+    return CTGN_OK;
+}
+
+ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
+    hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(128), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
+                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
+    HIPCHK(h, hipGetLastError());
+    return CTGN_OK;
+}
+
+void fill_params(ctgn_handle h, const ctgn_options *o, const ctgn_motion_prior *p) {
+    h->gn_opts = *o;
+    GnParams &g = h->prm;
+    g.min_nb = o->min_number_neighbors;
+    g.max_nb = o->max_number_neighbors;
+    g.max_dist = o->max_dist_to_plane_ct_icp;
+    g.thr_norm = o->threshold_orientation_norm;
+    g.has_prior = p ? 1 : 0;
+    g.beta_c = p ? p->beta_location_consistency : 0.0;
+    g.beta_e = p ? p->beta_constant_velocity : 0.0;
+    for (int c = 0; c < 3; ++c) {
+        g.prev_b[c] = p ? p->previous_begin_tr[c] : 0.0;
+        g.prev_e[c] = p ? p->previous_end_tr[c] : 0.0;
+    }
+}
+
+// Fold the HIP-event times of the accumulate launches that did real work into the running average.
+void harvest_events(ctgn_handle h, int real_launches) {
+    for (int i = 0; i < h->events_used; ++i) {
+        if (i < real_launches) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->events[i].start, h->events[i].stop) == hipSuccess) {
+                h->acc_ms += ms;
+                h->acc_launches++;
+            }
+        }
+    }
+    h->events_used = 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int32_t ctgn_abi_version(void) { return CTGN_ABI_VERSION; }
+
+const char *ctgn_status_string(ctgn_status s) { return status_str(s); }
+
+const char *ctgn_last_error(ctgn_handle h) { return h ? h->last_error.c_str() : "null handle"; }
+
+void ctgn_map_options_default(ctgn_map_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->num_resolutions = 3;
+    o->device = 0;
+    o->default_radius = 0.8;
+    o->resolutions[0] = ctgn_resolution_param{0.2, 0.03, 50, 0};
+    o->resolutions[1] = ctgn_resolution_param{0.5, 0.1, 40, 0};
+    o->resolutions[2] = ctgn_resolution_param{1.5, 0.15, 40, 0};
+    o->initial_voxel_capacity = 0;
+}
+
+void ctgn_options_default(ctgn_options *o) {
+    if (!o) return;
+    o->num_iters_icp = 5;
+    o->min_number_neighbors = 20;
+    o->max_number_neighbors = 20;
+    o->debug_print = 0;
+    o->max_dist_to_plane_ct_icp = 0.3;
+    o->threshold_orientation_norm = 0.0001;
+}
+
+ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
+    if (!opts || !out) return CTGN_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (opts->num_resolutions < 1 || opts->num_resolutions > CTGN_MAX_RESOLUTIONS) return CTGN_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < opts->num_resolutions; ++i) {
+        const ctgn_resolution_param &r = opts->resolutions[i];
+        if (!(r.resolution > 0) || r.max_num_points < 1 || r.max_num_points > 64) return CTGN_ERR_INVALID_ARGUMENT;
+    }
+    if (!(opts->default_radius > 0)) return CTGN_ERR_INVALID_ARGUMENT;
+    ctgn_context *h = new (std::nothrow) ctgn_context();
+    if (!h) return CTGN_ERR_OUT_OF_MEMORY;
+    h->opts = *opts;
+    h->device = opts->device;
+    h->levels.resize(opts->num_resolutions);
+    h->dlevels.resize(opts->num_resolutions);
+    for (int i = 0; i < opts->num_resolutions; ++i)
+        h->levels[i].init(opts->resolutions[i].resolution, opts->resolutions[i].min_distance_between_points,
+                          opts->resolutions[i].max_num_points, opts->initial_voxel_capacity);
+    if (h->device >= 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= h->device) { delete h; return CTGN_ERR_NO_DEVICE; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            delete h;
+            return CTGN_ERR_NO_DEVICE;
+        }
+        bool ok = hipSetDevice(h->device) == hipSuccess &&
+                  hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+        h->own_stream = ok;
+        ok = ok && hipMalloc(reinterpret_cast<void **>(&h->d_state), sizeof(GnState)) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(GnState), hipHostMallocDefault) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_sys), SYS_N * sizeof(double)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_partials), (size_t) MAX_PARTIAL_BLOCKS * SYS_N * sizeof(double)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
+             hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
+             hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
+             hipMemsetAsync(h->d_sys, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
+        // the kernels use up to ~37 KB of dynamic LDS (rows) / 62 KB (lane): allow it explicitly
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate_lane),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radius_search),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
+        if (!ok) { ctgn_destroy(h); return CTGN_ERR_HIP; }
+    }
+    *out = h;
+    return CTGN_OK;
+}
+
+void ctgn_destroy(ctgn_handle h) {
+    if (!h) return;
+    if (h->device >= 0) {
+        hipSetDevice(h->device);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
+        if (h->d_kp) hipFree(h->d_kp);
+        if (h->h_kp) hipHostFree(h->h_kp);
+        if (h->d_state) hipFree(h->d_state);
+        if (h->h_state) hipHostFree(h->h_state);
+        if (h->d_sys) hipFree(h->d_sys);
+        if (h->d_partials) hipFree(h->d_partials);
+        if (h->d_pose_in) hipFree(h->d_pose_in);
+        if (h->h_pose_in) hipHostFree(h->h_pose_in);
+        if (h->d_counters) hipFree(h->d_counters);
+        if (h->d_nnb) { hipFree(h->d_nnb); hipFree(h->d_normal); hipFree(h->d_a2d); hipFree(h->d_far); hipFree(h->d_used); }
+        if (h->d_edit) hipFree(h->d_edit);
+        if (h->h_edit) hipHostFree(h->h_edit);
+        for (auto &e : h->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+        if (h->ev_loop_start) hipEventDestroy(h->ev_loop_start);
+        if (h->ev_loop_stop) hipEventDestroy(h->ev_loop_stop);
+        if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------------- map
+ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
+    if (!h || (!xyz_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
+    bool range_error = false;
+    for (size_t i = 0; i < n; ++i) {
+        double x = read_elem(xyz_base, stride, dt, i, 0), y = read_elem(xyz_base, stride, dt, i, 1),
+               z = read_elem(xyz_base, stride, dt, i, 2);
+        int any = 0;
+        for (auto &L : h->levels) {                 // map.h:199-205: every resolution
+            int r = L.insert_point(x, y, z);
+            if (r < 0) range_error = true;
+            else any |= r;
+        }
+        if (out) out[i] = (uint8_t) any;
+    }
+    if (range_error) return fail(h, CTGN_ERR_VOXEL_RANGE, "a point fell outside the 21-bit voxel key range and was skipped");
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_remove_far(ctgn_handle h, const double location[3], double distance) {
+    if (!h || !location) return CTGN_ERR_INVALID_ARGUMENT;
+    for (auto &L : h->levels) L.remove_far(location, distance);
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_clear(ctgn_handle h) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    for (auto &L : h->levels) {
+        bool log = L.log_edits;
+        L.clear();
+        L.log_edits = log;
+    }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_num_points(ctgn_handle h, uint64_t *out) {
+    if (!h || !out) return CTGN_ERR_INVALID_ARGUMENT;
+    uint64_t s = 0;
+    for (auto &L : h->levels) s += L.num_points;
+    *out = s;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_num_voxels(ctgn_handle h, int32_t li, uint64_t *out) {
+    if (!h || !out || li < 0 || li >= (int) h->levels.size()) return CTGN_ERR_INVALID_ARGUMENT;
+    *out = h->levels[li].num_voxels;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_search_params(ctgn_handle h, double radius, int32_t *map_id, double *res, int32_t *nb) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    if (radius <= 0) radius = h->opts.default_radius;
+    int mi, n;
+    double r;
+    search_params(h->levels, radius, &mi, &r, &n);
+    if (map_id) *map_id = mi;
+    if (res) *res = r;
+    if (nb) *nb = n;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_export(ctgn_handle h, int32_t li, double *out_xyz, uint64_t cap, uint64_t *out_n) {
+    if (!h || li < 0 || li >= (int) h->levels.size()) return CTGN_ERR_INVALID_ARGUMENT;
+    uint64_t n = h->levels[li].export_points(out_xyz, cap);
+    if (out_n) *out_n = n;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_sync(ctgn_handle h) {
+    NEED_DEVICE(h);
+    MapView mv;
+    ctgn_status st = make_map_view(h, -1.0, &mv);
+    if (st != CTGN_OK) return st;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries, size_t n, double radius, int32_t k,
+                                   double *out_xyz, int32_t *out_count) {
+    NEED_DEVICE(h);
+    if ((!queries || !out_xyz || !out_count) && n) return CTGN_ERR_INVALID_ARGUMENT;
+    if (k < 1 || k > CTGN_MAX_NEIGHBORS) return fail(h, CTGN_ERR_UNSUPPORTED, "max_num_neighbors must be in [1, 32]");
+    if (n == 0) return CTGN_OK;
+    MapView mv;
+    ctgn_status st = make_map_view(h, radius, &mv);
+    if (st != CTGN_OK) return st;
+    double *dq = nullptr, *dout = nullptr;
+    int *dcnt = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dq), n * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dout), n * (size_t) k * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dcnt), n * sizeof(int)));
+    HIPCHK(h, hipMemcpyAsync(dq, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(dout, 0, n * (size_t) k * 3 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_radius_search, dim3((unsigned) ((n + LANE_BLOCK - 1) / LANE_BLOCK)), dim3(LANE_BLOCK),
+                       lane_kernel_smem(), h->stream, mv, dq, (int) n, (int) k, dout, dcnt);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out_xyz, dout, n * (size_t) k * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_count, dcnt, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(dq); hipFree(dout); hipFree(dcnt);
+    return CTGN_OK;
+}
+
+// ---------------------------------------------------------------------------------------- keypoints
+ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n) {
+    NEED_DEVICE(h);
+    if (n > 0 && (!raw.base || !world.base || !ts.base)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
+    if ((int) n > h->cap_kp) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_kp) HIPCHK(h, hipFree(h->d_kp));
+        if (h->h_kp) HIPCHK(h, hipHostFree(h->h_kp));
+        h->d_kp = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
+        size_t cap = std::max<size_t>(n + n / 4, 4096);
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), cap * 7 * sizeof(double)));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), cap * 7 * sizeof(double), hipHostMallocDefault));
+        h->cap_kp = (int) cap;
+    }
+    h->n_kp = (int) n;
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // staging reuse
+    const size_t c = (size_t) h->cap_kp;
+    double tmin = INFINITY, tmax = -INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            h->h_kp[a * c + i] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
+            h->h_kp[(4 + a) * c + i] = read_elem(world.base, world.stride_bytes, world.dtype, i, a);
+        }
+        double t = read_elem(ts.base, ts.stride_bytes, ts.dtype, i, 0);
+        h->h_kp[3 * c + i] = t;
+        tmin = t < tmin ? t : tmin;
+        tmax = t > tmax ? t : tmax;
+        if (t != t) tmax = NAN;
+    }
+    h->t_min = tmin; h->t_max = tmax;
+    if (n) {
+        for (int a = 0; a < 7; ++a)
+            HIPCHK(h, hipMemcpyAsync(h->d_kp + a * c, h->h_kp + a * c, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    ctgn_status st = ensure_debug(h);
+    if (st != CTGN_OK) return st;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride, ctgn_dtype dt, size_t n) {
+    NEED_DEVICE(h);
+    if (n > (size_t) h->n_kp || (!world_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CTGN_OK;
+    const size_t c = (size_t) h->cap_kp;
+    for (int a = 0; a < 3; ++a)
+        HIPCHK(h, hipMemcpyAsync(h->h_kp + (4 + a) * c, h->d_kp + (4 + a) * c, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; ++i) {
+        char *p = static_cast<char *>(world_base) + i * stride;
+        for (int a = 0; a < 3; ++a) {
+            double v = h->h_kp[(4 + a) * c + i];
+            if (dt == CTGN_F64) reinterpret_cast<double *>(p)[a] = v;
+            else reinterpret_cast<float *>(p)[a] = (float) v;
+        }
+    }
+    return CTGN_OK;
+}
+
+// ---------------------------------------------------------------------------------------- GN loop
+ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe[2], const ctgn_options *opts,
+                          const ctgn_motion_prior *prior) {
+    NEED_DEVICE(h);
+    if (!pose || !tbe || !opts) return CTGN_ERR_INVALID_ARGUMENT;
+    if (opts->max_number_neighbors < 1 || opts->max_number_neighbors > CTGN_MAX_NEIGHBORS)
+        return fail(h, CTGN_ERR_UNSUPPORTED, "max_number_neighbors must be in [1, 32]");
+    // InterpolatePose CHECKs begin.dest_timestamp <= t <= end.dest_timestamp (types.h:456); the reference would
+    // abort the process at ct_icp.cpp:965 — reported as an error instead, before anything is modified.
+    if (h->n_kp > 0 && !(tbe[0] <= h->t_min && h->t_max <= tbe[1]))
+        return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "keypoint timestamps must lie in [t_begin, t_end]");
+    h->gn_t0 = std::chrono::steady_clock::now();
+    fill_params(h, opts, prior);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
+    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);
+    HIPCHK(h, hipGetLastError());
+    h->launched_iters = 0;
+    h->events_used = 0;
+    h->gn_active = true;
+    HIPCHK(h, hipEventRecord(h->ev_loop_start, h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_gn_accumulate(ctgn_handle h) {
+    NEED_DEVICE(h);
+    if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
+    MapView mv;
+    ctgn_status st = make_map_view(h, -1.0, &mv);
+    if (st != CTGN_OK) return st;
+    st = launch_accumulate(h, mv, h->launched_iters == 0);
+    if (st != CTGN_OK) return st;
+    h->launched_iters++;
+    return launch_reduce_solve(h, 1);
+}
+
+ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out) {
+    NEED_DEVICE(h);
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    *out = h->d_sys;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_gn_solve_update(ctgn_handle h) {
+    NEED_DEVICE(h);
+    if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
+    return launch_reduce_solve(h, 2);
+}
+
+ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done) {
+    NEED_DEVICE(h);
+    if (!done) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *done = h->h_state->done;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summary) {
+    NEED_DEVICE(h);
+    if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
+    if (h->n_kp > 0) {
+        const int grid = std::max(1, std::min((h->n_kp + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_transform, dim3(grid), dim3(256), 0, h->stream, kp_view(h), h->d_state);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->gn_active = false;
+    const GnState &s = *h->h_state;
+    if (h->profiling) harvest_events(h, s.iter + (s.failed ? 1 : 0));
+    if (pose_out) for (int i = 0; i < 14; ++i) pose_out[i] = s.pose[i];
+    if (summary) {
+        std::memset(summary, 0, sizeof(*summary));
+        summary->success = s.failed ? 0 : 1;                       // ct_icp.cpp:869 / :992
+        summary->num_residuals_used = s.n_used;
+        summary->num_iters = s.iter;
+        summary->last_step_norm = s.step_norm;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, h->ev_loop_start, h->ev_loop_stop);
+        summary->duration_device_ms = ms;
+        summary->duration_total_ms =
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
+        if (s.failed) {
+            std::snprintf(summary->error_log, sizeof(summary->error_log),
+                          "[CT_ICP]Error : not enough keypoints selected in ct-icp !\n[CT_ICP]Number_of_residuals : %d\n",
+                          s.n_used);                                // same text as ct_icp.cpp:862-863
+            if (h->gn_opts.debug_print) std::fputs(summary->error_log, stdout);
+        }
+    }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                       const ctgn_motion_prior *prior, ctgn_summary *summary) {
+    ctgn_status st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
+    if (st != CTGN_OK) {
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", ctgn_last_error(h)); }
+        return st;
+    }
+    MapView mv;
+    st = make_map_view(h, -1.0, &mv);
+    for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {       // ct_icp.cpp:745
+        st = launch_accumulate(h, mv, it == 0);
+        if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
+    }
+    if (st != CTGN_OK) {
+        h->gn_active = false;
+        hipStreamSynchronize(h->stream);
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", ctgn_last_error(h)); }
+        return st;
+    }
+    return ctgn_gn_end(h, pose_io, summary);
+}
+
+ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t world_stride, ctgn_dtype world_dtype,
+                          ctgn_view ts, size_t n, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                          const ctgn_motion_prior *prior, ctgn_summary *summary) {
+    ctgn_view world{world_base, world_stride, world_dtype, 0};
+    ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
+    if (st != CTGN_OK) return st;
+    st = ctgn_solve(h, pose_io, tbe, opts, prior, summary);
+    if (st != CTGN_OK) return st;
+    return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
+}
+
+// ---------------------------------------------------------------------------------------- misc
+ctgn_status ctgn_set_stream(ctgn_handle h, void *stream) {
+    NEED_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = static_cast<hipStream_t>(stream);
+    h->own_stream = false;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_get_stream(ctgn_handle h, void **stream) {
+    NEED_DEVICE(h);
+    if (!stream) return CTGN_ERR_INVALID_ARGUMENT;
+    *stream = h->stream;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_debug(ctgn_handle h, int32_t enable) {
+    NEED_DEVICE(h);
+    h->debug = enable != 0;
+    return ensure_debug(h);
+}
+
+ctgn_status ctgn_get_debug(ctgn_handle h, int32_t *nnb, double *normal, double *a2d, double *farthest, uint8_t *used, size_t n) {
+    NEED_DEVICE(h);
+    if (!h->debug || !h->d_nnb) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "debug capture is off (ctgn_set_debug)");
+    if (n > (size_t) h->n_kp) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (nnb) HIPCHK(h, hipMemcpy(nnb, h->d_nnb, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (normal) HIPCHK(h, hipMemcpy(normal, h->d_normal, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (a2d) HIPCHK(h, hipMemcpy(a2d, h->d_a2d, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (farthest) HIPCHK(h, hipMemcpy(farthest, h->d_far, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (used) HIPCHK(h, hipMemcpy(used, h->d_used, n, hipMemcpyDeviceToHost));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_get_system(ctgn_handle h, double out[CTGN_SYSTEM_DOUBLES]) {
+    NEED_DEVICE(h);
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d_sys, SYS_N * sizeof(double), hipMemcpyDeviceToHost));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *probed, uint64_t *hit, uint64_t *points) {
+    NEED_DEVICE(h);
+    MapView mv;
+    ctgn_status st = make_map_view(h, -1.0, &mv);
+    if (st != CTGN_OK) return st;
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, sizeof(Counters), h->stream));
+    if (h->n_kp > 0) {
+        const int grid = std::max(1, std::min((h->n_kp + 255) / 256, 2048));
+        hipLaunchKernelGGL(k_count_traffic, dim3(grid), dim3(256), 0, h->stream, mv, kp_view(h), h->d_counters);
+        HIPCHK(h, hipGetLastError());
+    }
+    Counters c;
+    HIPCHK(h, hipMemcpyAsync(&c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (probed) *probed = c.probed;
+    if (hit) *hit = c.hit;
+    if (points) *points = c.points;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_profiling(ctgn_handle h, int32_t enable) {
+    NEED_DEVICE(h);
+    h->profiling = enable != 0;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_ms, int32_t *launches, int32_t reset) {
+    NEED_DEVICE(h);
+    if (avg_ms) *avg_ms = h->acc_launches ? h->acc_ms / h->acc_launches : 0.0;
+    if (launches) *launches = h->acc_launches;
+    if (reset) { h->acc_ms = 0.0; h->acc_launches = 0; }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant) {
+    if (!h || variant < 0 || variant > 2) return CTGN_ERR_INVALID_ARGUMENT;
+    h->variant = variant;
+    return CTGN_OK;
+}
+
+}  // extern "C"

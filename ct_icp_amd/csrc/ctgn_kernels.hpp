@@ -1,0 +1,818 @@
+// ctgn_kernels.hpp — gfx950 (CDNA4, wave64) kernels of the Gauss–Newton CT-ICP path.
+//
+// One GN iteration of ct_icp::CT_ICP_Registration::DoRegisterGaussNewton (reference
+// src/ct_icp/ct_icp.cpp:745-981) is two launches on one stream, with no host synchronisation:
+//
+//   k_accumulate_*   per keypoint: [re-transform with the current pose, :964-966] -> voxel-hash neighbour
+//                    search (include/ct_icp/map.h:449-514) -> mean/covariance -> normal + a2D
+//                    (include/SlamCore/experimental/neighborhood.h:225-257,285-316) -> gates, residual,
+//                    12-vector u (:782-841) -> per-block packed sum of u u^T | -u r | count (:843-850)
+//   k_reduce_solve   fixed-order sum of the per-block partials -> normalise, motion prior, LDL^T, pose
+//                    update, stop test (:860-962, :978-980); writes the stop flag the next launches read.
+//
+// Two accumulate kernels share everything except the search:
+//   k_accumulate_rows  (default) 16 lanes cooperate on one keypoint, 4 keypoints per wave in flight:
+//                      the 27/125 hash probes of a keypoint are issued by the 16 lanes in parallel, a voxel's
+//                      SoA point block is read as contiguous 8*BLK-byte runs, candidates are compacted into a
+//                      per-row LDS list with ballot/popcount, the k nearest are selected in LDS, and the
+//                      covariance sums are reduced with DPP row butterflies (no LDS, no bpermute).
+//   k_accumulate_lane  one lane per keypoint, sequential insertion list in LDS — the simple restatement used
+//                      to cross-check the row kernel on the GPU (ctgn_set_variant(h, 1)).
+//
+// No MFMA anywhere: the path is gather + tiny fixed-size outer products (BASELINE.json north_star).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ctgn_map.hpp"
+#include "ctgn_math.hpp"
+
+namespace ctgn {
+
+constexpr int SYS_N = 96;            // packed system: 78 upper-tri JtJ | 12 Jtr | count | pad
+constexpr int SYS_USED = 91;
+constexpr int KMAX = 32;             // CTGN_MAX_NEIGHBORS
+constexpr int MAX_PARTIAL_BLOCKS = 2048;
+
+struct MapView {
+    const Slot *slots;
+    const double *blocks;
+    uint32_t mask;
+    int blk;                 // points per block (max_num_points)
+    int nb;                  // sweep half-width (voxel_neighborhood)
+    double resolution;
+    double r2thr;            // radius_sq_threshold(radius)
+};
+
+struct KpView {
+    const double *rx, *ry, *rz, *t;
+    double *wx, *wy, *wz;
+    int n;
+};
+
+struct GnParams {
+    int min_nb, max_nb;
+    double max_dist;
+    double thr_norm;
+    int has_prior;
+    double beta_c, beta_e;
+    double prev_b[3], prev_e[3];
+};
+
+struct GnState {
+    double pose[14];         // begin (qx qy qz qw tx ty tz) | end
+    double tbe[2];
+    double slerp_theta, slerp_sin;
+    int slerp_linear, slerp_negate;
+    double x[12];
+    double step_norm;
+    int iter;                // solves completed
+    int done;                // stop flag: converged, failed or error
+    int failed;              // fewer than 100 keypoints contributed (ct_icp.cpp:860-871)
+    int n_used;
+};
+
+struct DebugView {
+    int *n_nb;
+    double *normal, *a2d, *farthest;
+    uint8_t *used;
+};
+
+struct Counters {
+    unsigned long long probed, hit, points;
+};
+
+// upper-triangular index tables of the packed system
+__constant__ uint8_t c_tri_i[78] = {0,0,0,0,0,0,0,0,0,0,0,0, 1,1,1,1,1,1,1,1,1,1,1, 2,2,2,2,2,2,2,2,2,2, 3,3,3,3,3,3,3,3,3,
+                                    4,4,4,4,4,4,4,4, 5,5,5,5,5,5,5, 6,6,6,6,6,6, 7,7,7,7,7, 8,8,8,8, 9,9,9, 10,10, 11};
+__constant__ uint8_t c_tri_j[78] = {0,1,2,3,4,5,6,7,8,9,10,11, 1,2,3,4,5,6,7,8,9,10,11, 2,3,4,5,6,7,8,9,10,11,
+                                    3,4,5,6,7,8,9,10,11, 4,5,6,7,8,9,10,11, 5,6,7,8,9,10,11, 6,7,8,9,10,11,
+                                    7,8,9,10,11, 8,9,10,11, 9,10,11, 10,11, 11};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Quat st_qb(const GnState *s) { return {s->pose[0], s->pose[1], s->pose[2], s->pose[3]}; }
+__device__ __forceinline__ Quat st_qe(const GnState *s) { return {s->pose[7], s->pose[8], s->pose[9], s->pose[10]}; }
+__device__ __forceinline__ Vec3 st_tb(const GnState *s) { return {s->pose[4], s->pose[5], s->pose[6]}; }
+__device__ __forceinline__ Vec3 st_te(const GnState *s) { return {s->pose[11], s->pose[12], s->pose[13]}; }
+
+// pose_begin.InterpolatePose(pose_end, t) * raw (types.h:453-470, :360-366, :353-357)
+__device__ __forceinline__ Vec3 ct_transform(const GnState *s, double alpha, Vec3 raw) {
+    SlerpPair sp{s->slerp_theta, s->slerp_sin, s->slerp_linear, s->slerp_negate};
+    Quat q = quat_normalized(slerp_eval(st_qb(s), st_qe(s), sp, alpha));
+    Vec3 tb = st_tb(s), te = st_te(s);
+    Vec3 r = quat_rotate(q, raw);
+    double oma = 1.0 - alpha;
+    return {r.x + (oma * tb.x + alpha * te.x), r.y + (oma * tb.y + alpha * te.y), r.z + (oma * tb.z + alpha * te.z)};
+}
+
+// hash lookup: returns block*128 + count (count >= 1) or 0 when the voxel is absent
+__device__ __forceinline__ uint32_t map_lookup(const MapView &m, int vx, int vy, int vz) {
+    uint64_t key = pack_key(vx, vy, vz);
+    uint32_t i = hash_key(key, m.mask);
+    for (;;) {
+        Slot s = m.slots[i];
+        if (s.key == key) return (s.block << 7) | s.count;
+        if (s.key == KEY_EMPTY) return 0u;
+        i = (i + 1) & m.mask;
+    }
+}
+
+__device__ __forceinline__ bool sweep_in_short_range(int k, int nb) {
+    // the reference's `short` sweep counters (map.h:470-472): outside this range its loops never end;
+    // defined here (and in the oracle) as "no neighbours".
+    return (k - nb >= -32768) && (k + nb + 1 <= 32767);
+}
+
+// Gates + residual + 12-vector u for one keypoint (ct_icp.cpp:769-841). n = neighbours kept,
+// S = sum p, SS = sum p p^T (6 unique), q = farthest kept neighbour (the reference's `closest_point`).
+__device__ __forceinline__ bool residual_jacobian(int n, Vec3 S, Sym3 SS, Vec3 q, Vec3 p, Vec3 raw, double alpha,
+                                                  const GnState *st, const GnParams &prm, double u[12], double &r,
+                                                  Vec3 &normal_out, double &a2d_out) {
+    if (n < prm.min_nb || n < 5) return false;               // :769 ; neighborhood.h:227-230
+    double dn = (double) n;
+    Vec3 mu{S.x / dn, S.y / dn, S.z / dn};                   // neighborhood.h:241
+    Sym3 C;                                                  // :242-243
+    C.xx = SS.xx / dn - mu.x * mu.x; C.xy = SS.xy / dn - mu.x * mu.y; C.xz = SS.xz / dn - mu.x * mu.z;
+    C.yy = SS.yy / dn - mu.y * mu.y; C.yz = SS.yz / dn - mu.y * mu.z; C.zz = SS.zz / dn - mu.z * mu.z;
+    Vec3 nrm;
+    double a2d;
+    sym3_normal_a2d(C, nrm, a2d);
+    Vec3 tb = st_tb(st);
+    if (dot(nrm, tb - p) < 0) nrm = Vec3{-nrm.x, -nrm.y, -nrm.z};      // :782-784
+    normal_out = nrm;
+    a2d_out = a2d;
+    double w = a2d * a2d;                                              // :787-788
+    Vec3 m{w * nrm.x, w * nrm.y, w * nrm.z};                           // :789
+    Vec3 d = p - q;
+    double dist = nrm.x * d.x + nrm.y * d.y + nrm.z * d.z;             // :793-795
+    if (!(fabs(dist) < prm.max_dist)) return false;                    // :803
+    r = m.x * d.x + m.y * d.y + m.z * d.z;                             // :805-807
+    Vec3 a = quat_rotate(st_qb(st), raw), e = quat_rotate(st_qe(st), raw);   // :813-816
+    double oma = 1.0 - alpha;
+    u[0] = oma * (a.y * m.z - a.z * m.y); u[1] = oma * (a.z * m.x - a.x * m.z); u[2] = oma * (a.x * m.y - a.y * m.x);
+    u[3] = oma * m.x; u[4] = oma * m.y; u[5] = oma * m.z;
+    u[6] = alpha * (e.y * m.z - e.z * m.y); u[7] = alpha * (e.z * m.x - e.x * m.z); u[8] = alpha * (e.x * m.y - e.y * m.x);
+    u[9] = alpha * m.x; u[10] = alpha * m.y; u[11] = alpha * m.z;
+    return true;
+}
+
+// One entry of the packed system from a 13-double record (u[0..11], r) — entry e of 91.
+__device__ __forceinline__ double sys_entry(const double *rec, int e) {
+    if (e < 78) return rec[c_tri_i[e]] * rec[c_tri_j[e]];
+    if (e < 90) return -rec[e - 78] * rec[12];
+    return 0.0;
+}
+
+// ================================================================================================
+// k_accumulate_lane — one lane per keypoint (cross-check kernel)
+// ================================================================================================
+constexpr int LANE_BLOCK = 128;
+
+// Sequential neighbour search with a sorted insertion list kept in LDS (column `tid` of d2s/ids).
+// Candidates are visited in the reference's order (x-major voxel sweep, insertion order inside a voxel), so
+// "insert after equal keys, replace only if strictly smaller" realises the total order (d2, visit index).
+__device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, double *d2s, uint32_t *ids, int stride,
+                                           Counters *cnt_out) {
+    int kx = voxel_coord(p.x, m.resolution), ky = voxel_coord(p.y, m.resolution), kz = voxel_coord(p.z, m.resolution);
+    if (!(sweep_in_short_range(kx, m.nb) && sweep_in_short_range(ky, m.nb) && sweep_in_short_range(kz, m.nb))) return 0;
+    int n = 0;
+    unsigned long long c_probe = 0, c_hit = 0, c_pts = 0;
+    for (int vx = kx - m.nb; vx <= kx + m.nb; ++vx)
+        for (int vy = ky - m.nb; vy <= ky + m.nb; ++vy)
+            for (int vz = kz - m.nb; vz <= kz + m.nb; ++vz) {
+                uint32_t bc = map_lookup(m, vx, vy, vz);
+                c_probe++;
+                if (!bc) continue;
+                uint32_t block = bc >> 7, count = bc & 127u;
+                c_hit++;
+                c_pts += count;
+                const double *bx = m.blocks + (size_t) block * 3 * m.blk;
+                for (uint32_t i = 0; i < count; ++i) {
+                    double dx = bx[i] - p.x, dy = bx[m.blk + i] - p.y, dz = bx[2 * m.blk + i] - p.z;
+                    double d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 > m.r2thr) continue;                       // map.h:491-493
+                    int pos;
+                    if (n < k) pos = n++;                             // map.h:494-500
+                    else if (d2 < d2s[(k - 1) * stride]) pos = k - 1;
+                    else continue;
+                    while (pos > 0 && d2s[(pos - 1) * stride] > d2) {
+                        d2s[pos * stride] = d2s[(pos - 1) * stride];
+                        ids[pos * stride] = ids[(pos - 1) * stride];
+                        --pos;
+                    }
+                    d2s[pos * stride] = d2;
+                    ids[pos * stride] = block * (uint32_t) m.blk + i;
+                }
+            }
+    if (cnt_out) {
+        atomicAdd(&cnt_out->probed, c_probe);
+        atomicAdd(&cnt_out->hit, c_hit);
+        atomicAdd(&cnt_out->points, c_pts);
+    }
+    return n;
+}
+
+__device__ __forceinline__ Vec3 map_point(const MapView &m, uint32_t id) {
+    uint32_t block = id / (uint32_t) m.blk, i = id - block * (uint32_t) m.blk;
+    const double *bx = m.blocks + (size_t) block * 3 * m.blk;
+    return {bx[i], bx[m.blk + i], bx[2 * m.blk + i]};
+}
+
+__global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                                double *partials, DebugView dbg, int first_iter) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const int k = prm.max_nb;
+    double *d2s = reinterpret_cast<double *>(smem);                        // [k][LANE_BLOCK]
+    uint32_t *ids = reinterpret_cast<uint32_t *>(d2s + (size_t) KMAX * LANE_BLOCK);   // [k][LANE_BLOCK]
+    double *rec = reinterpret_cast<double *>(ids + (size_t) KMAX * LANE_BLOCK);       // [LANE_BLOCK][13]
+    int *wcnt = reinterpret_cast<int *>(rec + (size_t) LANE_BLOCK * 13);               // [LANE_BLOCK/64]
+    double acc = 0.0;
+    const int ntiles = (kp.n + LANE_BLOCK - 1) / LANE_BLOCK;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * LANE_BLOCK + tid;
+        double u[12], r = 0.0;
+        bool used = false;
+        if (i < kp.n) {
+            Vec3 raw{kp.rx[i], kp.ry[i], kp.rz[i]};
+            double alpha = alpha_timestamp(kp.t[i], st->tbe[0], st->tbe[1]);
+            Vec3 p;
+            if (first_iter) {
+                p = Vec3{kp.wx[i], kp.wy[i], kp.wz[i]};                     // ct_icp.cpp:756 (iteration 0 uses the input)
+            } else {
+                p = ct_transform(st, alpha, raw);                          // :964-966 of the previous iteration
+                kp.wx[i] = p.x; kp.wy[i] = p.y; kp.wz[i] = p.z;
+            }
+            int n = lane_search(map, p, k, d2s + tid, ids + tid, LANE_BLOCK, nullptr);
+            Vec3 S{0, 0, 0}, q{0, 0, 0};
+            Sym3 SS{0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < n; ++j) {
+                Vec3 c = map_point(map, ids[j * LANE_BLOCK + tid]);
+                S = S + c;
+                SS.xx += c.x * c.x; SS.xy += c.x * c.y; SS.xz += c.x * c.z;
+                SS.yy += c.y * c.y; SS.yz += c.y * c.z; SS.zz += c.z * c.z;
+                if (j == n - 1) q = c;                                      // farthest kept (map.h:508-513)
+            }
+            Vec3 nrm{0, 0, 0};
+            double a2d = 0.0;
+            used = residual_jacobian(n, S, SS, q, p, raw, alpha, st, prm, u, r, nrm, a2d);
+            if (dbg.n_nb) {
+                dbg.n_nb[i] = n;
+                dbg.normal[3 * i] = nrm.x; dbg.normal[3 * i + 1] = nrm.y; dbg.normal[3 * i + 2] = nrm.z;
+                dbg.a2d[i] = a2d;
+                dbg.farthest[3 * i] = q.x; dbg.farthest[3 * i + 1] = q.y; dbg.farthest[3 * i + 2] = q.z;
+                dbg.used[i] = used ? 1 : 0;
+            }
+        }
+        __syncthreads();                      // everyone is done with the search lists of this tile
+        double *my = rec + tid * 13;
+        for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
+        my[12] = used ? r : 0.0;
+        const unsigned long long ub = __ballot(used);
+        if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(ub);
+        __syncthreads();
+        if (tid < 90) {
+            for (int j = 0; j < LANE_BLOCK; ++j) acc += sys_entry(rec + j * 13, tid);
+        } else if (tid == 90) {
+            for (int w = 0; w < LANE_BLOCK / 64; ++w) acc += (double) wcnt[w];
+        }
+        __syncthreads();
+    }
+    if (tid < SYS_N) partials[(size_t) blockIdx.x * SYS_N + tid] = (tid < SYS_USED) ? acc : 0.0;
+}
+
+inline size_t lane_kernel_smem() {
+    return (size_t) KMAX * LANE_BLOCK * (sizeof(double) + sizeof(uint32_t)) + (size_t) LANE_BLOCK * 13 * sizeof(double) + 64;
+}
+
+// ================================================================================================
+// k_accumulate_rows — 16 lanes per keypoint
+// ================================================================================================
+constexpr int ROW_WAVES = 4;                 // waves per block
+constexpr int ROW_BLOCK = ROW_WAVES * 64;
+constexpr int LCAP = 96;                     // per-row candidate list capacity (>= KMAX + 2*16)
+constexpr int MAXOWN = LCAP / 16;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 16 lanes of a DPP row: xor-1, xor-2 (quad_perm), then half-mirror and mirror, which act
+// as xor-4 / xor-8 once the lanes of a quad / half-row already agree. Fixed order -> deterministic.
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ int row_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+// inclusive prefix sum over the 16 lanes of a row (row_shr with zero fill)
+__device__ __forceinline__ int row_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return v;
+}
+
+// per-row LDS scratch
+template <int OCC>
+struct RowScratch {
+    double d2[LCAP];
+    uint32_t vis[LCAP];       // (occupied-voxel index << 6) | slot : the visit order, and the way back to the point
+    uint32_t occ[OCC];        // block*128 + count of the occupied voxels, in sweep order
+    uint32_t hist[16];
+};
+
+template <int OCC>
+struct WaveScratch {
+    double px[64], py[64], pz[64];     // world point of the tile's keypoints
+    int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
+    union {
+        RowScratch<OCC> row[4];
+        double rec[64 * 13];           // phase D: u[12] | r per keypoint
+    };
+};
+
+// k nearest of the row's list (d2, vis)[0..Ln) under the total order (d2, vis); winners are written back
+// sorted ascending at [0..min(Ln,k)). HIST: first cut the list with a 16-bin histogram of d2 over [0, hi].
+template <int OCC, bool HIST>
+__device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int sub, int row, double hi) {
+    // wave-uniform loop bounds (rows differ): the max over the wave
+    int maxLn = Ln;
+    maxLn = max(maxLn, __shfl_xor(maxLn, 16));
+    maxLn = max(maxLn, __shfl_xor(maxLn, 32));
+    if (maxLn <= k) return Ln;
+    double od2[MAXOWN];
+    uint32_t ovis[MAXOWN];
+#pragma unroll
+    for (int m = 0; m < MAXOWN; ++m) {
+        int e = sub + 16 * m;
+        bool ok = e < Ln;
+        od2[m] = ok ? R.d2[e] : __longlong_as_double(0x7ff0000000000000ll);
+        ovis[m] = ok ? R.vis[e] : 0xffffffffu;
+    }
+    if (HIST) {
+        // 16-bin histogram of d2 over [0, hi]; keep only the bins up to the one where the count reaches k
+        R.hist[sub] = 0;
+        const double scale = hi > 0.0 ? 16.0 / hi : 0.0;
+        int bin[MAXOWN];
+#pragma unroll
+        for (int m = 0; m < MAXOWN; ++m) {
+            int e = sub + 16 * m;
+            int b = (int) (od2[m] * scale);
+            bin[m] = b > 15 ? 15 : b;
+            if (e < Ln && Ln > k) atomicAdd(&R.hist[bin[m]], 1u);
+        }
+        int cum = row_scan_i32((int) R.hist[sub]);
+        unsigned long long reach = __ballot(cum >= k);
+        uint32_t rowmask = (uint32_t) (reach >> (16 * row)) & 0xffffu;
+        int bb = rowmask ? (__ffs(rowmask) - 1) : 15;
+        if (Ln > k) {
+            // stable in-place compaction of the entries with bin <= bb (all owned entries are in registers)
+            int base = 0;
+#pragma unroll
+            for (int m = 0; m < MAXOWN; ++m) {
+                int e = sub + 16 * m;
+                bool keep = (e < Ln) && (bin[m] <= bb);
+                unsigned long long kb = __ballot(keep);
+                uint32_t km = (uint32_t) (kb >> (16 * row)) & 0xffffu;
+                int pos = base + __popc(km & ((1u << sub) - 1u));
+                if (keep) { R.d2[pos] = od2[m]; R.vis[pos] = ovis[m]; }
+                base += __popc(km);
+            }
+            Ln = base;
+        }
+        maxLn = Ln;
+        maxLn = max(maxLn, __shfl_xor(maxLn, 16));
+        maxLn = max(maxLn, __shfl_xor(maxLn, 32));
+#pragma unroll
+        for (int m = 0; m < MAXOWN; ++m) {
+            int e = sub + 16 * m;
+            bool ok = e < Ln;
+            od2[m] = ok ? R.d2[e] : __longlong_as_double(0x7ff0000000000000ll);
+            ovis[m] = ok ? R.vis[e] : 0xffffffffu;
+        }
+    }
+    // rank sort: rank(e) = #{f : key_f < key_e}; ranks are distinct, winners land at their rank
+    int rank[MAXOWN];
+#pragma unroll
+    for (int m = 0; m < MAXOWN; ++m) rank[m] = 0;
+    const int mcount = (maxLn + 15) >> 4;
+    for (int f = 0; f < maxLn; ++f) {
+        bool fv = f < Ln;
+        double fd2 = fv ? R.d2[f] : __longlong_as_double(0x7ff0000000000000ll);
+        uint32_t fvis = fv ? R.vis[f] : 0xffffffffu;
+#pragma unroll
+        for (int m = 0; m < MAXOWN; ++m) {
+            if (m < mcount) rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
+        }
+    }
+    // every row is written back sorted (rows with <= k entries keep them all)
+#pragma unroll
+    for (int m = 0; m < MAXOWN; ++m) {
+        int e = sub + 16 * m;
+        if (e < Ln && rank[m] < k) { R.d2[rank[m]] = od2[m]; R.vis[rank[m]] = ovis[m]; }
+    }
+    return Ln < k ? Ln : k;
+}
+
+// NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection.
+template <int NB, bool HIST>
+__global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                               double *partials, DebugView dbg, int first_iter, int rounds) {
+    constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
+    WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
+    RowScratch<OCC> &R = W.row[row];
+    const int k = prm.max_nb;
+    const int blk = map.blk;
+
+    // sweep offsets of the voxels this lane probes: v = it*16 + sub in x-major order (map.h:470-472)
+    int ox[VIT], oy[VIT], oz[VIT];
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+        int v = it * 16 + sub;
+        ox[it] = v / (S * S) - NB;
+        oy[it] = (v / S) % S - NB;
+        oz[it] = v % S - NB;
+    }
+
+    double acc0 = 0.0, acc1 = 0.0;     // packed-system entries `lane` and `lane + 64`
+    // entry descriptors: e0 = lane (< 78: upper-tri product), e1 = lane + 64 (product | -u_i * r | count | none)
+    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
+    int e1i = 0, e1j = 0, e1kind = 2;          // kind 0: product, 1: -u*r, 2: count / none
+    double e1sign = 1.0;
+    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
+    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; e1sign = -1.0; }
+    const int kp_per_wave = 4 * rounds;
+    const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
+    for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
+        // ---------------- phase A: lane (row, sub < rounds) owns keypoint tile*4*rounds + row*rounds + sub
+        const int my_kp = tile * kp_per_wave + row * rounds + sub;
+        const bool own = (sub < rounds) && (my_kp < kp.n);
+        Vec3 raw{0, 0, 0}, p{0, 0, 0};
+        double alpha = 0.0;
+        int kxv = INT_MIN, kyv = 0, kzv = 0;
+        if (own) {
+            raw = Vec3{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+            alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+            if (first_iter) {
+                p = Vec3{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};
+            } else {
+                p = ct_transform(st, alpha, raw);
+                kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
+            }
+            int a = voxel_coord(p.x, map.resolution), b = voxel_coord(p.y, map.resolution), c = voxel_coord(p.z, map.resolution);
+            if (sweep_in_short_range(a, NB) && sweep_in_short_range(b, NB) && sweep_in_short_range(c, NB)) {
+                kxv = a; kyv = b; kzv = c;
+            }
+        }
+        W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
+        W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
+
+        // results of phase B for the keypoint this lane owns
+        int res_n = 0;
+        Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
+        Sym3 res_SS{0, 0, 0, 0, 0, 0};
+
+        // ---------------- phase B: the row works on the keypoint owned by its lane `r`
+        for (int r = 0; r < rounds; ++r) {
+            const int src = row * 16 + r;
+            const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
+            const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
+            const bool searching = kx != INT_MIN;
+
+            // B1: hash probes, 16 voxels per step, occupied ones compacted in sweep order
+            int occ_n = 0;
+#pragma unroll
+            for (int it = 0; it < VIT; ++it) {
+                const int v = it * 16 + sub;
+                uint32_t bc = 0;
+                if (searching && v < V) bc = map_lookup(map, kx + ox[it], ky + oy[it], kz + oz[it]);
+                unsigned long long fb = __ballot(bc != 0);
+                uint32_t fm = (uint32_t) (fb >> (16 * row)) & 0xffffu;
+                if (bc) R.occ[occ_n + __popc(fm & ((1u << sub) - 1u))] = bc;
+                occ_n += __popc(fm);
+            }
+
+            // B2: stream the occupied voxels' points, keep candidates within the radius (and below the
+            //     current k-th best once one is known) in the row's LDS list
+            int Ln = 0;
+            double kth_d2 = map.r2thr;
+            uint32_t kth_vis = 0xffffffffu;
+            int max_occ = occ_n;
+            max_occ = max(max_occ, __shfl_xor(max_occ, 16));
+            max_occ = max(max_occ, __shfl_xor(max_occ, 32));
+            for (int j = 0; j < max_occ; ++j) {
+                const uint32_t bc = (j < occ_n) ? R.occ[j] : 0u;
+                const uint32_t block = bc >> 7;
+                const int cnt = (int) (bc & 127u);
+                const double *bx = map.blocks + (size_t) block * 3 * blk;
+                int max_cnt = cnt;
+                max_cnt = max(max_cnt, __shfl_xor(max_cnt, 16));
+                max_cnt = max(max_cnt, __shfl_xor(max_cnt, 32));
+                for (int s = 0; s < max_cnt; s += 16) {
+                    const int i = s + sub;
+                    bool pass = false;
+                    double d2 = 0.0;
+                    if (i < cnt) {
+                        double dx = bx[i] - qx, dy = bx[blk + i] - qy, dz = bx[2 * blk + i] - qz;
+                        d2 = dx * dx + dy * dy + dz * dz;
+                        const uint32_t vis = ((uint32_t) j << 6) | (uint32_t) i;
+                        pass = (d2 < kth_d2) || (d2 == kth_d2 && vis < kth_vis);     // kth starts at (r2thr, +inf): d2 <= r2thr
+                    }
+                    unsigned long long pb = __ballot(pass);
+                    uint32_t pm = (uint32_t) (pb >> (16 * row)) & 0xffffu;
+                    if (pass) {
+                        int pos = Ln + __popc(pm & ((1u << sub) - 1u));
+                        R.d2[pos] = d2;
+                        R.vis[pos] = ((uint32_t) j << 6) | (uint32_t) i;
+                    }
+                    Ln += __popc(pm);
+                    if (__any(Ln > LCAP - 16)) {
+                        // list nearly full somewhere in the wave: cut every row back to its k best
+                        Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
+                        if (Ln >= k) { kth_d2 = R.d2[k - 1]; kth_vis = R.vis[k - 1]; }
+                    }
+                }
+            }
+            // B3: final selection -> list sorted ascending, [0..n)
+            Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
+            const int n = Ln;
+            // if the list was never cut it is still in visit order: find the farthest by rank sort too
+            // (row_select returns early when every row has <= k entries) -> sort those rows here.
+            // A list of <= k entries in arbitrary order: the farthest is the max under the total order.
+            // B4: covariance sums + farthest point, reduced over the row with DPP butterflies
+            double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+            // farthest: argmax of (d2, vis) over the kept entries
+            double fd2 = -1.0;
+            uint32_t fvis = 0;
+            double cx[2], cy[2], cz[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int e = sub + 16 * m;
+                cx[m] = cy[m] = cz[m] = 0.0;
+                if (e < n) {
+                    const uint32_t vis = R.vis[e];
+                    const double d2 = R.d2[e];
+                    const uint32_t bc = R.occ[vis >> 6];
+                    const double *pb = map.blocks + (size_t) (bc >> 7) * 3 * blk + (vis & 63u);
+                    const double x = pb[0], y = pb[blk], z = pb[2 * blk];
+                    cx[m] = x; cy[m] = y; cz[m] = z;
+                    sx += x; sy += y; sz += z;
+                    sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
+                    if (d2 > fd2 || (d2 == fd2 && vis > fvis)) { fd2 = d2; fvis = vis; }
+                }
+            }
+            // row argmax of (fd2, fvis): compare-exchange butterflies on the pair
+#define CTGN_ARGMAX_STEP(CTRL)                                                                      \
+            {                                                                                        \
+                double od = dpp_f64<CTRL>(fd2);                                                      \
+                uint32_t ov = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) fvis, CTRL, 0xf, 0xf, false); \
+                if (od > fd2 || (od == fd2 && ov > fvis)) { fd2 = od; fvis = ov; }                   \
+            }
+            CTGN_ARGMAX_STEP(0xB1) CTGN_ARGMAX_STEP(0x4E) CTGN_ARGMAX_STEP(0x141) CTGN_ARGMAX_STEP(0x140)
+#undef CTGN_ARGMAX_STEP
+            double fqx = 0, fqy = 0, fqz = 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int e = sub + 16 * m;
+                if (e < n && R.vis[e] == fvis) { fqx = cx[m]; fqy = cy[m]; fqz = cz[m]; }
+            }
+            sx = row_sum(sx); sy = row_sum(sy); sz = row_sum(sz);
+            sxx = row_sum(sxx); sxy = row_sum(sxy); sxz = row_sum(sxz);
+            syy = row_sum(syy); syz = row_sum(syz); szz = row_sum(szz);
+            fqx = row_sum(fqx); fqy = row_sum(fqy); fqz = row_sum(fqz);       // exactly one lane is non-zero
+            if (sub == r) {
+                res_n = n;
+                res_S = Vec3{sx, sy, sz};
+                res_SS = Sym3{sxx, sxy, sxz, syy, syz, szz};
+                res_q = Vec3{fqx, fqy, fqz};
+            }
+        }
+
+        // ---------------- phase C: lane per keypoint — normal, gates, residual, u
+        double u[12], rr = 0.0;
+        bool used = false;
+        Vec3 nrm{0, 0, 0};
+        double a2d = 0.0;
+        if (own) {
+            used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
+            if (dbg.n_nb) {
+                dbg.n_nb[my_kp] = res_n;
+                dbg.normal[3 * my_kp] = nrm.x; dbg.normal[3 * my_kp + 1] = nrm.y; dbg.normal[3 * my_kp + 2] = nrm.z;
+                dbg.a2d[my_kp] = a2d;
+                dbg.farthest[3 * my_kp] = res_q.x; dbg.farthest[3 * my_kp + 1] = res_q.y; dbg.farthest[3 * my_kp + 2] = res_q.z;
+                dbg.used[my_kp] = used ? 1 : 0;
+            }
+        }
+        // ---------------- phase D: packed u u^T | -u r | count, lanes own entries (LDS-transposed sum)
+        {
+            double *my = W.rec + lane * 13;          // aliases the row scratch: phase B is finished for this wave
+#pragma unroll
+            for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
+            my[12] = used ? rr : 0.0;
+            const unsigned long long ub = __ballot(used);
+            for (int j = 0; j < 64; ++j) {
+                const double *rj = W.rec + j * 13;
+                acc0 += rj[e0i] * rj[e0j];
+                if (e1kind != 2) acc1 += e1sign * rj[e1i] * rj[e1j];
+            }
+            if (e1kind == 2 && lane == 26) acc1 += (double) __popcll(ub);
+        }
+    }
+    // ---------------- block combine: fixed order over the waves
+    __syncthreads();
+    double *comb = reinterpret_cast<double *>(smem);      // [ROW_WAVES][SYS_N]
+    comb[wave * SYS_N + lane] = acc0;
+    if (lane < SYS_N - 64) comb[wave * SYS_N + 64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+    __syncthreads();
+    if (tid < SYS_N) {
+        double s = 0.0;
+        for (int w = 0; w < ROW_WAVES; ++w) s += comb[w * SYS_N + tid];
+        partials[(size_t) blockIdx.x * SYS_N + tid] = s;
+    }
+}
+
+template <int NB>
+inline size_t rows_kernel_smem() {
+    constexpr int S = 2 * NB + 1, V = S * S * S, OCC = (V + 3) & ~3;
+    return sizeof(WaveScratch<OCC>) * ROW_WAVES;
+}
+
+// ================================================================================================
+// k_reduce_solve — partials -> packed system -> (normalise, prior, LDL^T, pose update, stop test)
+//   mode 0: reduce + solve   1: reduce only (multi-GPU: the all-reduce sits in between)   2: solve only
+// ================================================================================================
+__global__ __launch_bounds__(128) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
+                                                      GnParams prm, int mode, int min_used) {
+    __shared__ double s_sys[SYS_N];
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    if (mode != 2) {
+        if (tid < SYS_N) {
+            double s = 0.0;
+            for (int b = 0; b < nblocks; ++b) s += partials[(size_t) b * SYS_N + tid];     // fixed order
+            sys[tid] = s;
+            s_sys[tid] = s;
+        }
+    } else {
+        if (tid < SYS_N) s_sys[tid] = sys[tid];
+    }
+    __syncthreads();
+    if (mode == 1 || tid != 0) return;
+
+    const int n_used = (int) (s_sys[90] + 0.5);
+    st->n_used = n_used;
+    if (n_used < min_used) {              // ct_icp.cpp:860-871 — soft failure, pose untouched
+        st->failed = 1;
+        st->done = 1;
+        return;
+    }
+    double A[144], b[12], x[12];
+    const double dn = (double) n_used;
+    for (int e = 0; e < 78; ++e) {
+        int i = c_tri_i[e], j = c_tri_j[e];
+        double v = s_sys[e] / dn;                                   // :877-882
+        A[12 * i + j] = v;
+        A[12 * j + i] = v;
+    }
+    for (int i = 0; i < 12; ++i) b[i] = s_sys[78 + i] / dn;
+    if (prm.has_prior) {                                            // :885-910
+        for (int c = 0; c < 3; ++c) {
+            double diff_traj = st->pose[4 + c] - st->pose[11 + c];
+            A[13 * (3 + c)] += prm.beta_c;
+            b[3 + c] -= prm.beta_c * diff_traj;
+            double diff_ego = st->pose[11 + c] - st->pose[4 + c] - prm.prev_e[c] + prm.prev_b[c];
+            A[13 * (9 + c)] += prm.beta_e;
+            b[9 + c] -= prm.beta_e * diff_ego;
+        }
+    }
+    ldlt_solve12(A, b, x);                                          // :914
+    double Rb[9], Re[9], Q[9], P[9];
+    euler_rotation(x[0], x[1], x[2], Rb);                           // :916-932
+    euler_rotation(x[6], x[7], x[8], Re);                           // :935-947
+    quat_to_matrix(st_qb(st), Q);
+    mat3_mul(Rb, Q, P);
+    Quat qb = quat_normalized(matrix_to_quat(P));                   // :950-951, :961
+    quat_to_matrix(st_qe(st), Q);
+    mat3_mul(Re, Q, P);
+    Quat qe = quat_normalized(matrix_to_quat(P));                   // :953-954, :962
+    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
+    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
+    for (int c = 0; c < 3; ++c) {
+        st->pose[4 + c] += x[3 + c];                                // :952
+        st->pose[11 + c] += x[9 + c];                               // :955
+    }
+    SlerpPair sp = slerp_prepare(qb, qe);
+    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
+    double nrm = 0.0;
+    for (int i = 0; i < 12; ++i) { nrm += x[i] * x[i]; st->x[i] = x[i]; }
+    nrm = sqrt(nrm);
+    st->step_norm = nrm;
+    st->iter += 1;
+    if (nrm < prm.thr_norm) st->done = 1;                           // :978-980
+}
+
+// Re-transform every keypoint with the final pose (ct_icp.cpp:964-966 of the last executed iteration).
+__global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st) {
+    if (st->failed || st->iter == 0) return;      // failure: world points stay as the failing iteration saw them
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.n; i += gridDim.x * blockDim.x) {
+        Vec3 raw{kp.rx[i], kp.ry[i], kp.rz[i]};
+        double alpha = alpha_timestamp(kp.t[i], st->tbe[0], st->tbe[1]);
+        Vec3 p = ct_transform(st, alpha, raw);
+        kp.wx[i] = p.x; kp.wy[i] = p.y; kp.wz[i] = p.z;
+    }
+}
+
+// GnState initialisation on the device (pose normalisation :716-717 + slerp constants).
+__global__ void k_state_init(GnState *st, const double *pose_in, double tb, double te) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Quat qb = quat_normalized(Quat{pose_in[0], pose_in[1], pose_in[2], pose_in[3]});
+    Quat qe = quat_normalized(Quat{pose_in[7], pose_in[8], pose_in[9], pose_in[10]});
+    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
+    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
+    for (int c = 0; c < 3; ++c) { st->pose[4 + c] = pose_in[4 + c]; st->pose[11 + c] = pose_in[11 + c]; }
+    st->tbe[0] = tb; st->tbe[1] = te;
+    SlerpPair sp = slerp_prepare(qb, qe);
+    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
+    for (int i = 0; i < 12; ++i) st->x[i] = 0.0;
+    st->step_norm = 0.0;
+    st->iter = 0; st->done = 0; st->failed = 0; st->n_used = 0;
+}
+
+// ================================================================================================
+// map maintenance + queries
+// ================================================================================================
+__global__ void k_scatter_slots(Slot *slots, const SlotEdit *edits, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[edits[i].slot] = edits[i].value;     // edits are in log order; duplicates carry increasing
+}                                                         // counts and are resolved on the host (last one wins)
+
+__global__ void k_scatter_points(double *blocks, int blk, const PointEdit *edits, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        PointEdit e = edits[i];
+        double *bx = blocks + (size_t) e.block * 3 * blk;
+        bx[e.index] = e.x; bx[blk + e.index] = e.y; bx[2 * blk + e.index] = e.z;
+    }
+}
+
+// RadiusSearch for a batch of queries (map.h:449-514): farthest-first output, as the reference drains its heap.
+__global__ __launch_bounds__(LANE_BLOCK) void k_radius_search(MapView map, const double *queries, int n, int k,
+                                                              double *out_xyz, int *out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    double *d2s = reinterpret_cast<double *>(smem);
+    uint32_t *ids = reinterpret_cast<uint32_t *>(d2s + (size_t) KMAX * LANE_BLOCK);
+    const int i = blockIdx.x * LANE_BLOCK + tid;
+    if (i >= n) return;
+    Vec3 p{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]};
+    int cnt = lane_search(map, p, k, d2s + tid, ids + tid, LANE_BLOCK, nullptr);
+    out_count[i] = cnt;
+    for (int j = 0; j < cnt; ++j) {
+        Vec3 c = map_point(map, ids[(cnt - 1 - j) * LANE_BLOCK + tid]);
+        double *o = out_xyz + ((size_t) i * k + j) * 3;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+    }
+}
+
+// Counting pass for the roofline: voxels probed / hit, points scanned, at the current world points.
+__global__ __launch_bounds__(256) void k_count_traffic(MapView map, KpView kp, Counters *out) {
+    unsigned long long c_probe = 0, c_hit = 0, c_pts = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.n; i += gridDim.x * blockDim.x) {
+        int kx = voxel_coord(kp.wx[i], map.resolution), ky = voxel_coord(kp.wy[i], map.resolution),
+            kz = voxel_coord(kp.wz[i], map.resolution);
+        if (!(sweep_in_short_range(kx, map.nb) && sweep_in_short_range(ky, map.nb) && sweep_in_short_range(kz, map.nb)))
+            continue;
+        for (int vx = kx - map.nb; vx <= kx + map.nb; ++vx)
+            for (int vy = ky - map.nb; vy <= ky + map.nb; ++vy)
+                for (int vz = kz - map.nb; vz <= kz + map.nb; ++vz) {
+                    uint32_t bc = map_lookup(map, vx, vy, vz);
+                    c_probe++;
+                    if (bc) { c_hit++; c_pts += bc & 127u; }
+                }
+    }
+    atomicAdd(&out->probed, c_probe);
+    atomicAdd(&out->hit, c_hit);
+    atomicAdd(&out->points, c_pts);
+}
+
+}  // namespace ctgn

@@ -1,0 +1,241 @@
+// ctgn_math.hpp — fixed-size double-precision SE(3) / small linear algebra used by the gfx950 kernels and by
+// the host side of libctgn (compiled by hipcc for both). Quaternions are (x, y, z, w), Eigen's coeffs() order.
+//
+// Semantics follow Eigen 3 as used by the reference at
+//   src/ct_icp/ct_icp.cpp:716-717,813-816,914-962 and include/SlamCore/types.h:192-219,353-366,453-470
+// (slerp with the |dot| >= 1-eps linear fallback, rotate = v + w*(2 q_v x v) + q_v x (2 q_v x v),
+//  matrix->quaternion by the trace / largest-diagonal branches, diagonally pivoted LDL^T).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+#define CTGN_HD __host__ __device__ __forceinline__
+
+namespace ctgn {
+
+struct Vec3 {
+    double x, y, z;
+};
+
+CTGN_HD Vec3 v3(double x, double y, double z) { return Vec3{x, y, z}; }
+CTGN_HD Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+CTGN_HD Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+CTGN_HD Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+CTGN_HD double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+CTGN_HD Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct Quat {
+    double x, y, z, w;
+};
+
+CTGN_HD Quat quat_normalized(Quat q) {
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return {q.x / n, q.y / n, q.z / n, q.w / n};
+}
+
+// Eigen QuaternionBase::_transformVector
+CTGN_HD Vec3 quat_rotate(Quat q, Vec3 v) {
+    Vec3 qv{q.x, q.y, q.z};
+    Vec3 uv = cross(qv, v);
+    uv = uv + uv;
+    Vec3 c = cross(qv, uv);
+    return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+
+// Slerp coefficients of Eigen QuaternionBase::slerp for a FIXED pair (a, b): they depend on the pair only
+// through d = a.b, theta = acos(|d|), sin(theta); those are hoisted out of the per-keypoint work.
+struct SlerpPair {
+    double theta;      // acos(|d|)
+    double sin_theta;  // sin(theta)
+    int linear;        // |d| >= 1 - eps  -> scale0 = 1-t, scale1 = t
+    int negate;        // d < 0 -> scale1 = -scale1
+};
+
+CTGN_HD SlerpPair slerp_prepare(Quat a, Quat b) {
+    SlerpPair s;
+    const double one = 1.0 - DBL_EPSILON;
+    double d = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    double ad = fabs(d);
+    s.linear = (ad >= one) ? 1 : 0;
+    s.negate = (d < 0) ? 1 : 0;
+    if (s.linear) {
+        s.theta = 0.0;
+        s.sin_theta = 1.0;
+    } else {
+        s.theta = acos(ad);
+        s.sin_theta = sin(s.theta);
+    }
+    return s;
+}
+
+CTGN_HD Quat slerp_eval(Quat a, Quat b, SlerpPair s, double t) {
+    double s0, s1;
+    if (s.linear) {
+        s0 = 1.0 - t;
+        s1 = t;
+    } else {
+        s0 = sin((1.0 - t) * s.theta) / s.sin_theta;
+        s1 = sin(t * s.theta) / s.sin_theta;
+    }
+    if (s.negate) s1 = -s1;
+    return {s0 * a.x + s1 * b.x, s0 * a.y + s1 * b.y, s0 * a.z + s1 * b.z, s0 * a.w + s1 * b.w};
+}
+
+// TPose::GetAlphaTimestamp (reference include/SlamCore/types.h:192-219): 0 below the min AND above the max.
+CTGN_HD double alpha_timestamp(double t, double t_begin, double t_end) {
+    double lo = fmin(t_begin, t_end), hi = fmax(t_begin, t_end);
+    if (lo > t) return 0.0;
+    if (hi < t) return 0.0;
+    if (lo == hi) return 1.0;
+    return (t - lo) / (hi - lo);
+}
+
+// Eigen toRotationMatrix, row-major.
+CTGN_HD void quat_to_matrix(Quat q, double R[9]) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+// Eigen Quaterniond(Matrix3d).
+CTGN_HD Quat matrix_to_quat(const double R[9]) {
+    double q[4];
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    return {q[0], q[1], q[2], q[3]};
+}
+
+// Rz(gamma) Ry(beta) Rx(alpha) exactly as spelled at reference src/ct_icp/ct_icp.cpp:919-932.
+CTGN_HD void euler_rotation(double al, double be, double ga, double R[9]) {
+    double sa = sin(al), ca = cos(al), sb = sin(be), cb = cos(be), sg = sin(ga), cg = cos(ga);
+    R[0] = cg * cb; R[1] = -sg * ca + cg * sb * sa; R[2] = sg * sa + cg * sb * ca;
+    R[3] = sg * cb; R[4] = cg * ca + sg * sb * sa;  R[5] = -cg * sa + sg * sb * ca;
+    R[6] = -sb;     R[7] = cb * sa;                 R[8] = cb * ca;
+}
+
+CTGN_HD void mat3_mul(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// Smallest-|eigenvalue| eigenvector (the reference's `normal`, V.col(2) of JacobiSVD, neighborhood.h:293-303)
+// and a2D = (sqrt|s1| - sqrt|s2|) / sqrt|s0| (:304-311) of a symmetric 3x3 given by its 6 unique entries.
+// Cyclic Jacobi in registers: every index is a compile-time constant so nothing spills to scratch.
+struct Sym3 {
+    double xx, xy, xz, yy, yz, zz;
+};
+
+#define CTGN_JACOBI_ROT(app, aqq, apq, arp, arq, vp0, vq0, vp1, vq1, vp2, vq2)                       \
+    if (apq != 0.0) {                                                                                \
+        double theta_ = (aqq - app) / (2.0 * apq);                                                   \
+        double t_ = copysign(1.0, theta_) / (fabs(theta_) + sqrt(theta_ * theta_ + 1.0));            \
+        double c_ = 1.0 / sqrt(t_ * t_ + 1.0), s_ = t_ * c_;                                         \
+        app -= t_ * apq;                                                                             \
+        aqq += t_ * apq;                                                                             \
+        apq = 0.0;                                                                                   \
+        double n_rp = c_ * arp - s_ * arq, n_rq = s_ * arp + c_ * arq;                               \
+        arp = n_rp; arq = n_rq;                                                                      \
+        double n0 = c_ * vp0 - s_ * vq0, m0 = s_ * vp0 + c_ * vq0; vp0 = n0; vq0 = m0;              \
+        double n1 = c_ * vp1 - s_ * vq1, m1 = s_ * vp1 + c_ * vq1; vp1 = n1; vq1 = m1;              \
+        double n2 = c_ * vp2 - s_ * vq2, m2 = s_ * vp2 + c_ * vq2; vp2 = n2; vq2 = m2;              \
+    }
+
+CTGN_HD void sym3_normal_a2d(Sym3 c, Vec3 &normal, double &a2d) {
+    double a00 = c.xx, a01 = c.xy, a02 = c.xz, a11 = c.yy, a12 = c.yz, a22 = c.zz;
+    // V columns: (v00,v10,v20) = eigenvector 0, etc.
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        double off = fabs(a01) + fabs(a02) + fabs(a12);
+        double scale = fabs(a00) + fabs(a11) + fabs(a22);
+        if (off <= 1e-300 + 1e-22 * scale) break;
+        // (p,q) = (0,1), r = 2 : arp = a02, arq = a12
+        CTGN_JACOBI_ROT(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21)
+        // (p,q) = (0,2), r = 1 : arp = a01, arq = a12
+        CTGN_JACOBI_ROT(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22)
+        // (p,q) = (1,2), r = 0 : arp = a01, arq = a02
+        CTGN_JACOBI_ROT(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22)
+    }
+    double m0 = fabs(a00), m1 = fabs(a11), m2 = fabs(a22);
+    // singular values = |eigenvalues| sorted descending; the normal belongs to the smallest
+    double smin = m0, smid, smax;
+    Vec3 n{v00, v10, v20};
+    if (m1 < smin) { smin = m1; n = Vec3{v01, v11, v21}; }
+    if (m2 < smin) { smin = m2; n = Vec3{v02, v12, v22}; }
+    smax = fmax(m0, fmax(m1, m2));
+    smid = fmax(fmin(m0, m1), fmin(fmax(m0, m1), m2));   // median of three, exact
+    normal = n;
+    a2d = (sqrt(smid) - sqrt(smin)) / sqrt(smax);
+}
+
+// Diagonally pivoted LDL^T solve of a symmetric 12x12 system (Eigen LDLT::compute + solve, ct_icp.cpp:914).
+// m is the full matrix, row-major, destroyed.
+CTGN_HD void ldlt_solve12(double *m, const double *b, double *x) {
+    const int N = 12;
+    int transp[12];
+    double temp[12];
+    for (int k = 0; k < N; ++k) {
+        int big = k;
+        double best = fabs(m[k * N + k]);
+        for (int i = k + 1; i < N; ++i)
+            if (fabs(m[i * N + i]) > best) { best = fabs(m[i * N + i]); big = i; }
+        transp[k] = big;
+        if (big != k) {
+            for (int j = 0; j < k; ++j) { double t = m[k * N + j]; m[k * N + j] = m[big * N + j]; m[big * N + j] = t; }
+            for (int i = big + 1; i < N; ++i) { double t = m[i * N + k]; m[i * N + k] = m[i * N + big]; m[i * N + big] = t; }
+            for (int i = k + 1; i < big; ++i) { double t = m[i * N + k]; m[i * N + k] = m[big * N + i]; m[big * N + i] = t; }
+            double t = m[k * N + k]; m[k * N + k] = m[big * N + big]; m[big * N + big] = t;
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) temp[j] = m[j * N + j] * m[k * N + j];
+            double acc = 0;
+            for (int j = 0; j < k; ++j) acc += m[k * N + j] * temp[j];
+            m[k * N + k] -= acc;
+            for (int i = k + 1; i < N; ++i) {
+                double a2 = 0;
+                for (int j = 0; j < k; ++j) a2 += m[i * N + j] * temp[j];
+                m[i * N + k] -= a2;
+            }
+        }
+        double akk = m[k * N + k];
+        if (fabs(akk) > 0)
+            for (int i = k + 1; i < N; ++i) m[i * N + k] /= akk;
+    }
+    double y[12];
+    for (int i = 0; i < N; ++i) y[i] = b[i];
+    for (int k = 0; k < N; ++k)
+        if (transp[k] != k) { double t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < i; ++j) y[i] -= m[i * N + j] * y[j];
+    for (int i = 0; i < N; ++i) y[i] = (fabs(m[i * N + i]) > DBL_MIN) ? y[i] / m[i * N + i] : 0.0;
+    for (int i = N - 1; i >= 0; --i)
+        for (int j = i + 1; j < N; ++j) y[i] -= m[j * N + i] * y[j];
+    for (int k = N - 1; k >= 0; --k)
+        if (transp[k] != k) { double t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
+    for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+}  // namespace ctgn

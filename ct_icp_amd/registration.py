@@ -1,0 +1,188 @@
+"""CT_ICP_Registration — host-side mirror of ct_icp::CT_ICP_Registration for `solver: GN`
+(reference include/ct_icp/ct_icp.h:171-215, src/ct_icp/ct_icp.cpp:998-1053). `Register` keeps the reference's
+argument order and in-place semantics: the TrajectoryFrame poses and the keypoints' world points are updated,
+an ICPSummary is returned. The work is done by libctgn (HIP, gfx950); nothing here computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .map import GpuVoxelMap
+from .types import GN, CTICPOptions, ICPSummary, PreviousFrameMotionModel, TrajectoryFrame, WPOINT3D_DTYPE
+
+
+def _view(arr: np.ndarray, offset: int = 0) -> L.View:
+    dt = L.CTGN_F64 if arr.dtype == np.float64 else L.CTGN_F32
+    return L.View(arr.ctypes.data + offset, arr.strides[0], dt, 0)
+
+
+def _c_options(o: CTICPOptions) -> L.Options:
+    return L.Options(o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors, int(o.debug_print),
+                     o.max_dist_to_plane_ct_icp, o.threshold_orientation_norm)
+
+
+def _c_prior(motion_model) -> L.MotionPrior | None:
+    # ct_icp.cpp:885-889: only a PreviousFrameMotionModel contributes
+    if motion_model is None or not isinstance(motion_model, PreviousFrameMotionModel):
+        return None
+    p = L.MotionPrior()
+    p.beta_location_consistency = motion_model.beta_location_consistency
+    p.beta_constant_velocity = motion_model.beta_constant_velocity
+    pf = motion_model.PreviousFrame()
+    for i in range(3):
+        p.previous_begin_tr[i] = float(pf.BeginTr()[i])
+        p.previous_end_tr[i] = float(pf.EndTr()[i])
+    return p
+
+
+def _summary(s: L.Summary) -> ICPSummary:
+    return ICPSummary(success=bool(s.success), num_residuals_used=s.num_residuals_used, num_iters=s.num_iters,
+                      error_log=s.error_log.decode(), duration_total=s.duration_total_ms * 1e-3,
+                      avg_duration_iter=(s.duration_device_ms * 1e-3 / s.num_iters) if s.num_iters else 0.0,
+                      last_step_norm=s.last_step_norm)
+
+
+class CT_ICP_Registration:
+    def __init__(self, options: CTICPOptions | None = None):
+        self._options = options or CTICPOptions(solver=GN)
+
+    def Options(self) -> CTICPOptions:
+        return self._options
+
+    def Register(self, voxel_map: GpuVoxelMap, keypoints: np.ndarray, trajectory_frame: TrajectoryFrame,
+                 motion_model=None, strategy=None) -> ICPSummary:
+        """keypoints: structured array of WPOINT3D_DTYPE (the vector<slam::WPoint3D> overload, ct_icp.cpp:1026-1037).
+        `strategy` is accepted and ignored, as DoRegisterGaussNewton ignores it."""
+        if self._options.solver != GN:
+            raise RuntimeError("Unsupported Solver Type")        # ct_icp.cpp:1022 — only the GN arm lives here
+        if not isinstance(voxel_map, GpuVoxelMap):
+            raise TypeError("Register needs a GpuVoxelMap (the GPU path has no other map backend)")
+        if keypoints.dtype != WPOINT3D_DTYPE:
+            raise TypeError("keypoints must be a WPOINT3D_DTYPE structured array")
+        h = voxel_map.handle
+        n = len(keypoints)
+        raw = L.View(keypoints.ctypes.data + 0, keypoints.strides[0] if n else 64, L.CTGN_F64, 0)
+        ts = L.View(keypoints.ctypes.data + 24, keypoints.strides[0] if n else 64, L.CTGN_F64, 0)
+        pose = np.ascontiguousarray(trajectory_frame.pose14(), dtype=np.float64)
+        tbe = np.array([trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp])
+        opts = _c_options(self._options)
+        prior = _c_prior(motion_model)
+        s = L.Summary()
+        dp = C.POINTER(C.c_double)
+        st = L.lib().ctgn_register(h, raw, keypoints.ctypes.data + 32, keypoints.strides[0] if n else 64, L.CTGN_F64, ts, n,
+                                   pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                                   C.byref(prior) if prior is not None else None, C.byref(s))
+        L.check(h, st)
+        trajectory_frame.set_pose14(pose)
+        return _summary(s)
+
+
+class GnSolver:
+    """Array-level access to the same entry points (resident keypoints, repeated solves, stepwise GN for the
+    sharded multi-GPU mode, introspection). Used by bench.py, ct_icp_amd.distributed and the parity tests."""
+
+    def __init__(self, voxel_map: GpuVoxelMap):
+        self.map = voxel_map
+        self._h = voxel_map.handle
+        self._n = 0
+
+    def set_keypoints(self, raw, world, t):
+        raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+        world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        assert len(raw) == len(world) == len(t)
+        self._n = len(t)
+        L.check(self._h, L.lib().ctgn_set_keypoints(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0),
+                                                   L.View(world.ctypes.data, 24, L.CTGN_F64, 0),
+                                                   L.View(t.ctypes.data, 8, L.CTGN_F64, 0), self._n))
+
+    def solve(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
+        pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        opts, prior, s = _c_options(options), _c_prior(motion_model), L.Summary()
+        dp = C.POINTER(C.c_double)
+        st = L.lib().ctgn_solve(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                                C.byref(prior) if prior is not None else None, C.byref(s))
+        L.check(self._h, st)
+        return pose, _summary(s), s
+
+    def world_points(self) -> np.ndarray:
+        out = np.zeros((self._n, 3))
+        L.check(self._h, L.lib().ctgn_get_world_points(self._h, out.ctypes.data, 24, L.CTGN_F64, self._n))
+        return out
+
+    # ---- stepwise ------------------------------------------------------------------------------------------
+    def gn_begin(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
+        pose = np.ascontiguousarray(pose14, dtype=np.float64)
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        opts, prior = _c_options(options), _c_prior(motion_model)
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_gn_begin(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                                              C.byref(prior) if prior is not None else None))
+
+    def gn_accumulate(self):
+        L.check(self._h, L.lib().ctgn_gn_accumulate(self._h))
+
+    def gn_solve_update(self):
+        L.check(self._h, L.lib().ctgn_gn_solve_update(self._h))
+
+    def gn_system_ptr(self) -> int:
+        p = C.c_void_p()
+        L.check(self._h, L.lib().ctgn_gn_system_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def gn_done(self) -> bool:
+        d = C.c_int32()
+        L.check(self._h, L.lib().ctgn_gn_done(self._h, C.byref(d)))
+        return bool(d.value)
+
+    def gn_end(self):
+        pose, s = np.zeros(14), L.Summary()
+        L.check(self._h, L.lib().ctgn_gn_end(self._h, pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(s)))
+        return pose, _summary(s), s
+
+    # ---- introspection ---------------------------------------------------------------------------------------
+    def set_debug(self, on=True):
+        L.check(self._h, L.lib().ctgn_set_debug(self._h, int(on)))
+
+    def get_debug(self):
+        n = self._n
+        nn = np.zeros(n, dtype=np.int32)
+        normal, a2d, far = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3))
+        used = np.zeros(n, dtype=np.uint8)
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_get_debug(self._h, nn.ctypes.data_as(C.POINTER(C.c_int32)), normal.ctypes.data_as(dp),
+                                               a2d.ctypes.data_as(dp), far.ctypes.data_as(dp),
+                                               used.ctypes.data_as(C.POINTER(C.c_uint8)), n))
+        return dict(n_neighbors=nn, normal=normal, a2d=a2d, farthest=far, used=used.astype(bool))
+
+    def get_system(self):
+        """(A 12x12, b 12, n_used) unpacked from the 96-double packed system of the last accumulate."""
+        s = np.zeros(L.CTGN_SYSTEM_DOUBLES)
+        L.check(self._h, L.lib().ctgn_get_system(self._h, s.ctypes.data_as(C.POINTER(C.c_double))))
+        A = np.zeros((12, 12))
+        iu = np.triu_indices(12)
+        A[iu] = s[:78]
+        A = A + np.triu(A, 1).T
+        return A, s[78:90].copy(), int(round(s[90]))
+
+    def count_traffic(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(self._h, L.lib().ctgn_count_traffic(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_profiling(self, on=True):
+        L.check(self._h, L.lib().ctgn_set_profiling(self._h, int(on)))
+
+    def kernel_timing(self, reset=False):
+        ms, n = C.c_double(), C.c_int32()
+        L.check(self._h, L.lib().ctgn_kernel_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def set_variant(self, v: int):
+        L.check(self._h, L.lib().ctgn_set_variant(self._h, v))
+
+    def set_stream(self, stream_ptr: int):
+        L.check(self._h, L.lib().ctgn_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -1,0 +1,267 @@
+"""Seeded synthetic LiDAR inputs for the parity tests and bench.py (no dataset ships with this image).
+
+Behavioural template: the reference's scene generator (src/SlamCore/experimental/synthetic.cxx — planes,
+lines, spheres sampled per frame along an interpolated trajectory; unseeded there, seeded here) and the
+6-plane box of its integration test (test/integration/testint_utils.h:39-96). Configs follow SURVEY.md
+section 8d: B = HDL-64E over a procedural street, C = HDL-32E with jittery motion, D = Ouster-128-style
+dense scan. Everything is ray-cast, so points lie exactly on the primitives before noise is added, and
+every point's pose is the slerp/lerp interpolation of its frame's begin/end pose — i.e. the scans are
+exactly representable by the continuous-time model the solver fits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import se3
+
+
+# --------------------------------------------------------------------------------------------------
+# Scene = planes (optionally bounded), axis-aligned boxes, vertical cylinders, spheres
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class Scene:
+    planes: np.ndarray      # (P, 4): n.x + d = 0 ; plus bounds in plane_bounds
+    plane_bounds: np.ndarray  # (P, 6): xmin,xmax,ymin,ymax,zmin,zmax of the valid hit region
+    boxes: np.ndarray       # (B, 6): xmin,ymin,zmin,xmax,ymax,zmax
+    cylinders: np.ndarray   # (C, 5): cx, cy, radius, zmin, zmax  (vertical axis)
+    spheres: np.ndarray     # (S, 4): cx, cy, cz, radius
+
+    def raycast(self, origins: np.ndarray, dirs: np.ndarray, max_range: float) -> np.ndarray:
+        """Nearest positive hit distance per ray (np.inf when nothing within max_range)."""
+        n = len(origins)
+        best = np.full(n, np.inf)
+        eps = 1e-6
+        for (a, b, c, d), bd in zip(self.planes, self.plane_bounds):
+            denom = dirs @ np.array([a, b, c])
+            num = -(origins @ np.array([a, b, c]) + d)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = num / denom
+                hit = origins + t[:, None] * dirs
+            ok = (np.abs(denom) > 1e-12) & (t > eps) & (t < best)
+            ok &= (hit[:, 0] >= bd[0]) & (hit[:, 0] <= bd[1]) & (hit[:, 1] >= bd[2]) & (hit[:, 1] <= bd[3]) \
+                  & (hit[:, 2] >= bd[4]) & (hit[:, 2] <= bd[5])
+            best = np.where(ok, t, best)
+        if len(self.boxes):
+            # prune boxes that no ray of this sweep can reach, then slab-test per axis on (rays x boxes) tiles
+            omin, omax = origins.min(axis=0) - max_range, origins.max(axis=0) + max_range
+            keep = np.all(self.boxes[:, 3:6] >= omin, axis=1) & np.all(self.boxes[:, 0:3] <= omax, axis=1)
+            bxs = self.boxes[keep]
+            chunk = max(1, int(3_000_000 // max(1, len(bxs))))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv_all = 1.0 / dirs
+                for s0 in range(0, n, chunk if len(bxs) else n):
+                    if not len(bxs):
+                        break
+                    tmin = None
+                    tmax = None
+                    for ax in range(3):
+                        o = origins[s0:s0 + chunk, ax, None]
+                        inv = inv_all[s0:s0 + chunk, ax, None]
+                        t1 = (bxs[None, :, ax] - o) * inv
+                        t2 = (bxs[None, :, 3 + ax] - o) * inv
+                        lo_, hi_ = np.fmin(t1, t2), np.fmax(t1, t2)
+                        tmin = lo_ if tmin is None else np.fmax(tmin, lo_)
+                        tmax = hi_ if tmax is None else np.fmin(tmax, hi_)
+                    tmin[(tmax < tmin) | (tmin <= eps)] = np.inf
+                    best[s0:s0 + chunk] = np.minimum(best[s0:s0 + chunk], tmin.min(axis=1))
+        for cx, cy, r, z0, z1 in self.cylinders:
+            ox, oy = origins[:, 0] - cx, origins[:, 1] - cy
+            dx, dy = dirs[:, 0], dirs[:, 1]
+            A = dx * dx + dy * dy
+            B = 2 * (ox * dx + oy * dy)
+            Cc = ox * ox + oy * oy - r * r
+            disc = B * B - 4 * A * Cc
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (-B - np.sqrt(np.maximum(disc, 0))) / (2 * A)
+            z = origins[:, 2] + t * dirs[:, 2]
+            ok = (disc > 0) & (A > 1e-12) & (t > eps) & (t < best) & (z >= z0) & (z <= z1)
+            best = np.where(ok, t, best)
+        for cx, cy, cz, r in self.spheres:
+            oc = origins - np.array([cx, cy, cz])
+            B = 2 * np.einsum("ij,ij->i", oc, dirs)
+            Cc = np.einsum("ij,ij->i", oc, oc) - r * r
+            disc = B * B - 4 * Cc
+            t = (-B - np.sqrt(np.maximum(disc, 0))) / 2
+            ok = (disc > 0) & (t > eps) & (t < best)
+            best = np.where(ok, t, best)
+        best[best > max_range] = np.inf
+        return best
+
+
+def _inf_bounds():
+    return [-np.inf, np.inf, -np.inf, np.inf, -np.inf, np.inf]
+
+
+def street_scene(length: float = 400.0, seed: int = 1, half_width=(10.0, 12.0), building_height: float = 12.0) -> Scene:
+    """Procedural street along +x: ground plane z=0, rows of box 'buildings' with staggered
+    fronts and alleys between them (so the along-track direction is observable, as in a real street), parked box
+    'cars', 0.4 m-diameter poles, and two far backstop planes behind the buildings."""
+    rng = np.random.default_rng(seed)
+    back = 18.0
+    planes = [[0, 0, 1, 0.0], [0, 1, 0, -(half_width[0] + back)], [0, 1, 0, half_width[1] + back]]
+    bounds = [_inf_bounds(),
+              [-np.inf, np.inf, -np.inf, np.inf, 0.0, building_height],
+              [-np.inf, np.inf, -np.inf, np.inf, 0.0, building_height]]
+    boxes = []
+    for side, hw in ((1, half_width[0]), (-1, half_width[1])):
+        x = -60.0
+        while x < length + 60.0:
+            w = rng.uniform(6.0, 18.0)
+            front = hw + rng.uniform(0.0, 3.0)
+            depth = rng.uniform(8.0, 14.0)
+            h = rng.uniform(5.0, building_height)
+            if side > 0:
+                boxes.append([x, front, 0.0, x + w, front + depth, h])
+            else:
+                boxes.append([x, -front - depth, 0.0, x + w, -front, h])
+            # a porch / bay window on some fronts
+            if rng.random() < 0.5:
+                bw, bd = rng.uniform(1.5, 4.0), rng.uniform(0.5, 1.5)
+                bx = x + rng.uniform(0.5, max(0.6, w - bw - 0.5))
+                if side > 0:
+                    boxes.append([bx, front - bd, 0.0, bx + bw, front, rng.uniform(2.5, h)])
+                else:
+                    boxes.append([bx, -front, 0.0, bx + bw, -front + bd, rng.uniform(2.5, h)])
+            x += w + (rng.uniform(1.5, 5.0) if rng.random() < 0.6 else 0.0)
+    x = -40.0
+    while x < length + 40.0:       # parked cars
+        side = 1 if rng.random() < 0.5 else -1
+        y = side * rng.uniform(3.0, 5.5)
+        boxes.append([x, y - 0.9, 0.0, x + rng.uniform(3.8, 4.8), y + 0.9, rng.uniform(1.3, 1.7)])
+        x += rng.uniform(6.0, 15.0)
+    cyl = []
+    x = -45.0
+    while x < length + 45.0:       # poles
+        for side in (1, -1):
+            cyl.append([x + rng.uniform(-1, 1), side * rng.uniform(6.5, 8.0), 0.2, 0.0, rng.uniform(4.0, 8.0)])
+        x += 15.0
+    return Scene(np.array(planes, float), np.array(bounds, float), np.array(boxes, float), np.array(cyl, float),
+                 np.zeros((0, 4)))
+
+
+def box_scene(half: float = 10.0, n_spheres: int = 4, seed: int = 20240901) -> Scene:
+    """Closed 6-plane box (reference test/integration/testint_utils.h:39-96) with a few spheres and pillars inside
+    (courtyard-like)."""
+    rng = np.random.default_rng(seed)
+    planes, bounds = [], []
+    for axis in range(3):
+        for sgn in (-1.0, 1.0):
+            n = [0.0, 0.0, 0.0]
+            n[axis] = 1.0
+            planes.append(n + [-sgn * half])
+            bounds.append(_inf_bounds())
+    spheres = [[*rng.uniform(-0.6 * half, 0.6 * half, 3), rng.uniform(0.5, 1.5)] for _ in range(n_spheres)]
+    boxes = []
+    for _ in range(6):
+        c = rng.uniform(-0.8 * half, 0.8 * half, 3)
+        s = rng.uniform(0.5, 2.0, 3)
+        if np.all(np.abs(c) - s > 1.5):   # keep the sensor corridor near the origin free
+            boxes.append([*(c - s), *(c + s)])
+    return Scene(np.array(planes, float), np.array(bounds, float), np.array(boxes, float).reshape(-1, 6),
+                 np.zeros((0, 5)), np.array(spheres, float).reshape(-1, 4))
+
+
+# --------------------------------------------------------------------------------------------------
+# Sensors: unit directions in the sensor frame + relative firing time in [0, 1)
+# --------------------------------------------------------------------------------------------------
+def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps: int = 1):
+    if kind == "hdl64":          # HDL-64E: +2 .. -24.8 deg, ~0.17 deg azimuth -> ~133 k returns
+        elev = np.radians(np.linspace(2.0, -24.8, 64))
+        az_steps = azimuth_steps or 2083
+    elif kind == "hdl32":        # HDL-32E: +10.67 .. -30.67 deg
+        elev = np.radians(np.linspace(10.67, -30.67, 32))
+        az_steps = azimuth_steps or 1800
+    elif kind == "os128":        # Ouster-128 style: +-22.5 deg, 2048 columns, accumulated sub-sweeps
+        elev = np.radians(np.linspace(22.5, -22.5, 128))
+        az_steps = azimuth_steps or 2048
+    else:
+        raise ValueError(kind)
+    cols = az_steps * sweeps
+    # sub-sweeps are offset by a fraction of a column so accumulated scans are denser, not duplicated
+    az = (np.arange(cols) % az_steps + (np.arange(cols) // az_steps) / max(sweeps, 1)) * (2 * np.pi / az_steps)
+    rel_t = np.arange(cols) / cols
+    ce, se_ = np.cos(elev), np.sin(elev)
+    dirs = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se_)], axis=-1)
+    return dirs.reshape(-1, 3), np.repeat(rel_t, len(elev))
+
+
+# --------------------------------------------------------------------------------------------------
+# Trajectory: frame k spans [k*dt, (k+1)*dt]; end pose of frame k == begin pose of frame k+1
+# --------------------------------------------------------------------------------------------------
+def driving_trajectory(num_frames: int, dt: float = 0.1, speed: float = 10.0, yaw_rate: float = 0.1,
+                       height: float = 1.73, jitter: float = 0.0, seed: int = 0, start_x: float = 0.0):
+    """Knot poses (num_frames+1, 7) of a constant-speed, constant-yaw-rate vehicle; optional roll/pitch jitter
+    (config C). Yaw oscillates so the vehicle stays inside the street."""
+    rng = np.random.default_rng(seed)
+    poses = np.zeros((num_frames + 1, 7))
+    x, y, yaw = start_x, 0.0, 0.0
+    for k in range(num_frames + 1):
+        roll, pitch = (rng.normal(0, jitter, 2) if jitter > 0 else (0.0, 0.0))
+        q = se3.quat_mul(se3.quat_from_rotvec([0, 0, yaw]),
+                         se3.quat_mul(se3.quat_from_rotvec([0, pitch, 0]), se3.quat_from_rotvec([roll, 0, 0])))
+        poses[k, 0:4] = se3.quat_normalize(q)
+        poses[k, 4:7] = [x, y, height]
+        x += speed * dt * np.cos(yaw)
+        y += speed * dt * np.sin(yaw)
+        yaw += yaw_rate * dt * np.cos(2 * np.pi * k / 40.0)
+    return poses
+
+
+def frame_pose14(knots: np.ndarray, k: int) -> np.ndarray:
+    return np.concatenate([knots[k], knots[k + 1]])
+
+
+@dataclass
+class Scan:
+    raw: np.ndarray          # (N, 3) sensor-frame points
+    t: np.ndarray            # (N,) absolute timestamps
+    world_gt: np.ndarray     # (N, 3) ground-truth world points
+    pose_gt: np.ndarray      # (14,) begin|end ground-truth pose
+    t_begin_end: np.ndarray  # (2,)
+
+
+def generate_scan(scene: Scene, dirs: np.ndarray, rel_t: np.ndarray, pose14: np.ndarray, t_begin: float,
+                  t_end: float, max_range: float = 100.0, min_range: float = 1.0, noise: float = 0.0,
+                  seed: int = 0) -> Scan:
+    """Ray-cast one sweep with the sensor moving continuously from the begin to the end pose."""
+    rng = np.random.default_rng(seed)
+    alpha = rel_t
+    q = se3.quat_normalize(se3.quat_slerp(pose14[0:4], pose14[7:11], alpha))
+    origin = (1 - alpha)[:, None] * pose14[4:7] + alpha[:, None] * pose14[11:14]
+    wdirs = se3.quat_rotate(q, dirs)
+    rng_hit = scene.raycast(origin, wdirs, max_range)
+    ok = np.isfinite(rng_hit) & (rng_hit > min_range)
+    r = rng_hit[ok]
+    if noise > 0:
+        r = r + rng.normal(0.0, noise, len(r))
+    raw = dirs[ok] * r[:, None]
+    t = t_begin + alpha[ok] * (t_end - t_begin)
+    t = np.clip(t, t_begin, t_end)
+    world = se3.quat_rotate(q[ok], raw) + origin[ok]
+    return Scan(raw, t, world, np.asarray(pose14, float).copy(), np.array([t_begin, t_end]))
+
+
+def grid_sample_indices(points: np.ndarray, voxel_size: float) -> np.ndarray:
+    """Indices kept by the reference's sub_sample_frame (src/ct_icp/ct_icp.cpp:65-83): first point of every
+    voxel, voxel = static_cast<short>(p / size) per axis. Output sorted by first occurrence (the reference's
+    robin_map iteration order is unspecified)."""
+    v = np.trunc(np.asarray(points, float) / voxel_size).astype(np.int64)
+    v = ((v + 32768) % 65536) - 32768      # static_cast<short>
+    key = (v[:, 0] + 32768) * 65536 * 65536 + (v[:, 1] + 32768) * 65536 + (v[:, 2] + 32768)
+    _, first = np.unique(key, return_index=True)
+    return np.sort(first)
+
+
+def perturb_pose(pose14: np.ndarray, rot: float, trans: float, seed: int = 0) -> np.ndarray:
+    """Initial guess = ground truth composed with a small random left rotation / translation per end."""
+    rng = np.random.default_rng(seed)
+    out = np.asarray(pose14, float).copy()
+    for off in (0, 7):
+        rv = rng.normal(size=3)
+        rv *= rot / np.linalg.norm(rv)
+        out[off:off + 4] = se3.quat_normalize(se3.quat_mul(se3.quat_from_rotvec(rv), out[off:off + 4]))
+        tv = rng.normal(size=3)
+        out[off + 4:off + 7] += tv * trans / np.linalg.norm(tv)
+    return out

@@ -1,0 +1,234 @@
+/*
+ * ctgn.h — C ABI of libctgn.so: the MI355X (gfx950) Gauss–Newton CT-ICP registration path.
+ *
+ * This is the drop-in boundary for ONE hot path of jedeschaud/ct_icp:
+ *   ct_icp::CT_ICP_Registration::DoRegisterGaussNewton   (reference src/ct_icp/ct_icp.cpp:709-996)
+ * together with the read side of the local voxel map it queries
+ *   ct_icp::MultipleResolutionVoxelMap::RadiusSearchInPlace (reference include/ct_icp/map.h:449-514)
+ * and the write side needed to keep that map resident on the GPU
+ *   InsertPointInVoxelMap / RemoveElementsFarFromLocation  (reference include/ct_icp/map.h:261-293, 305-322).
+ *
+ * The reference has no C ABI / FFI for this path (it is C++ member calls inside libCT_ICP.so), so the
+ * entry points below are what a maintainer would bind from
+ *   - a `GpuVoxelMap : ct_icp::ISlamMap` (reference include/ct_icp/map.h:14-83) -> ctgn_map_* calls
+ *   - the `case GN:` arm of SELECT_SOLVER (reference src/ct_icp/ct_icp.cpp:1008-1014) -> ctgn_register
+ * INTEGRATION.md shows that binding; ct_icp_amd/cpp/ct_icp_gpu.hpp is the C++ adapter.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; every function returns a ctgn_status
+ *     (0 = ok, <0 = error) and never throws or aborts across the boundary.
+ *   - poses are 7 doubles (qx, qy, qz, qw, tx, ty, tz): Eigen's coeffs() order, the same order as
+ *     slam::TSE3::operator[] (reference include/SlamCore/types.h:378-385).
+ *   - all host buffers are borrowed for the duration of the call only.
+ *   - a handle owns one HIP device + one HIP stream and is NOT re-entrant (the reference's Odometry is
+ *     not thread-safe either, include/ct_icp/odometry.h:275-287).
+ *   - there is NO CPU fallback: every call fails with CTGN_ERR_NO_DEVICE when no gfx950 device exists.
+ */
+#ifndef CTGN_H
+#define CTGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTGN_ABI_VERSION 1
+#define CTGN_MAX_RESOLUTIONS 8
+/* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
+#define CTGN_MIN_KEYPOINTS_USED 100
+/* Packed normal equations: 78 upper-triangular JtJ + 12 Jtr + 1 count, padded to 96 doubles. */
+#define CTGN_SYSTEM_DOUBLES 96
+/* Upper bound of CTICPOptions::max_number_neighbors supported by the kernels. */
+#define CTGN_MAX_NEIGHBORS 32
+
+typedef struct ctgn_context *ctgn_handle;
+
+typedef enum {
+    CTGN_OK = 0,
+    CTGN_ERR_INVALID_ARGUMENT = -1,
+    CTGN_ERR_NO_DEVICE = -2,       /* no HIP device / not gfx950: there is no CPU fallback           */
+    CTGN_ERR_HIP = -3,             /* a HIP runtime call failed; see ctgn_last_error()                */
+    CTGN_ERR_OUT_OF_MEMORY = -4,
+    CTGN_ERR_TIMESTAMP_RANGE = -5, /* a keypoint timestamp lies outside [t_begin, t_end]: the reference
+                                      glog-CHECK-aborts here (include/SlamCore/types.h:456)           */
+    CTGN_ERR_VOXEL_RANGE = -6,     /* voxel coordinate outside the int16 sweep range of the reference
+                                      (`short kxx`, include/ct_icp/map.h:470-472)                     */
+    CTGN_ERR_UNSUPPORTED = -7
+} ctgn_status;
+
+typedef enum { CTGN_F32 = 0, CTGN_F64 = 1 } ctgn_dtype;
+
+/* -------------------------------------------------------------------------------------------------
+ * Map: mirrors ct_icp::MultipleResolutionVoxelMap::Options / ResolutionParam
+ * (reference include/ct_icp/map.h:109-125).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double resolution;                  /* voxel edge (m)                                   */
+    double min_distance_between_points; /* insert only if farther than this from all others */
+    int32_t max_num_points;             /* per-voxel capacity                               */
+    int32_t _pad;
+} ctgn_resolution_param;
+
+typedef struct {
+    int32_t num_resolutions;
+    int32_t device;                     /* HIP device ordinal                                          */
+    double default_radius;              /* radius used by ComputeNeighborhood (map.h:527-530)         */
+    ctgn_resolution_param resolutions[CTGN_MAX_RESOLUTIONS]; /* ascending resolution, as the reference */
+    uint64_t initial_voxel_capacity;    /* 0 = default; tables grow on demand                          */
+} ctgn_map_options;
+
+/* Fills the reference's defaults: {0.2,0.03,50},{0.5,0.1,40},{1.5,0.15,40}, radius 0.8 (map.h:117-125). */
+void ctgn_map_options_default(ctgn_map_options *opts);
+
+/* Create a context (device map + solver workspace). Replaces MakeMapFromOptions (map.h:127-133). */
+ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out);
+void ctgn_destroy(ctgn_handle h);
+const char *ctgn_last_error(ctgn_handle h);          /* valid until the next call on h */
+const char *ctgn_status_string(ctgn_status s);
+int32_t ctgn_abi_version(void);
+
+/* InsertPointCloud on world points (map.h:153-254 -> InsertPointInVoxelMap :261-293), applied to every
+ * resolution. Points are read from a strided view (base + i*stride_bytes -> 3 x dtype).
+ * out_inserted (optional, n bytes): 1 if the point was inserted in at least one resolution
+ * (the reference's `selected_indices`, map.h:196-206). */
+ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride_bytes, ctgn_dtype dtype,
+                            size_t n, uint8_t *out_inserted);
+/* RemoveElementsFarFromLocation (map.h:305-322): drops a voxel iff its FIRST point is farther than
+ * `distance` from `location`. */
+ctgn_status ctgn_map_remove_far(ctgn_handle h, const double location[3], double distance);
+/* ClearMap (map.h:296). */
+ctgn_status ctgn_map_clear(ctgn_handle h);
+/* NumPoints (map.h:341-347): summed over all resolutions, as the reference does. */
+ctgn_status ctgn_map_num_points(ctgn_handle h, uint64_t *out);
+ctgn_status ctgn_map_num_voxels(ctgn_handle h, int32_t resolution_index, uint64_t *out);
+/* SearchParamsFromRadiusSearch (map.h:416-432): which resolution a radius selects and the sweep half-width. */
+ctgn_status ctgn_map_search_params(ctgn_handle h, double radius, int32_t *map_id, double *voxel_resolution,
+                                   int32_t *voxel_neighborhood);
+/* MapAsPointCloud for one resolution (map.h:349-407, xyz only). Call with out=NULL to get the count. */
+ctgn_status ctgn_map_export(ctgn_handle h, int32_t resolution_index, double *out_xyz, uint64_t capacity_points,
+                            uint64_t *out_num_points);
+/* Push pending host-side map edits to the device now (otherwise done lazily by the next query). */
+ctgn_status ctgn_map_sync(ctgn_handle h);
+
+/* ComputeNeighborhoods (map.h:532-541) / RadiusSearch (map.h:516-522) for a batch of queries, ON THE GPU.
+ * Output layout per query i: out_count[i] neighbours, out_xyz[(i*max_num_neighbors + j)*3 ..] for
+ * j < out_count[i], FARTHEST FIRST (the reference drains a max-heap from top(), map.h:508-513).
+ * radius <= 0 selects options.default_radius. */
+ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries_xyz, size_t n, double radius,
+                                   int32_t max_num_neighbors, double *out_xyz, int32_t *out_count);
+
+/* -------------------------------------------------------------------------------------------------
+ * Solver: the GN-relevant fields of ct_icp::CTICPOptions (reference include/ct_icp/ct_icp.h:56-153;
+ * the fields DoRegisterGaussNewton actually reads, src/ct_icp/ct_icp.cpp:727,743,762,803,866,978).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t num_iters_icp;               /* default 5                                   */
+    int32_t min_number_neighbors;        /* default 20                                  */
+    int32_t max_number_neighbors;        /* default 20, <= CTGN_MAX_NEIGHBORS           */
+    int32_t debug_print;                 /* print the soft-failure message to stdout    */
+    double max_dist_to_plane_ct_icp;     /* default 0.3                                 */
+    double threshold_orientation_norm;   /* default 1e-4 (stop on ||x||_2 of all 12)    */
+} ctgn_options;
+
+void ctgn_options_default(ctgn_options *opts);
+
+/* PreviousFrameMotionModel terms (reference src/ct_icp/ct_icp.cpp:885-910,
+ * include/ct_icp/motion_model.h:42-58,72). Pass NULL when the motion model is null or not a
+ * PreviousFrameMotionModel. */
+typedef struct {
+    double beta_location_consistency;    /* ALPHA_C */
+    double beta_constant_velocity;       /* ALPHA_E */
+    double previous_begin_tr[3];         /* PreviousFrame().BeginTr() */
+    double previous_end_tr[3];           /* PreviousFrame().EndTr()   */
+} ctgn_motion_prior;
+
+/* ICPSummary (reference include/ct_icp/ct_icp.h:155-169) + device timings. */
+typedef struct {
+    int32_t success;                     /* ICPSummary::success                                  */
+    int32_t num_residuals_used;          /* keypoints that passed the gates in the last iteration */
+    int32_t num_iters;                   /* GN iterations executed (reference leaves this 0)      */
+    int32_t _pad;
+    double duration_total_ms;            /* host wall time of the call                            */
+    double duration_device_ms;           /* HIP-event time of the iteration loop                  */
+    double last_step_norm;               /* ||x||_2 of the last solve                             */
+    char error_log[256];                 /* ICPSummary::error_log (same text as ct_icp.cpp:862-863) */
+} ctgn_summary;
+
+/* A strided read-only view of N elements, the C image of slam::ProxyView
+ * (reference include/SlamCore/data/view.h:98-116). */
+typedef struct {
+    const void *base;
+    size_t stride_bytes;
+    ctgn_dtype dtype;
+    int32_t _pad;
+} ctgn_view;
+
+/* Upload a keypoint set (raw xyz, world xyz, timestamp) to the device. */
+ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw_xyz, ctgn_view world_xyz, ctgn_view timestamps,
+                               size_t n);
+/* Run the GN loop on the resident keypoints. pose_io = begin(7) | end(7); t_begin_end = dest_timestamp
+ * of begin_pose / end_pose. Replaces DoRegisterGaussNewton (ct_icp.cpp:709-996). */
+ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double t_begin_end[2],
+                       const ctgn_options *opts, const ctgn_motion_prior *prior, ctgn_summary *summary);
+/* Copy the (re-transformed) world points back into a strided host view (ct_icp.cpp:964-966). */
+ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride_bytes, ctgn_dtype dtype,
+                                  size_t n);
+
+/* One-shot drop-in for `case GN:` of SELECT_SOLVER (ct_icp.cpp:1008-1014) =
+ * ctgn_set_keypoints + ctgn_solve + ctgn_get_world_points (world points are rewritten in place). */
+ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw_xyz, void *world_base, size_t world_stride_bytes,
+                          ctgn_dtype world_dtype, ctgn_view timestamps, size_t n, double pose_io[14],
+                          const double t_begin_end[2], const ctgn_options *opts,
+                          const ctgn_motion_prior *prior, ctgn_summary *summary);
+
+/* -------------------------------------------------------------------------------------------------
+ * Stepwise GN (for the keypoint-sharded multi-GPU mode: one all-reduce of the packed system between
+ * accumulate and solve; the library itself never calls a collective).
+ * ---------------------------------------------------------------------------------------------- */
+ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double t_begin_end[2],
+                          const ctgn_options *opts, const ctgn_motion_prior *prior);
+/* Enqueue neighbour search + residual/Jacobian + reduction for the current pose; the packed system
+ * (CTGN_SYSTEM_DOUBLES doubles: 78 JtJ upper | 12 Jtr | count | pad) is left in device memory. */
+ctgn_status ctgn_gn_accumulate(ctgn_handle h);
+/* Device address of the packed system (valid for the life of the handle). */
+ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out_device_ptr);
+/* Enqueue normalise + motion prior + 12x12 solve + pose update + stop test (ct_icp.cpp:877-980). */
+ctgn_status ctgn_gn_solve_update(ctgn_handle h);
+/* Synchronise, re-transform the world points with the final pose, return pose + summary. */
+ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summary);
+/* Non-blocking query of the device-side stop flag of the running GN loop (synchronises the stream). */
+ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done);
+
+/* Use an externally owned HIP stream (e.g. torch's current stream) instead of the handle's own. */
+ctgn_status ctgn_set_stream(ctgn_handle h, void *hip_stream);
+ctgn_status ctgn_get_stream(ctgn_handle h, void **hip_stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * Introspection for tests / measurement.
+ * ---------------------------------------------------------------------------------------------- */
+/* Per-keypoint outputs of the last accumulate pass (host copies; any pointer may be NULL):
+ *   n_neighbors[i]; normal[3i..] (oriented, unit); a2d[i]; farthest[3i..] (the reference's
+ *   `closest_point` = points[0]); used[i] (passed both gates). Requires ctgn_set_debug(h, 1). */
+ctgn_status ctgn_set_debug(ctgn_handle h, int32_t enable);
+ctgn_status ctgn_get_debug(ctgn_handle h, int32_t *n_neighbors, double *normal, double *a2d, double *farthest,
+                           uint8_t *used, size_t n);
+/* Host copy of the packed system of the last accumulate/solve. */
+ctgn_status ctgn_get_system(ctgn_handle h, double out[CTGN_SYSTEM_DOUBLES]);
+/* Counting pass for the roofline: V = voxels probed per keypoint, total map points inside them, summed
+ * over the resident keypoints at their current world positions. */
+ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *voxels_probed, uint64_t *voxels_hit,
+                               uint64_t *points_scanned);
+/* Bracket every accumulate launch with HIP events on the handle's stream (off by default). */
+ctgn_status ctgn_set_profiling(ctgn_handle h, int32_t enable);
+/* Average HIP-event time (ms) of the accumulate kernel over the launches that did work since the last reset. */
+ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t *launches, int32_t reset);
+/* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
+ * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection. Test hook. */
+ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTGN_H */

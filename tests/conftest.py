@@ -1,0 +1,74 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) — run with `pytest -m gpu` on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "gn_small.npz")))
+
+
+def _sphere_pattern(n_az, n_el, el_lim=75.0):
+    el = np.radians(np.linspace(-el_lim, el_lim, n_el))
+    az = np.linspace(0, 2 * np.pi, n_az, endpoint=False)
+    dirs = np.stack([np.outer(np.cos(az), np.cos(el)), np.outer(np.sin(az), np.cos(el)),
+                     np.outer(np.ones_like(az), np.sin(el))], -1).reshape(-1, 3)
+    return dirs, np.repeat(np.arange(n_az) / n_az, n_el)
+
+
+@pytest.fixture(scope="session")
+def box_case():
+    """Config-A-like: closed box + spheres, 0.5 m map, radius 0.8 (125 voxels / query), k = 20."""
+    from ct_icp_amd import se3, synthetic as syn
+    scene = syn.box_scene(8.0, n_spheres=3, seed=20240901)
+    dirs, rel_t = _sphere_pattern(300, 48)
+    knots = np.zeros((8, 7))
+    for j in range(8):
+        knots[j, :4] = se3.quat_from_rotvec(np.array([0.02 * j, -0.015 * j, 0.05 * j]))
+        knots[j, 4:] = [0.12 * j, 0.06 * j, 0.02 * j]
+    scans = [syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), max_range=40.0,
+                               min_range=0.3, noise=0.01, seed=10 + j) for j in range(7)]
+    return dict(scene=scene, knots=knots, scans=scans, resolutions=[(0.5, 0.05, 20)], default_radius=0.8)
+
+
+@pytest.fixture(scope="session")
+def street_case():
+    """Config-B-like (driving profile, reduced azimuth resolution): 0.8 m map x 30 pts, radius 0.75 (27 voxels)."""
+    from ct_icp_amd import synthetic as syn
+    scene = syn.street_scene(200.0, seed=1)
+    dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=700)
+    knots = syn.driving_trajectory(12, seed=0, start_x=20.0)
+    scans = [syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02,
+                               seed=100 + j) for j in range(11)]
+    return dict(scene=scene, knots=knots, scans=scans, resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
+
+
+def build_maps(case, n_map_frames, with_gpu=False, device=0, subsample=None):
+    """Insert the first n_map_frames scans (ground-truth world points) into an oracle map and, optionally, a
+    GpuVoxelMap, through their own insert rules."""
+    from oracle import oracle as orc
+    from ct_icp_amd import synthetic as syn
+    om = orc.Map(resolutions=case["resolutions"], default_radius=case["default_radius"])
+    gm = None
+    if with_gpu:
+        import ct_icp_amd as cia
+        gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in case["resolutions"]],
+                                                    default_radius=case["default_radius"], device=device))
+    for j in range(n_map_frames):
+        pts = case["scans"][j].world_gt
+        if subsample:
+            pts = pts[syn.grid_sample_indices(case["scans"][j].raw, subsample)]
+        om.insert(pts)
+        if gm is not None:
+            gm.InsertPointCloud(pts)
+    return om, gm

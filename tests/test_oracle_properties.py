@@ -1,0 +1,316 @@
+"""CPU tests pinning the oracle (oracle/ctgn_oracle.c).
+
+The reference holds no golden vectors for the GN path (its TEST(CT_ICP, GN) body is empty,
+test/unit/ct_icp/test_ct_icp.cxx:10-12), so the oracle is pinned by
+  (1) the property tests the reference DOES have, re-expressed here with their file:line,
+  (2) golden vectors from an independent NumPy/SciPy derivation (tests/golden/make_golden.py),
+  (3) recovery of a known ground-truth pose on noise-free planes.
+"""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation, Slerp
+
+from oracle import oracle as orc
+from oracle import numpy_check as npc
+from ct_icp_amd import se3, synthetic as syn
+from conftest import build_maps
+
+
+# ---------------------------------------------------------------- (1) reference property tests
+def test_map_one_nn_identity_and_all_points():
+    """reference test/unit/SlamCore/test_map.cxx:25-36: every inserted point is its own nearest neighbour within
+    1e-5, and a huge-radius / huge-k query returns all points (here: all points of the swept voxels)."""
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-2, 2, (300, 3))
+    m = orc.Map(resolutions=[(0.5, 0.0, 60)], default_radius=0.5)
+    kept = m.insert(pts)
+    assert kept.all() and m.num_points() == 300
+    for p in pts[:60]:
+        nn = m.radius_search(p, 0.5, 1)
+        assert len(nn) == 1 and np.linalg.norm(nn[0] - p) < 1e-5
+    got = m.radius_search(np.zeros(3), 100.0, 64)      # sweep = ceil(100/0.5) voxels: covers everything
+    assert len(got) == 64                               # capped by k; all 300 are candidates
+    d = np.linalg.norm(got, axis=1)
+    assert np.all(np.diff(d) <= 0), "neighbours must come back farthest-first (map.h:508-513)"
+    ref = np.sort(np.linalg.norm(pts, axis=1))[:64]
+    assert np.allclose(np.sort(d), ref, rtol=0, atol=0)
+
+
+def test_neighborhood_planar_normal_is_ez():
+    """reference test/unit/SlamCore/test_neighborhood.cxx:40-53: 10 points with z = 1 => |normal . ez| == 1."""
+    rng = np.random.default_rng(1)
+    pts = np.c_[rng.uniform(-1, 1, (10, 2)), np.ones(10)]
+    ok, normal, a2d = orc.neighborhood(pts)
+    assert ok
+    assert abs(abs(normal[2]) - 1.0) < 1e-12
+    assert 0.0 <= a2d <= 1.0
+    ok, _, _ = orc.neighborhood(pts[:4])
+    assert not ok                                      # MinNeighborhoodSize() == 5 (neighborhood.h:184,227)
+
+
+def test_ct_point_to_plane_residual_definition():
+    """reference test/unit/ct_icp/test_cost_functions.cxx:70-105: with random begin/end poses and alpha = 0.3 the CT
+    point-to-plane residual (ref - T(alpha) raw) . n is <= 1e-12 for an on-plane point and >= 1e-3 off-plane."""
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        pose = np.zeros(14)
+        pose[0:4] = se3.quat_normalize(np.array([0, 0, 0, 1.0]) + 0.3 * rng.uniform(-1, 1, 4))
+        pose[7:11] = se3.quat_normalize(np.array([0, 0, 0, 1.0]) + 0.3 * rng.uniform(-1, 1, 4))
+        pose[4:7], pose[11:14] = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        tbe = np.array([0.0, 1.0])
+        raw = rng.uniform(-5, 5, 3)
+        world = orc.transform_points(pose, tbe, [0.3], raw[None])[0]
+        n = se3.quat_normalize(rng.normal(size=3))
+        ref_on = world + np.cross(n, rng.normal(size=3))            # in the plane through `world`
+        assert abs((ref_on - world) @ n) <= 1e-12
+        ref_off = world + 0.01 * n
+        assert abs((ref_off - world) @ n) >= 1e-3
+        # and the interpolation itself is slerp + lerp at alpha = 0.3
+        R = Slerp([0, 1], Rotation.from_quat(np.stack([pose[0:4], pose[7:11]])))([0.3])
+        expect = R.apply(raw)[0] + 0.7 * pose[4:7] + 0.3 * pose[11:14]
+        assert np.allclose(world, expect, atol=1e-12)
+
+
+def test_se3_identities():
+    """reference test/unit/SlamCore/test_types.cxx:20-31,59-87: inverse / compose identities to 1e-10."""
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        q = se3.quat_normalize(rng.normal(size=4))
+        v = rng.normal(size=3)
+        R = orc.quat_to_matrix(q)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-10) and abs(np.linalg.det(R) - 1) < 1e-10
+        assert np.allclose(orc.quat_rotate(q, v), R @ v, atol=1e-12)
+        assert np.allclose(orc.quat_rotate(se3.quat_conj(q), orc.quat_rotate(q, v)), v, atol=1e-10)
+        q2 = orc.matrix_to_quat(R)
+        assert min(np.linalg.norm(q2 - q), np.linalg.norm(q2 + q)) < 1e-12
+        assert np.allclose(Rotation.from_quat(q).as_matrix(), R, atol=1e-12)
+
+
+def test_alpha_timestamp_quirks():
+    """types.h:192-219: 0 below the min, 0 (sic) above the max, 1 when min == max."""
+    assert orc.alpha_timestamp(0.25, 0.0, 1.0) == 0.25
+    assert orc.alpha_timestamp(-0.1, 0.0, 1.0) == 0.0
+    assert orc.alpha_timestamp(1.1, 0.0, 1.0) == 0.0
+    assert orc.alpha_timestamp(2.0, 2.0, 2.0) == 1.0
+    assert orc.alpha_timestamp(0.75, 1.0, 0.0) == 0.75       # min/max, not begin/end
+    for t in (0.0, 0.3, 1.0, 1.5, -2.0):
+        assert orc.alpha_timestamp(t, 0.0, 1.0) == float(se3.alpha_timestamp(t, 0.0, 1.0))
+
+
+def test_voxel_coordinates_truncate_toward_zero():
+    """src/SlamCore/types.cxx:13-20."""
+    assert orc.voxel_coord(-0.3, 0.5) == 0 and orc.voxel_coord(0.3, 0.5) == 0
+    assert orc.voxel_coord(-0.5, 0.5) == -1 and orc.voxel_coord(-0.9999, 0.5) == -1
+    assert orc.voxel_coord(1.6, 0.8) == 2
+
+
+def test_search_params_selection():
+    """map.h:416-432 with the shipped option sets (SURVEY.md section 8 header)."""
+    m = orc.Map()                                         # defaults 0.2/0.5/1.5, radius 0.8
+    assert m.search_params() == (1, 0.5, 2)
+    m = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
+    assert m.search_params() == (0, 0.8, 1)
+    m = orc.Map(resolutions=[(0.5, 0.1, 30), (1.0, 0.1, 30), (2.0, 0.1, 30)], default_radius=0.8)
+    assert m.search_params() == (0, 0.5, 2)
+    assert m.search_params(1.0) == (1, 1.0, 1)
+
+
+def test_insert_rule_and_eviction():
+    """map.h:261-293 (min-distance strictly greater, capacity) and :305-322 (first point decides)."""
+    m = orc.Map(resolutions=[(1.0, 0.1, 3)], default_radius=1.0)
+    pts = np.array([[0.5, 0.5, 0.5], [0.55, 0.5, 0.5], [0.6, 0.5, 0.5], [0.9, 0.5, 0.5], [0.2, 0.2, 0.2], [0.1, 0.9, 0.1]])
+    kept = m.insert(pts)
+    # 2nd is 0.05 away (< 0.1): dropped; 3rd is exactly 0.1 from the 1st in exact arithmetic but 0.0999.. / 0.1000..1 in
+    # floating point — use the oracle's own arithmetic for the expectation
+    d2 = np.sum((pts[2] - pts[0]) ** 2)
+    expect3 = d2 > 0.1 * 0.1
+    assert kept[0] and not kept[1] and kept[2] == expect3 and kept[3]
+    assert m.num_points() == int(kept.sum()) <= 3 + 0      # capacity 3 in the single voxel
+    assert m.num_voxels(0) == 1
+    m.insert(np.array([[10.2, 0.0, 0.0], [10.9, 0.0, 0.0]]))
+    assert m.num_voxels(0) == 2
+    m.remove_far(np.array([0.5, 0.5, 0.5]), 5.0)
+    assert m.num_voxels(0) == 1
+    m.remove_far(np.array([100.0, 0, 0]), 5.0)
+    assert m.num_voxels(0) == 0 and m.num_points() == 0
+
+
+def test_heap_modes_agree_without_ties(box_case):
+    """The libstdc++-heap order (mode 0) and the total order (d^2, visit) the GPU uses (mode 1) give the same
+    neighbour lists when no two candidate distances tie."""
+    om, _ = build_maps(box_case, 4)
+    rng = np.random.default_rng(5)
+    qs = box_case["scans"][4].world_gt[rng.choice(len(box_case["scans"][4].world_gt), 200, replace=False)]
+    for q in qs:
+        a = om.radius_search(q, 0.0, 20, heap_mode=0)
+        b = om.radius_search(q, 0.0, 20, heap_mode=1)
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_short_sweep_range_defined_as_no_neighbours():
+    m = orc.Map(resolutions=[(0.001, 0.0, 10)], default_radius=0.001)
+    p = np.array([40.0, 0.0, 0.0])                     # voxel 40000 > int16
+    m.insert(p[None])
+    assert len(m.radius_search(p, 0.0, 5)) == 0
+
+
+# ---------------------------------------------------------------- numerics vs NumPy / SciPy
+def test_sym_eigen_and_ldlt_against_numpy():
+    rng = np.random.default_rng(6)
+    for _ in range(100):
+        M = rng.normal(size=(3, 3))
+        C = M @ M.T * rng.uniform(1e-4, 1.0)
+        ev, V = orc.sym_eigen3(C)
+        w = np.linalg.eigvalsh(C)[::-1]
+        assert np.allclose(ev, w, rtol=1e-11, atol=1e-15)
+        assert np.allclose(V @ np.diag(ev) @ V.T, C, atol=1e-13)
+    for _ in range(50):
+        J = rng.normal(size=(40, 12))
+        A = J.T @ J / 40 + 1e-3 * np.eye(12)
+        b = rng.normal(size=12)
+        assert np.allclose(orc.ldlt_solve12(A, b), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+
+
+def test_slerp_against_scipy_and_numpy_mirror():
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        a, b = se3.quat_normalize(rng.normal(size=4)), se3.quat_normalize(rng.normal(size=4))
+        for t in (0.0, 0.3, 0.77, 1.0):
+            q = orc.quat_slerp(a, b, t)
+            assert np.allclose(q, se3.quat_slerp(a, b, np.array(t)), atol=1e-15)
+            Rs = Slerp([0, 1], Rotation.from_quat(np.stack([a, b])))([t]).as_matrix()[0]
+            assert np.allclose(orc.quat_to_matrix(se3.quat_normalize(q)), Rs, atol=1e-12)
+    # near-identical quaternions take the linear branch
+    a = se3.quat_normalize(np.array([0.1, 0.2, 0.3, 0.9]))
+    assert np.allclose(orc.quat_slerp(a, a, 0.4), a, atol=1e-15)
+    assert np.allclose(orc.quat_slerp(a, -a, 0.4), a, atol=1e-15)     # d < 0: scale1 negated -> 0.6 a - 0.4 (-a)
+
+
+# ---------------------------------------------------------------- (2) golden vectors
+def _golden_map(g):
+    m = orc.Map(resolutions=[(float(g["resolution"]), float(g["min_dist"]), int(g["max_pts"]))],
+                default_radius=float(g["radius"]))
+    kept = m.insert(g["insert_points"])
+    return m, kept
+
+
+def test_golden_map_insert(golden):
+    m, kept = _golden_map(golden)
+    assert np.array_equal(kept, golden["insert_kept"])
+    got = m.export(0)
+    want = golden["map_points"]
+    assert got.shape == want.shape
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert np.array_equal(key(got), key(want))
+
+
+def test_golden_accumulate(golden):
+    g = golden
+    m, _ = _golden_map(g)
+    opts = orc.Options(num_iters_icp=1, min_number_neighbors=int(g["min_nb"]), max_number_neighbors=int(g["k"]),
+                       max_dist_to_plane_ct_icp=float(g["max_dist"]))
+    A, b, n_used, info = orc.gn_accumulate(m, g["raw"], g["world0"], g["t"], g["pose0"], g["tbe"], opts, debug=True)
+    assert n_used == int(g["n_used"])
+    assert np.array_equal(info["n_neighbors"], g["n_neighbors"])
+    assert np.array_equal(info["used"], g["used"])
+    has = g["n_neighbors"] >= max(int(g["min_nb"]), 5)
+    assert np.array_equal(info["farthest"][has], g["farthest"][has])
+    assert np.allclose(info["normal"][has], g["normal"][has], atol=1e-7)       # eigenvector conditioning ~ eps / gap
+    assert np.allclose(info["a2d"][has], g["a2d"][has], atol=1e-9)
+    assert np.allclose(A, g["A"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(b, g["b"], rtol=1e-8, atol=1e-10)
+
+
+def test_golden_solve_update_and_register(golden):
+    g = golden
+    prior = orc.MotionPrior(float(g["prior_beta"][0]), float(g["prior_beta"][1]), g["prior_prev_b"], g["prior_prev_e"])
+    pose1, x, nrm = orc.gn_solve_update(g["A"], g["b"], int(g["n_used"]), prior, g["pose0"])
+    assert np.allclose(x, g["x"], rtol=1e-8, atol=1e-11)
+    assert np.allclose(pose1, g["pose1"], atol=1e-10)
+    assert abs(nrm - np.linalg.norm(g["x"])) < 1e-10
+    m, _ = _golden_map(g)
+    opts = orc.Options(num_iters_icp=1, min_number_neighbors=int(g["min_nb"]), max_number_neighbors=int(g["k"]),
+                       max_dist_to_plane_ct_icp=float(g["max_dist"]), threshold_orientation_norm=0.0)
+    pose, world, s = orc.register_gn(m, g["raw"], g["world0"], g["t"], g["pose0"], g["tbe"], opts, prior)
+    assert s.success and s.num_iters == 1 and s.num_residuals_used == int(g["n_used"])
+    assert np.allclose(pose, g["pose1"], atol=1e-9)
+    assert np.allclose(world, g["world1"], atol=1e-9)
+
+
+def test_numpy_rederivation_live(box_case):
+    """Same comparison on a fresh (non-golden) input, so the golden file cannot go stale silently."""
+    om, _ = build_maps(box_case, 3)
+    sc = box_case["scans"][3]
+    sel = syn.grid_sample_indices(sc.raw, 1.0)[:120]
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.005, 0.03, seed=1)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    opts = orc.Options(num_iters_icp=1)
+    A, b, n_used, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, opts, debug=True)
+    A2, b2, n2, info2 = npc.gn_accumulate(om.export(0), 0.5, 2, 0.8, raw, world0, t, pose0, sc.t_begin_end)
+    assert n_used == n2 and np.array_equal(info["n_neighbors"], info2["n_neighbors"])
+    assert np.allclose(A, A2, rtol=1e-8, atol=1e-10) and np.allclose(b, b2, rtol=1e-8, atol=1e-10)
+
+
+# ---------------------------------------------------------------- (3) ground-truth recovery
+def test_recovers_ground_truth_pose_on_noise_free_planes():
+    """Noise-free points on the 6 planes of a closed box (reference test/integration/testint_utils.h:39-96):
+    every neighbourhood is exactly planar, so GN must converge to the ground-truth CT pose."""
+    scene = syn.box_scene(6.0, n_spheres=0, seed=1)
+    scene.boxes = scene.boxes[:0]
+    el = np.radians(np.linspace(-70, 70, 40)); az = np.linspace(0, 2 * np.pi, 240, endpoint=False)
+    dirs = np.stack([np.outer(np.cos(az), np.cos(el)), np.outer(np.sin(az), np.cos(el)),
+                     np.outer(np.ones_like(az), np.sin(el))], -1).reshape(-1, 3)
+    rel_t = np.repeat(np.arange(len(az)) / len(az), len(el))
+    knots = np.zeros((7, 7))
+    for j in range(7):
+        knots[j, :4] = se3.quat_from_rotvec(np.array([0.02 * j, -0.03 * j, 0.04 * j]))
+        knots[j, 4:] = [0.1 * j, -0.05 * j, 0.03 * j]
+    m = orc.Map(resolutions=[(0.5, 0.04, 30)], default_radius=0.8)
+    for j in range(5):
+        m.insert(syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), j * 0.1, (j + 1) * 0.1, 30.0, 0.2).world_gt)
+    sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 5), 0.5, 0.6, 30.0, 0.2)
+    sel = syn.grid_sample_indices(sc.raw, 0.6)
+    # keep keypoints whose whole search ball stays on ONE face (>= 1 m from every edge): their neighbourhoods are
+    # exactly planar, so the ground truth is an exact fixed point of the iteration
+    w = np.abs(sc.world_gt[sel])
+    sel = sel[np.sum(w > 6.0 - 1.0, axis=1) == 1]
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.01, 0.05, seed=11)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    opts = orc.Options(num_iters_icp=30, threshold_orientation_norm=1e-13)
+    pose, world, s = orc.register_gn(m, raw, world0, t, pose0, sc.t_begin_end, opts, None)
+    assert s.success and s.num_residuals_used > 500
+    tr_err, rot_err = se3.pose_error(pose, sc.pose_gt)
+    assert tr_err < 1e-8 and rot_err < 1e-8, (tr_err, rot_err)
+    assert np.allclose(world, sc.world_gt[sel], atol=1e-8)
+    # the threaded CPU-N variant solves the same problem (summation order differs only)
+    pose_t, _, s_t = orc.register_gn(m, raw, world0, t, pose0, sc.t_begin_end, opts, None, num_threads=4)
+    assert se3.pose_error(pose_t, pose)[0] < 1e-9 and s_t.num_residuals_used == s.num_residuals_used
+
+
+def test_soft_failure_below_100_keypoints(box_case):
+    """ct_icp.cpp:860-871: fewer than 100 contributing keypoints -> success = false + the reference's message."""
+    om, _ = build_maps(box_case, 3)
+    sc = box_case["scans"][3]
+    raw, t = sc.raw[:50], sc.t[:50]
+    world0 = se3.ct_transform(sc.pose_gt, sc.t_begin_end, t, raw)
+    pose, world, s = orc.register_gn(om, raw, world0, t, sc.pose_gt, sc.t_begin_end, orc.Options())
+    assert not s.success and "not enough keypoints selected in ct-icp" in s.error_log
+    assert np.allclose(pose, sc.pose_gt, atol=1e-15) and np.array_equal(world, world0)
+    with pytest.raises(ValueError):
+        orc.register_gn(om, raw, world0, t + 1.0, sc.pose_gt, sc.t_begin_end, orc.Options())
+
+
+def test_grid_sampling_first_point_per_voxel():
+    """ct_icp.cpp:65-83 and reference test/unit/SlamCore/test_A_grid_sampling.cxx:7-23 (sampled size <= input)."""
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-20, 20, (5000, 3))
+    idx = orc.grid_sampling(pts, 1.5)
+    assert 0 < len(idx) <= len(pts)
+    vox = np.trunc(pts / 1.5).astype(int)
+    seen = {}
+    for i, v in enumerate(map(tuple, vox)):
+        seen.setdefault(v, i)
+    assert sorted(idx.tolist()) == sorted(seen.values())
+    assert np.array_equal(np.sort(idx), syn.grid_sample_indices(pts, 1.5))
