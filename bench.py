@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — registered keypoints/s per Gauss–Newton iteration of the CT-ICP registration path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run, one rank per GPU over RCCL. A "step" is ONE GN iteration (neighbour search + covariance/normal +
+residual/Jacobian + reduction + 12x12 solve + pose update) over the resident keypoint batch. Rank 0 prints one JSON line.
+
+Workload at N = 1: BASELINE.json configs[1] — KITTI-00-like HDL-64E sweep (~130 k returns) over a procedural street,
+driving profile (0.8 m map x 30 pts, radius 0.75 => 27 voxels / query, k = 20), every return used as a keypoint
+(the throughput regime B2 of SURVEY.md section 8d). Inputs are synthetic (no dataset on the box) and already resident
+in HBM when the timed region starts. At N > 1 every rank holds its own ~130 k-keypoint shard of a denser scan of the same
+scene (weak scaling) and the packed normal equations are all-reduced once per iteration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+B_KP, B_SLOT, B_PT = 32, 16, 24    # algorithmic bytes: keypoint record, hash slot, map point (FP64 xyz storage)
+
+
+def make_inputs(rank: int, map_frames: int, cache_dir: str = "/tmp"):
+    """Deterministic config-B inputs: map insert list (world points of `map_frames` preceding sweeps after the 0.5 m
+    frame grid) + the sweep to register. Cached as .npz because ray-casting 21 sweeps in NumPy takes ~30 s."""
+    from ct_icp_amd import synthetic as syn
+    tag = f"ctgn_bench_B_v3_r{rank}_m{map_frames}.npz"
+    path = os.path.join(cache_dir, tag)
+    if os.path.exists(path):
+        d = np.load(path)
+        return {k: d[k] for k in d.files}
+    scene = syn.street_scene(400.0, seed=1)
+    dirs, rel_t = syn.lidar_pattern("hdl64")
+    knots = syn.driving_trajectory(map_frames + 2, seed=0, start_x=20.0)
+    map_pts = []
+    for j in range(map_frames):
+        sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=100 + j)
+        map_pts.append(sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)])
+    j = map_frames
+    # every rank registers the same frame geometry with its own noise realisation (a different shard of a denser scan)
+    sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02,
+                           seed=1000 + 17 * rank)
+    out = dict(map_points=np.concatenate(map_pts), map_counts=np.array([len(m) for m in map_pts]), raw=sc.raw, t=sc.t,
+               pose_gt=sc.pose_gt, tbe=sc.t_begin_end, prev_b=knots[j - 1, 4:7], prev_e=knots[j, 4:7])
+    try:
+        np.savez(path, **out)
+    except OSError:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--map-frames", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
+    args = ap.parse_args()
+
+    import torch
+    import ct_icp_amd as cia
+    from ct_icp_amd import se3, synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    inp = make_inputs(rank, args.map_frames)
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75,
+                                                device=local_rank))
+    gm.InsertPointCloud(inp["map_points"])
+    gm.Sync()
+    raw, t = inp["raw"], inp["t"]
+    n_kp = len(t)
+    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
+    world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
+    mm = cia.PreviousFrameMotionModel()
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([[0, 0, 0, 1], inp["prev_b"], [0, 0, 0, 1], inp["prev_e"]]), 0, 0)
+
+    def options(iters):   # threshold 0: no early stop, exactly `iters` GN iterations
+        return cia.CTICPOptions(solver=cia.GN, num_iters_icp=iters, threshold_orientation_norm=0.0, debug_print=False)
+
+    if world > 1:
+        from ct_icp_amd.distributed import ShardedGnSolver
+        sh = ShardedGnSolver(gm)
+        solver = sh.solver
+        run = lambda iters: sh.solve(pose0, inp["tbe"], options(iters), mm)
+    else:
+        solver = cia.GnSolver(gm)
+        run = lambda iters: solver.solve(pose0, inp["tbe"], options(iters), mm)[:2] + (None,)
+    solver.set_variant(args.variant)
+    solver.set_keypoints(raw, world0, t)                       # inputs resident in HBM before the timed region
+    probed, hit, points = solver.count_traffic()
+    alg_bytes = n_kp * B_KP + probed * B_SLOT + points * B_PT   # per accumulate launch
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        solver.set_keypoints(raw, world0, t)
+        run(args.warmup)
+    solver.set_keypoints(raw, world0, t)
+    solver.set_profiling(True)
+    solver.kernel_timing(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    pose1, summ, _ = run(args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_launches = solver.kernel_timing(reset=True)
+    solver.set_profiling(False)
+    assert summ.success and summ.num_iters == args.steps, summ
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nn = torch.tensor([n_kp], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_kp = int(nn.item())
+    else:
+        total_kp = n_kp
+
+    result = None
+    if rank == 0:
+        value = total_kp * args.steps / dt
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        result = {
+            "metric": "registered keypoints/sec per GN iter", "value": value, "unit": "keypoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config B2: synthetic HDL-64E sweep over procedural street (KITTI-00-like), all returns "
+                                   "as keypoints, driving profile map 0.8 m x 30 pts, radius 0.75 (27 voxels), k=20, "
+                                   f"{args.map_frames} map frames",
+                       "keypoints_per_gpu": n_kp, "keypoints_total": total_kp, "map_points": int(gm.NumPoints()),
+                       "map_voxels": int(gm.NumVoxels(0)), "n_used_last_iter": summ.num_residuals_used,
+                       "parallelism": "single GPU" if world == 1 else f"keypoints sharded x{world}, 1 all-reduce(96 f64)/iter",
+                       "kernel_variant": args.variant},
+            "frames_per_sec_equiv": 1.0 / (dt / args.steps * 5) if dt > 0 else None,   # 5 GN iterations per frame (driving profile)
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_accumulate_rows" if args.variant != 1 else "k_accumulate_lane",
+                         "kernel_ms_avg": kern_ms, "kernel_launches": kern_launches,
+                         "alg_bytes_per_launch": alg_bytes,
+                         "alg_bytes_per_keypoint": alg_bytes / n_kp,
+                         "voxels_probed_per_keypoint": probed / n_kp, "voxels_hit_per_keypoint": hit / n_kp,
+                         "points_scanned_per_keypoint": points / n_kp},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
+            if result["cpu_baseline"]["value"]:
+                result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(inp, pose0, world0, args):
+    """The oracle (a port, not the reference: it cannot be built here) timed on this box's host cores on the same
+    workload: CPU-N = OpenMP over keypoints on all cores, plus the faithful serial CPU-1 the reference actually runs
+    (its GN keypoint loop has no `#pragma omp`, ct_icp.cpp:753)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    om = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
+    om.insert(inp["map_points"])
+    n = len(inp["t"]) if args.cpu_sample <= 0 else min(args.cpu_sample, len(inp["t"]))
+    raw, t, w0 = inp["raw"][:n], inp["t"][:n], world0[:n]
+    prior = orc.MotionPrior(previous_begin_tr=inp["prev_b"], previous_end_tr=inp["prev_e"])
+
+    def timed(threads, iters):
+        o = orc.Options(num_iters_icp=iters, threshold_orientation_norm=0.0)
+        t0 = time.perf_counter()
+        _, _, s = orc.register_gn(om, raw, w0, t, pose0, inp["tbe"], o, prior, heap_mode=0, num_threads=threads)
+        return n * s.num_iters / (time.perf_counter() - t0)
+
+    timed(cores, 1)                                        # warm the caches / OpenMP pool
+    iters_n = 10
+    v_n = timed(cores, iters_n)
+    v_1 = timed(1, 2)
+    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port",
+            "sample": f"oracle GN loop, {n} keypoints x {iters_n} iterations, OpenMP over keypoints on {cores} threads "
+                      f"(same map and sweep as the GPU run)",
+            "single_thread_value": v_1,
+            "single_thread_note": "serial keypoint loop, as the reference executes GN (no OpenMP at ct_icp.cpp:753)"}
+
+
+if __name__ == "__main__":
+    main()

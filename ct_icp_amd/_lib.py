@@ -85,6 +85,7 @@ SYMBOLS = {
     "ctgn_gn_begin": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior)]),
     "ctgn_gn_accumulate": (C.c_int, [_H]),
     "ctgn_gn_system_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "ctgn_gn_set_system_buffer": (C.c_int, [_H, C.c_void_p]),
     "ctgn_gn_solve_update": (C.c_int, [_H]),
     "ctgn_gn_end": (C.c_int, [_H, _dp, C.POINTER(Summary)]),
     "ctgn_gn_done": (C.c_int, [_H, C.POINTER(C.c_int32)]),

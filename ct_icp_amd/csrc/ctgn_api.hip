@@ -50,7 +50,8 @@ struct ctgn_context {
     // solver
     GnState *d_state = nullptr;
     GnState *h_state = nullptr;         // pinned
-    double *d_sys = nullptr;
+    double *d_sys = nullptr;            // packed system in use (own buffer or caller-owned)
+    double *d_sys_own = nullptr;
     double *d_partials = nullptr;
     double *d_pose_in = nullptr;
     double *h_pose_in = nullptr;        // pinned
@@ -406,14 +407,15 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
         h->own_stream = ok;
         ok = ok && hipMalloc(reinterpret_cast<void **>(&h->d_state), sizeof(GnState)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(GnState), hipHostMallocDefault) == hipSuccess &&
-             hipMalloc(reinterpret_cast<void **>(&h->d_sys), SYS_N * sizeof(double)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_sys_own), SYS_N * sizeof(double)) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_partials), (size_t) MAX_PARTIAL_BLOCKS * SYS_N * sizeof(double)) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
              hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
              hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
-             hipMemsetAsync(h->d_sys, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
+             hipMemsetAsync(h->d_sys_own, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
+        h->d_sys = h->d_sys_own;
         // the kernels use up to ~37 KB of dynamic LDS (rows) / 62 KB (lane): allow it explicitly
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate_lane),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
@@ -435,7 +437,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
         if (h->h_state) hipHostFree(h->h_state);
-        if (h->d_sys) hipFree(h->d_sys);
+        if (h->d_sys_own) hipFree(h->d_sys_own);
         if (h->d_partials) hipFree(h->d_partials);
         if (h->d_pose_in) hipFree(h->d_pose_in);
         if (h->h_pose_in) hipHostFree(h->h_pose_in);
@@ -654,6 +656,13 @@ ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out) {
     NEED_DEVICE(h);
     if (!out) return CTGN_ERR_INVALID_ARGUMENT;
     *out = h->d_sys;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_gn_set_system_buffer(ctgn_handle h, void *device_ptr) {
+    NEED_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->d_sys = device_ptr ? static_cast<double *>(device_ptr) : h->d_sys_own;
     return CTGN_OK;
 }
 

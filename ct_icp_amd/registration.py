@@ -133,6 +133,9 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_gn_system_device_ptr(self._h, C.byref(p)))
         return p.value
 
+    def gn_set_system_buffer(self, device_ptr: int | None):
+        L.check(self._h, L.lib().ctgn_gn_set_system_buffer(self._h, C.c_void_p(device_ptr or 0)))
+
     def gn_done(self) -> bool:
         d = C.c_int32()
         L.check(self._h, L.lib().ctgn_gn_done(self._h, C.byref(d)))

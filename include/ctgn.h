@@ -192,8 +192,11 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double t_b
 /* Enqueue neighbour search + residual/Jacobian + reduction for the current pose; the packed system
  * (CTGN_SYSTEM_DOUBLES doubles: 78 JtJ upper | 12 Jtr | count | pad) is left in device memory. */
 ctgn_status ctgn_gn_accumulate(ctgn_handle h);
-/* Device address of the packed system (valid for the life of the handle). */
+/* Device address of the packed system (valid for the life of the handle, or until ctgn_gn_set_system_buffer). */
 ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out_device_ptr);
+/* Make the library keep the packed system in a caller-owned device buffer of CTGN_SYSTEM_DOUBLES doubles (e.g. a
+ * torch tensor that torch.distributed all-reduces in place). NULL restores the handle's own buffer. */
+ctgn_status ctgn_gn_set_system_buffer(ctgn_handle h, void *device_ptr);
 /* Enqueue normalise + motion prior + 12x12 solve + pose update + stop test (ct_icp.cpp:877-980). */
 ctgn_status ctgn_gn_solve_update(ctgn_handle h);
 /* Synchronise, re-transform the world points with the final pose, return pose + summary. */

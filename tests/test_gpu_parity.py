@@ -1,0 +1,325 @@
+"""GPU parity tests (run on an MI355X with `pytest -m gpu`): the HIP path, called through the C ABI of libctgn.so,
+against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): neighbour sets / indices / gate decisions are bit-exact; floating-point results agree
+to the stated SE(3) tolerance of 1e-4 m / 1e-4 rad — the tests assert the much tighter FP64 agreement actually
+expected (1e-9 .. 1e-7), so a drift far below the contractual tolerance is still caught.
+"""
+import numpy as np
+import pytest
+
+import ct_icp_amd as cia
+from ct_icp_amd import _lib as L
+from ct_icp_amd import se3, synthetic as syn
+from oracle import oracle as orc
+from conftest import build_maps
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4          # the stated tolerance
+TIGHT = 1e-8                                   # what FP64 on both sides actually delivers
+
+
+def _keypoints(case, frame, voxel, n_max=None, perturb=(0.005, 0.03), seed=1):
+    sc = case["scans"][frame]
+    sel = syn.grid_sample_indices(sc.raw, voxel)
+    if n_max:
+        sel = sel[:n_max]
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, perturb[0], perturb[1], seed=seed)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    return sc, raw, t, pose0, world0
+
+
+def _prior(case, frame):
+    k = case["knots"]
+    mm = cia.PreviousFrameMotionModel()
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([k[frame - 1], k[frame]]), 0.0, 0.0)
+    op = orc.MotionPrior(previous_begin_tr=k[frame - 1, 4:7], previous_end_tr=k[frame, 4:7])
+    return mm, op
+
+
+def _opts(**kw):
+    d = dict(solver=cia.GN, debug_print=False)
+    d.update(kw)
+    return cia.CTICPOptions(**d)
+
+
+def _oopts(o: cia.CTICPOptions):
+    return orc.Options(o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors, False, o.max_dist_to_plane_ct_icp,
+                       o.threshold_orientation_norm)
+
+
+# ------------------------------------------------------------------------------------------------- neighbour search
+@pytest.mark.parametrize("case_name", ["box_case", "street_case"])
+def test_radius_search_is_bit_exact(case_name, request):
+    case = request.getfixturevalue(case_name)
+    om, gm = build_maps(case, 5, with_gpu=True)
+    rng = np.random.default_rng(0)
+    pts = case["scans"][5].world_gt
+    qs = pts[rng.choice(len(pts), 600, replace=False)] + rng.normal(0, 0.05, (600, 3))
+    got = gm.ComputeNeighborhoods(qs, 20)
+    n_full = 0
+    for q, g in zip(qs, got):
+        want = om.radius_search(q, 0.0, 20, heap_mode=1)
+        assert g.shape == want.shape and np.array_equal(g, want)
+        assert np.array_equal(want, om.radius_search(q, 0.0, 20, heap_mode=0))      # no ties in this data
+        n_full += len(g) == 20
+    assert n_full > 300
+    # 1-NN identity (reference test/unit/SlamCore/test_map.cxx:25-33) through the GPU map
+    mp = gm.MapAsPointCloud(0)
+    sub = mp[rng.choice(len(mp), 300, replace=False)]
+    for q, g in zip(sub, gm.ComputeNeighborhoods(sub, 1)):
+        assert len(g) == 1 and np.array_equal(g[0], q)
+    # explicit radius selects another sweep width
+    r = case["default_radius"] * 0.5
+    for q, g in zip(qs[:50], gm.ComputeNeighborhoods(qs[:50], 12, radius=r)):
+        assert np.array_equal(g, om.radius_search(q, r, 12, heap_mode=1))
+
+
+# ------------------------------------------------------------------------------------------------- one accumulation
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("case_name,voxel", [("box_case", 0.4), ("street_case", 0.6)])
+def test_accumulate_matches_oracle(case_name, voxel, variant, request):
+    case = request.getfixturevalue(case_name)
+    om, gm = build_maps(case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, voxel)
+    assert len(t) > 1500
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_variant(variant)
+    s.set_debug(True)
+    s.set_keypoints(raw, world0, t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
+    dbg = s.get_debug()
+    A, b, n_used = s.get_system()
+    Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=1, debug=True)
+    assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
+    has = info["n_neighbors"] >= max(o.min_number_neighbors, 5)
+    assert has.sum() > 500
+    assert np.array_equal(dbg["farthest"][has], info["farthest"][has])
+    assert np.array_equal(dbg["used"], info["used"])
+    assert n_used == no == summ.num_residuals_used
+    assert np.allclose(dbg["a2d"][has], info["a2d"][has], atol=1e-9)
+    planar = has & (info["a2d"] > 0.2)               # eigenvector conditioning ~ eps / gap: compare where it is defined
+    assert np.abs(dbg["normal"][planar] - info["normal"][planar]).max() < 1e-8
+    scale = np.abs(Ao).max()
+    assert np.abs(A - Ao).max() < 1e-10 * scale and np.abs(b - bo).max() < 1e-10 * max(np.abs(bo).max(), 1e-30) + 1e-14
+    # and the solve that followed
+    pose_o, x_o, _ = orc.gn_solve_update(Ao, bo, no, None, pose0)
+    tr, rot = se3.pose_error(pose1, pose_o)
+    assert tr < TIGHT and rot < TIGHT
+
+
+# ------------------------------------------------------------------------------------------------- full registration
+@pytest.mark.parametrize("case_name,voxel,iters", [("box_case", 0.5, 8), ("street_case", 0.8, 6)])
+def test_register_matches_oracle(case_name, voxel, iters, request):
+    case = request.getfixturevalue(case_name)
+    om, gm = build_maps(case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, voxel)
+    mm, op = _prior(case, 6)
+    o = _opts(num_iters_icp=iters, threshold_orientation_norm=1e-5)
+    kps = np.zeros(len(t), dtype=cia.WPOINT3D_DTYPE)
+    kps["raw_point"], kps["t"], kps["world_point"] = raw, t, world0
+    frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+    summ = cia.CT_ICP_Registration(o).Register(gm, kps, frame, mm)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    assert summ.success and so.success
+    assert summ.num_iters == so.num_iters and summ.num_residuals_used == so.num_residuals_used
+    tr, rot = se3.pose_error(frame.pose14(), pose_o)
+    assert tr < POSE_TOL_M and rot < POSE_TOL_RAD
+    assert tr < 1e-7 and rot < 1e-7, (tr, rot)
+    assert np.abs(kps["world_point"] - world_o).max() < 1e-7
+    assert abs(summ.last_step_norm - so.last_step_norm) < 1e-7
+    # the registration did something useful: closer to the ground truth than the initial guess
+    assert se3.pose_error(frame.pose14(), sc.pose_gt)[0] < se3.pose_error(pose0, sc.pose_gt)[0]
+
+
+def test_golden_vectors_through_the_gpu(golden):
+    g = golden
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(float(g["resolution"]), float(g["min_dist"]),
+                                                                                   int(g["max_pts"]))],
+                                                default_radius=float(g["radius"])))
+    kept = gm.InsertPointCloud(g["insert_points"])
+    assert np.array_equal(kept, g["insert_kept"])
+    s = cia.GnSolver(gm)
+    s.set_debug(True)
+    s.set_keypoints(g["raw"], g["world0"], g["t"])
+    mm = cia.PreviousFrameMotionModel(float(g["prior_beta"][0]), float(g["prior_beta"][1]))
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([[0, 0, 0, 1], g["prior_prev_b"], [0, 0, 0, 1], g["prior_prev_e"]]), 0, 0)
+    o = _opts(num_iters_icp=1, min_number_neighbors=int(g["min_nb"]), max_number_neighbors=int(g["k"]),
+              max_dist_to_plane_ct_icp=float(g["max_dist"]), threshold_orientation_norm=0.0)
+    pose1, summ, _ = s.solve(g["pose0"], g["tbe"], o, mm)
+    dbg = s.get_debug()
+    A, b, n_used = s.get_system()
+    assert n_used == int(g["n_used"]) and np.array_equal(dbg["n_neighbors"], g["n_neighbors"])
+    assert np.array_equal(dbg["used"], g["used"])
+    has = g["n_neighbors"] >= 20
+    assert np.array_equal(dbg["farthest"][has], g["farthest"][has])
+    assert np.allclose(A, g["A"], rtol=1e-8, atol=1e-10) and np.allclose(b, g["b"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(pose1, g["pose1"], atol=1e-9)
+    assert np.allclose(s.world_points(), g["world1"], atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------- edge cases
+def test_soft_failure_and_errors(box_case):
+    om, gm = build_maps(box_case, 4, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 4, 0.5, n_max=60)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, _opts())
+    assert not summ.success and summ.num_iters == 0                      # ct_icp.cpp:860-871
+    assert summ.error_log.startswith("[CT_ICP]Error : not enough keypoints selected in ct-icp !")
+    assert f"Number_of_residuals : {summ.num_residuals_used}" in summ.error_log
+    q0 = se3.quat_normalize(pose0[0:4])
+    assert np.allclose(pose1[4:7], pose0[4:7], atol=0) and np.allclose(pose1[0:4], q0, atol=1e-15)
+    assert np.array_equal(s.world_points(), world0)                      # untouched on failure at iteration 0
+    _, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, orc.Options())
+    assert so.num_residuals_used == summ.num_residuals_used
+    # a timestamp outside [t_begin, t_end]: the reference CHECK-aborts (types.h:456); the ABI returns an error
+    s.set_keypoints(raw, world0, t + 1.0)
+    with pytest.raises(cia.CtgnError) as e:
+        s.solve(pose0, sc.t_begin_end, _opts())
+    assert e.value.status == L.ERR_TIMESTAMP_RANGE
+    # empty keypoint set: soft failure with 0 residuals
+    s.set_keypoints(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))
+    _, summ, _ = s.solve(pose0, sc.t_begin_end, _opts())
+    assert not summ.success and summ.num_residuals_used == 0
+    # empty map
+    gm.ClearMap()
+    s.set_keypoints(raw, world0, t)
+    _, summ, _ = s.solve(pose0, sc.t_begin_end, _opts())
+    assert not summ.success and summ.num_residuals_used == 0
+    with pytest.raises(cia.CtgnError):
+        s.solve(pose0, sc.t_begin_end, _opts(max_number_neighbors=33))
+
+
+def test_float32_strided_keypoints(box_case):
+    """ProxyView semantics (include/SlamCore/data/view.h:98-116): FLOAT32 fields with arbitrary stride are cast."""
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.6)
+    rec = np.zeros(len(t), dtype=[("raw", "<f4", 3), ("junk", "<u2"), ("t", "<f8"), ("world", "<f4", 3)])
+    rec["raw"], rec["t"], rec["world"] = raw, t, world0
+    lib = L.lib()
+    h = gm.handle
+    import ctypes as C
+    o = L.Options(4, 20, 20, 0, 0.3, 0.0)
+    summ = L.Summary()
+    pose = pose0.copy()
+    tbe = np.ascontiguousarray(sc.t_begin_end)
+    dp = C.POINTER(C.c_double)
+    st = lib.ctgn_register(h, L.View(rec.ctypes.data + rec.dtype.fields["raw"][1], rec.strides[0], L.CTGN_F32, 0),
+                           rec.ctypes.data + rec.dtype.fields["world"][1], rec.strides[0], L.CTGN_F32,
+                           L.View(rec.ctypes.data + rec.dtype.fields["t"][1], rec.strides[0], L.CTGN_F64, 0), len(t),
+                           pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(o), None, C.byref(summ))
+    L.check(h, st)
+    raw32, world32 = rec["raw"].astype(np.float64), world0.astype(np.float32).astype(np.float64)
+    pose_o, world_o, so = orc.register_gn(om, raw.astype(np.float32).astype(np.float64), world32, t, pose0, sc.t_begin_end,
+                                          orc.Options(4, 20, 20, False, 0.3, 0.0), None, heap_mode=1)
+    assert summ.success and summ.num_residuals_used == so.num_residuals_used
+    tr, rot = se3.pose_error(pose, pose_o)
+    assert tr < 1e-7 and rot < 1e-7
+    assert np.abs(rec["world"].astype(np.float64) - world_o).max() < 1e-5          # float32 write-back
+
+
+def test_incremental_map_updates_reach_the_device(street_case):
+    """Insert / evict after the map is resident: the delta upload (scatter of logged edits) must leave the device map
+    identical to a map built from scratch — checked through bit-exact neighbour lists."""
+    case = street_case
+    om, gm = build_maps(case, 3, with_gpu=True)
+    rng = np.random.default_rng(3)
+    for j in range(3, 9):
+        qs = case["scans"][j].world_gt[rng.choice(len(case["scans"][j].world_gt), 200, replace=False)]
+        for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):            # forces residency / sync before the edits
+            assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+        pts = case["scans"][j].world_gt
+        gm.InsertPointCloud(pts)
+        om.insert(pts)
+        loc = case["scans"][j].pose_gt[11:14]
+        gm.RemoveElementsFarFromLocation(loc, 30.0)
+        om.remove_far(loc, 30.0)
+        assert gm.NumPoints() == om.num_points()
+    qs = case["scans"][9].world_gt[rng.choice(len(case["scans"][9].world_gt), 500, replace=False)]
+    for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):
+        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+
+
+def test_stepwise_api_equals_fused_loop(box_case):
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.5)
+    o = _opts(num_iters_icp=4, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    pose_f, summ_f, _ = s.solve(pose0, sc.t_begin_end, o)
+    w_f = s.world_points()
+    s.set_keypoints(raw, world0, t)
+    s.gn_begin(pose0, sc.t_begin_end, o)
+    for _ in range(4):
+        s.gn_accumulate()
+        s.gn_solve_update()
+    assert not s.gn_done()
+    pose_s, summ_s, _ = s.gn_end()
+    assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, s.world_points())       # deterministic reductions
+    assert summ_s.num_iters == summ_f.num_iters == 4
+
+
+# ------------------------------------------------------------------------------------------------- full-size properties
+@pytest.fixture(scope="module")
+def config_b_full():
+    """BASELINE.json configs[1] at full size: HDL-64E sweep (~130 k returns) over the procedural street, driving
+    profile map (0.8 m x 30 pts, radius 0.75), 10 map frames."""
+    scene = syn.street_scene(300.0, seed=1)
+    dirs, rel_t = syn.lidar_pattern("hdl64")
+    knots = syn.driving_trajectory(12, seed=0, start_x=20.0)
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75))
+    for j in range(10):
+        sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=100 + j)
+        gm.InsertPointCloud(sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)])
+    sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 10), 1.0, 1.1, noise=0.02, seed=110)
+    return gm, sc
+
+
+def test_full_size_properties(config_b_full):
+    gm, sc = config_b_full
+    n = len(sc.t)
+    assert n > 100_000
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=4)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t, sc.raw)
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    results = {}
+    for variant in (0, 1, 2):
+        s.set_variant(variant)
+        s.set_keypoints(sc.raw, world0, sc.t)
+        pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
+        results[variant] = (s.get_system(), pose1, summ.num_residuals_used)
+    (A0, b0, n0), p0, _ = results[0]
+    assert n0 > 20_000
+    for v in (1, 2):                                   # two independent search kernels agree at full size
+        (A, b, nu), p, _ = results[v]
+        assert nu == n0
+        assert np.abs(A - A0).max() < 1e-9 * np.abs(A0).max() and np.abs(b - b0).max() < 1e-9 * np.abs(b0).max() + 1e-13
+        assert se3.pose_error(p, p0)[0] < 1e-9
+    # permutation invariance: the sum over keypoints does not depend on their order (up to FP64 rounding)
+    perm = np.random.default_rng(0).permutation(n)
+    s.set_variant(0)
+    s.set_keypoints(sc.raw[perm], world0[perm], sc.t[perm])
+    pose_p, summ_p, _ = s.solve(pose0, sc.t_begin_end, o)
+    Ap, bp, npn = s.get_system()
+    assert npn == n0 and np.abs(Ap - A0).max() < 1e-9 * np.abs(A0).max()
+    wp = s.world_points()
+    # re-transform property: the returned world points are T(pose) raw for the returned pose
+    assert np.abs(wp - se3.ct_transform(pose_p, sc.t_begin_end, sc.t[perm], sc.raw[perm])).max() < 1e-9
+    # linearity of the packed system: accumulating two halves separately and adding equals the whole
+    half = n // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, n)):
+        s.set_keypoints(sc.raw[sl], world0[sl], sc.t[sl])
+        s.solve(pose0, sc.t_begin_end, o)
+        parts.append(s.get_system())
+    assert parts[0][2] + parts[1][2] == n0
+    assert np.abs(parts[0][0] + parts[1][0] - A0).max() < 1e-9 * np.abs(A0).max()
+    # traffic counters are exactly 27 probes per in-range keypoint
+    s.set_keypoints(sc.raw, world0, sc.t)
+    probed, hit, pts = s.count_traffic()
+    assert probed == 27 * n and 0 < hit < probed and pts > 20 * n
