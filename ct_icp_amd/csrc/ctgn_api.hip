@@ -35,6 +35,7 @@ struct EventPair {
 
 struct ctgn_context {
     int device = -1;                    // -1: host-only map mirror, every device entry point fails
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     ctgn_map_options opts{};
@@ -44,6 +45,7 @@ struct ctgn_context {
     // keypoints: one device allocation of 7 arrays [rx ry rz t wx wy wz] x cap_kp
     int n_kp = 0, cap_kp = 0;
     double *d_kp = nullptr;
+    double *d_res = nullptr;            // [cap_kp][13] row-phase -> lane-phase hand-over records
     double *h_kp = nullptr;             // pinned staging, same layout
     double t_min = 0, t_max = 0;
 
@@ -83,7 +85,8 @@ struct ctgn_context {
     double acc_ms = 0.0;
     int acc_launches = 0;
 
-    int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist
+    int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
+    unsigned long long *d_prof = nullptr;
     std::string last_error;
 };
 
@@ -146,6 +149,8 @@ ctgn_status sync_level(ctgn_handle h, int li) {
     DeviceLevel &D = h->dlevels[li];
     const size_t nslots = (size_t) L.mask + 1;
     const size_t nblk_doubles = (size_t) L.nblocks_cap * 3 * L.blk;
+    if ((size_t) L.nblocks_used * 3 * L.blk * sizeof(double) >= ((size_t) 1 << 32))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB (32-bit block offsets in the kernels)");
     bool full = L.need_full_upload || !D.resident;
     if (!full && L.slot_edits.size() * 4 > nslots) full = true;
     if (full) {
@@ -229,6 +234,7 @@ KpView kp_view(ctgn_handle h) {
     const size_t c = (size_t) h->cap_kp;
     v.rx = h->d_kp; v.ry = h->d_kp + c; v.rz = h->d_kp + 2 * c; v.t = h->d_kp + 3 * c;
     v.wx = h->d_kp + 4 * c; v.wy = h->d_kp + 5 * c; v.wz = h->d_kp + 6 * c;
+    v.res = h->d_res;
     v.n = h->n_kp;
     return v;
 }
@@ -253,12 +259,27 @@ ctgn_status ensure_debug(ctgn_handle h) {
     return CTGN_OK;
 }
 
-// How many keypoints one wave owns per tile (4 rows x rounds): large tiles for large N (fewer, fuller waves),
-// small tiles for the latency regime so that a 1-3 k keypoint frame still spreads over the 256 CUs.
-int pick_rounds(int n) {
-    int rounds = 16;
-    while (rounds > 1 && (long long) n < (long long) 4 * rounds * 2048) rounds >>= 1;
-    return rounds;
+// Tile shape of the row kernel: a wave owns 4 x rounds keypoints per tile. Pick `rounds` (1..16) so that the
+// resident waves of the chip get equal work: with W resident waves, a wave runs ceil(tiles / W) tiles of
+// (rounds + overhead) steps; minimise that. Large scans end up with 64-keypoint tiles, a 1-3 k keypoint frame with
+// 4-8 keypoint tiles spread over all 256 CUs.
+int pick_rounds(int n, int resident_waves) {
+    int best = 16;
+    double best_cost = 1e300;
+    for (int r = 1; r <= 16; ++r) {
+        const long long tiles = ((long long) n + 4 * r - 1) / (4 * r);
+        const long long per_wave = (tiles + resident_waves - 1) / resident_waves;
+        const double cost = (double) per_wave * (r + 2.0);      // ~2 rounds' worth of per-tile phases A, C, D
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
+    }
+    return best;
+}
+
+template <typename K>
+int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    return per_cu * h->num_cus;
 }
 
 ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter) {
@@ -283,20 +304,38 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
         hipLaunchKernelGGL(k_accumulate_lane, dim3(grid), dim3(LANE_BLOCK), lane_kernel_smem(), h->stream, mv, kv,
                            h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0);
     } else {
-        const int rounds = pick_rounds(h->n_kp);
-        const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
-        grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, MAX_PARTIAL_BLOCKS));
         const bool hist = h->variant != 2;
+        if (h->variant == 3 && mv.nb == 1) {
+            const int rb = std::min(resident_blocks(h, k_accumulate_rows<1, true, true>, ROW_BLOCK, rows_kernel_smem<1>()), MAX_PARTIAL_BLOCKS);
+            const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
+            const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
+            grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
+            hipLaunchKernelGGL((k_accumulate_rows<1, true, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
+                               mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, h->d_prof);
+            HIPCHK(h, hipGetLastError());
+            if (ev) HIPCHK(h, hipEventRecord(ev->stop, h->stream));
+            h->last_grid = grid;
+            return CTGN_OK;
+        }
+        int res_blocks;
+        if (mv.nb == 1) res_blocks = hist ? resident_blocks(h, k_accumulate_rows<1, true>, ROW_BLOCK, rows_kernel_smem<1>())
+                                          : resident_blocks(h, k_accumulate_rows<1, false>, ROW_BLOCK, rows_kernel_smem<1>());
+        else res_blocks = hist ? resident_blocks(h, k_accumulate_rows<2, true>, ROW_BLOCK, rows_kernel_smem<2>())
+                               : resident_blocks(h, k_accumulate_rows<2, false>, ROW_BLOCK, rows_kernel_smem<2>());
+        res_blocks = std::min(res_blocks, MAX_PARTIAL_BLOCKS);
+        const int rounds = pick_rounds(h->n_kp, res_blocks * ROW_WAVES);
+        const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
+        grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, res_blocks));
         if (mv.nb == 1) {
             if (hist) hipLaunchKernelGGL((k_accumulate_rows<1, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
-                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
             else hipLaunchKernelGGL((k_accumulate_rows<1, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
-                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
         } else {
             if (hist) hipLaunchKernelGGL((k_accumulate_rows<2, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
-                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
             else hipLaunchKernelGGL((k_accumulate_rows<2, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
-                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -306,7 +345,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
 }
 
 ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
-    hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(128), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
+    hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
                        h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
     HIPCHK(h, hipGetLastError());
     return CTGN_OK;
@@ -402,6 +441,7 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
             delete h;
             return CTGN_ERR_NO_DEVICE;
         }
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         bool ok = hipSetDevice(h->device) == hipSuccess &&
                   hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
         h->own_stream = ok;
@@ -412,6 +452,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_prof), 8 * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemsetAsync(h->d_prof, 0, 8 * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
              hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_sys_own, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
@@ -434,6 +476,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->stream) hipStreamSynchronize(h->stream);
         for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
         if (h->d_kp) hipFree(h->d_kp);
+        if (h->d_res) hipFree(h->d_res);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
         if (h->h_state) hipHostFree(h->h_state);
@@ -442,6 +485,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_pose_in) hipFree(h->d_pose_in);
         if (h->h_pose_in) hipHostFree(h->h_pose_in);
         if (h->d_counters) hipFree(h->d_counters);
+        if (h->d_prof) hipFree(h->d_prof);
         if (h->d_nnb) { hipFree(h->d_nnb); hipFree(h->d_normal); hipFree(h->d_a2d); hipFree(h->d_far); hipFree(h->d_used); }
         if (h->d_edit) hipFree(h->d_edit);
         if (h->h_edit) hipHostFree(h->h_edit);
@@ -564,10 +608,12 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     if ((int) n > h->cap_kp) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_kp) HIPCHK(h, hipFree(h->d_kp));
+        if (h->d_res) HIPCHK(h, hipFree(h->d_res));
         if (h->h_kp) HIPCHK(h, hipHostFree(h->h_kp));
-        h->d_kp = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
+        h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), cap * 7 * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), cap * 13 * sizeof(double)));
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), cap * 7 * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
@@ -828,8 +874,17 @@ ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_ms, int32_t *launches,
     return CTGN_OK;
 }
 
+ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[8], int32_t reset) {
+    NEED_DEVICE(h);
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d_prof, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 8 * sizeof(unsigned long long)));
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant) {
-    if (!h || variant < 0 || variant > 2) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h || variant < 0 || variant > 3) return CTGN_ERR_INVALID_ARGUMENT;
     h->variant = variant;
     return CTGN_OK;
 }

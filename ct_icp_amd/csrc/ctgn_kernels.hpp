@@ -48,6 +48,7 @@ struct MapView {
 struct KpView {
     const double *rx, *ry, *rz, *t;
     double *wx, *wy, *wz;
+    double *res;             // [n][13] per-keypoint hand-over between the row phase and the lane phase of k_accumulate_rows
     int n;
 };
 
@@ -117,6 +118,32 @@ __device__ __forceinline__ uint32_t map_lookup(const MapView &m, int vx, int vy,
         if (s.key == key) return (s.block << 7) | s.count;
         if (s.key == KEY_EMPTY) return 0u;
         i = (i + 1) & m.mask;
+    }
+}
+
+// Split lookup for software pipelining: probe_issue starts the first slot load of a voxel, probe_resolve finishes
+// the probe sequence later (the load latency is covered by whatever runs in between).
+struct Probe {
+    uint64_t key;
+    uint32_t idx;
+    Slot s;
+    bool active;
+};
+__device__ __forceinline__ Probe probe_issue(const MapView &m, bool active, int vx, int vy, int vz) {
+    Probe p;
+    p.active = active;
+    p.key = pack_key(vx, vy, vz);
+    p.idx = active ? hash_key(p.key, m.mask) : 0u;
+    p.s = m.slots[p.idx];
+    return p;
+}
+__device__ __forceinline__ uint32_t probe_resolve(const MapView &m, Probe &p) {
+    if (!p.active) return 0u;
+    for (;;) {
+        if (p.s.key == p.key) return (p.s.block << 7) | p.s.count;
+        if (p.s.key == KEY_EMPTY) return 0u;
+        p.idx = (p.idx + 1) & m.mask;
+        p.s = m.slots[p.idx];
     }
 }
 
@@ -282,7 +309,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
         }
         __syncthreads();
     }
-    if (tid < SYS_N) partials[(size_t) blockIdx.x * SYS_N + tid] = (tid < SYS_USED) ? acc : 0.0;
+    if (tid < SYS_N) partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = (tid < SYS_USED) ? acc : 0.0;
 }
 
 inline size_t lane_kernel_smem() {
@@ -329,6 +356,17 @@ __device__ __forceinline__ int row_scan_i32(int v) {
     return v;
 }
 
+// the 16 ballot bits of DPP row `row`
+__device__ __forceinline__ uint32_t row_bits(unsigned long long ballot, int row) {
+    return (uint32_t) (ballot >> (16 * row)) & 0xffffu;
+}
+// max over the 4 rows of a row-uniform value, as a wave-uniform scalar (readlane -> SALU, no LDS round trip)
+__device__ __forceinline__ int max_over_rows(int v) {
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
 // per-row LDS scratch
 template <int OCC>
 struct RowScratch {
@@ -336,6 +374,8 @@ struct RowScratch {
     uint32_t vis[LCAP];       // (occupied-voxel index << 6) | slot : the visit order, and the way back to the point
     uint32_t occ[OCC];        // block*128 + count of the occupied voxels, in sweep order
     uint32_t hist[16];
+    uint2 chunk[64];          // per 16-point chunk of the probe batch in flight: .x = byte offset of its first x,
+                              // .y = (visit index of its first point << 8) | points in the chunk (1..16)
 };
 
 template <int OCC>
@@ -353,9 +393,7 @@ struct WaveScratch {
 template <int OCC, bool HIST>
 __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int sub, int row, double hi) {
     // wave-uniform loop bounds (rows differ): the max over the wave
-    int maxLn = Ln;
-    maxLn = max(maxLn, __shfl_xor(maxLn, 16));
-    maxLn = max(maxLn, __shfl_xor(maxLn, 32));
+    int maxLn = max_over_rows(Ln);
     if (maxLn <= k) return Ln;
     double od2[MAXOWN];
     uint32_t ovis[MAXOWN];
@@ -389,17 +427,14 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
             for (int m = 0; m < MAXOWN; ++m) {
                 int e = sub + 16 * m;
                 bool keep = (e < Ln) && (bin[m] <= bb);
-                unsigned long long kb = __ballot(keep);
-                uint32_t km = (uint32_t) (kb >> (16 * row)) & 0xffffu;
+                uint32_t km = row_bits(__ballot(keep), row);
                 int pos = base + __popc(km & ((1u << sub) - 1u));
                 if (keep) { R.d2[pos] = od2[m]; R.vis[pos] = ovis[m]; }
                 base += __popc(km);
             }
             Ln = base;
         }
-        maxLn = Ln;
-        maxLn = max(maxLn, __shfl_xor(maxLn, 16));
-        maxLn = max(maxLn, __shfl_xor(maxLn, 32));
+        maxLn = max_over_rows(Ln);
 #pragma unroll
         for (int m = 0; m < MAXOWN; ++m) {
             int e = sub + 16 * m;
@@ -413,6 +448,7 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
 #pragma unroll
     for (int m = 0; m < MAXOWN; ++m) rank[m] = 0;
     const int mcount = (maxLn + 15) >> 4;
+#pragma unroll 4
     for (int f = 0; f < maxLn; ++f) {
         bool fv = f < Ln;
         double fd2 = fv ? R.d2[f] : __longlong_as_double(0x7ff0000000000000ll);
@@ -432,9 +468,13 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
 }
 
 // NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection.
-template <int NB, bool HIST>
-__global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                               double *partials, DebugView dbg, int first_iter, int rounds) {
+// PROF: per-phase shader-clock accounting (s_memtime) summed over waves into prof[0..7]:
+//   0 phase A (transform, voxel) | 1 hash probes + chunk lists | 2 candidate streaming | 3 in-stream prunes |
+//   4 final selection | 5 covariance sums | 6 phase C (normal, residual, u) | 7 phase D (u u^T accumulation)
+template <int NB, bool HIST, bool PROF = false>
+__global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                               double *partials, DebugView dbg, int first_iter, int rounds,
+                                                               unsigned long long *prof = nullptr) {
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (st->done) return;
@@ -443,18 +483,20 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
     RowScratch<OCC> &R = W.row[row];
     const int k = prm.max_nb;
     const int blk = map.blk;
-
-    // sweep offsets of the voxels this lane probes: v = it*16 + sub in x-major order (map.h:470-472)
-    int ox[VIT], oy[VIT], oz[VIT];
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-        int v = it * 16 + sub;
-        ox[it] = v / (S * S) - NB;
-        oy[it] = (v / S) % S - NB;
-        oz[it] = v % S - NB;
-    }
+    const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
+    const uint32_t blk8 = (uint32_t) blk * 8u, stride3 = 3u * blk8;
+    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;      // uniform bases: scalar-base + 32-bit lane offset loads
 
     double acc0 = 0.0, acc1 = 0.0;     // packed-system entries `lane` and `lane + 64`
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    if (PROF) tprev = __builtin_readcyclecounter();
+#define CTGN_TICK(slot)                                                  \
+    if (PROF) {                                                          \
+        const unsigned long long now_ = __builtin_readcyclecounter();    \
+        pc[slot] += now_ - tprev;                                        \
+        tprev = now_;                                                    \
+    }
     // entry descriptors: e0 = lane (< 78: upper-tri product), e1 = lane + 64 (product | -u_i * r | count | none)
     const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
     int e1i = 0, e1j = 0, e1kind = 2;          // kind 0: product, 1: -u*r, 2: count / none
@@ -467,12 +509,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
         // ---------------- phase A: lane (row, sub < rounds) owns keypoint tile*4*rounds + row*rounds + sub
         const int my_kp = tile * kp_per_wave + row * rounds + sub;
         const bool own = (sub < rounds) && (my_kp < kp.n);
-        Vec3 raw{0, 0, 0}, p{0, 0, 0};
-        double alpha = 0.0;
+        {
+        Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
         if (own) {
-            raw = Vec3{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
-            alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+            const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+            const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
             if (first_iter) {
                 p = Vec3{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};
             } else {
@@ -486,76 +528,111 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
         }
         W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
         W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
-
-        // results of phase B for the keypoint this lane owns
-        int res_n = 0;
-        Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
-        Sym3 res_SS{0, 0, 0, 0, 0, 0};
+        }
+        CTGN_TICK(0)
 
         // ---------------- phase B: the row works on the keypoint owned by its lane `r`
+        Probe nxt;
+        {
+            const int src0 = row * 16;
+            const int kx0 = W.kx[src0], ky0 = W.ky[src0], kz0 = W.kz[src0];
+            nxt = probe_issue(map, kx0 != INT_MIN, kx0 + sub / (S * S) - NB, ky0 + (sub / S) % S - NB, kz0 + sub % S - NB);
+        }
         for (int r = 0; r < rounds; ++r) {
             const int src = row * 16 + r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
             const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
             const bool searching = kx != INT_MIN;
 
-            // B1: hash probes, 16 voxels per step, occupied ones compacted in sweep order
-            int occ_n = 0;
+            // B1 + B2, interleaved per batch of 16 sweep voxels:
+            //   probe 16 voxels (one per lane) -> occupied ones appended to R.occ in sweep order (x-major, as the
+            //   reference's loops, map.h:470-472) -> one chunk per 16 points of each occupied voxel -> the row streams
+            //   the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
+            //   loads of chunk c+1 in flight while chunk c is tested against the radius / current k-th best and
+            //   compacted into the row's LDS candidate list.
+            int occ_n = 0, Ln = 0;
+            double kth_d2 = map.r2thr;
+            uint32_t kth_vis = 0xffffffffu;       // (r2thr, +inf): "d2 <= r2thr" until a k-th best is known
+            const uint32_t lt_mask = (1u << sub) - 1u;
 #pragma unroll
             for (int it = 0; it < VIT; ++it) {
-                const int v = it * 16 + sub;
-                uint32_t bc = 0;
-                if (searching && v < V) bc = map_lookup(map, kx + ox[it], ky + oy[it], kz + oz[it]);
-                unsigned long long fb = __ballot(bc != 0);
-                uint32_t fm = (uint32_t) (fb >> (16 * row)) & 0xffffu;
-                if (bc) R.occ[occ_n + __popc(fm & ((1u << sub) - 1u))] = bc;
+                // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
+                // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
+                Probe cur = nxt;
+                if (it + 1 < VIT) {
+                    const int v = (it + 1) * 16 + sub;
+                    nxt = probe_issue(map, searching && v < V, kx + v / (S * S) - NB, ky + (v / S) % S - NB, kz + v % S - NB);
+                } else if (r + 1 < rounds) {
+                    const int src2 = row * 16 + r + 1;
+                    const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
+                    nxt = probe_issue(map, kx2 != INT_MIN, kx2 + sub / (S * S) - NB, ky2 + (sub / S) % S - NB, kz2 + sub % S - NB);
+                }
+                const uint32_t bc = probe_resolve(map, cur);
+                const uint32_t fm = row_bits(__ballot(bc != 0), row);
+                const int myj = occ_n + __popc(fm & lt_mask);
+                if (bc) R.occ[myj] = bc;
                 occ_n += __popc(fm);
-            }
-
-            // B2: stream the occupied voxels' points, keep candidates within the radius (and below the
-            //     current k-th best once one is known) in the row's LDS list
-            int Ln = 0;
-            double kth_d2 = map.r2thr;
-            uint32_t kth_vis = 0xffffffffu;
-            int max_occ = occ_n;
-            max_occ = max(max_occ, __shfl_xor(max_occ, 16));
-            max_occ = max(max_occ, __shfl_xor(max_occ, 32));
-            for (int j = 0; j < max_occ; ++j) {
-                const uint32_t bc = (j < occ_n) ? R.occ[j] : 0u;
-                const uint32_t block = bc >> 7;
-                const int cnt = (int) (bc & 127u);
-                const double *bx = map.blocks + (size_t) block * 3 * blk;
-                int max_cnt = cnt;
-                max_cnt = max(max_cnt, __shfl_xor(max_cnt, 16));
-                max_cnt = max(max_cnt, __shfl_xor(max_cnt, 32));
-                for (int s = 0; s < max_cnt; s += 16) {
-                    const int i = s + sub;
-                    bool pass = false;
-                    double d2 = 0.0;
-                    if (i < cnt) {
-                        double dx = bx[i] - qx, dy = bx[blk + i] - qy, dz = bx[2 * blk + i] - qz;
-                        d2 = dx * dx + dy * dy + dz * dz;
-                        const uint32_t vis = ((uint32_t) j << 6) | (uint32_t) i;
-                        pass = (d2 < kth_d2) || (d2 == kth_d2 && vis < kth_vis);     // kth starts at (r2thr, +inf): d2 <= r2thr
+                const int cnt_mine = (int) (bc & 127u);
+                const uint32_t off_mine = (bc >> 7) * stride3;
+                int nchunk = 0;
+                for (int hh = 0; hh < 4; ++hh) {
+                    const int left = cnt_mine - 16 * hh;
+                    const bool has = left > 0;
+                    const unsigned long long hb = __ballot(has);
+                    if (!hb) break;
+                    const uint32_t hm = row_bits(hb, row);
+                    if (has) R.chunk[nchunk + __popc(hm & lt_mask)] =
+                            make_uint2(off_mine + 128u * hh, ((((uint32_t) myj << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
+                    nchunk += __popc(hm);
+                }
+                CTGN_TICK(1)
+                double nx, ny, nz;
+                uint32_t nvis;
+                bool nvalid;
+                auto fetch = [&](int c) {
+                    nvalid = false;
+                    nx = ny = nz = 0.0;
+                    nvis = 0u;
+                    if (c < nchunk) {
+                        const uint2 ch = R.chunk[c];
+                        nvalid = (uint32_t) sub < (ch.y & 0xffu);
+                        const uint32_t off = ch.x + (nvalid ? (uint32_t) sub * 8u : 0u);      // legal address either way
+                        nx = *reinterpret_cast<const double *>(pbase + off);
+                        ny = *reinterpret_cast<const double *>(pbase_y + off);
+                        nz = *reinterpret_cast<const double *>(pbase_z + off);
+                        nvis = (ch.y >> 8) + (uint32_t) sub;
                     }
-                    unsigned long long pb = __ballot(pass);
-                    uint32_t pm = (uint32_t) (pb >> (16 * row)) & 0xffffu;
+                };
+                fetch(0);
+                for (int c = 0; __any(c < nchunk); ++c) {
+                    const double x = nx, y = ny, z = nz;
+                    const uint32_t vis = nvis;
+                    const bool valid = nvalid;
+                    fetch(c + 1);
+                    const double dx = x - qx, dy = y - qy, dz = z - qz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const bool pass = valid && ((d2 < kth_d2) || (d2 == kth_d2 && vis < kth_vis));
+                    const uint32_t pm = row_bits(__ballot(pass), row);
                     if (pass) {
-                        int pos = Ln + __popc(pm & ((1u << sub) - 1u));
+                        const int pos = Ln + __popc(pm & lt_mask);
                         R.d2[pos] = d2;
-                        R.vis[pos] = ((uint32_t) j << 6) | (uint32_t) i;
+                        R.vis[pos] = vis;
                     }
                     Ln += __popc(pm);
                     if (__any(Ln > LCAP - 16)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
+                        CTGN_TICK(2)
                         Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
                         if (Ln >= k) { kth_d2 = R.d2[k - 1]; kth_vis = R.vis[k - 1]; }
+                        CTGN_TICK(3)
                     }
                 }
+                CTGN_TICK(2)
             }
             // B3: final selection -> list sorted ascending, [0..n)
             Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
             const int n = Ln;
+            CTGN_TICK(4)
             // if the list was never cut it is still in visit order: find the farthest by rank sort too
             // (row_select returns early when every row has <= k entries) -> sort those rows here.
             // A list of <= k entries in arbitrary order: the farthest is the max under the total order.
@@ -573,8 +650,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
                     const uint32_t vis = R.vis[e];
                     const double d2 = R.d2[e];
                     const uint32_t bc = R.occ[vis >> 6];
-                    const double *pb = map.blocks + (size_t) (bc >> 7) * 3 * blk + (vis & 63u);
-                    const double x = pb[0], y = pb[blk], z = pb[2 * blk];
+                    const uint32_t off = (bc >> 7) * stride3 + (vis & 63u) * 8u;
+                    const double x = *reinterpret_cast<const double *>(pbase + off);
+                    const double y = *reinterpret_cast<const double *>(pbase_y + off);
+                    const double z = *reinterpret_cast<const double *>(pbase_z + off);
                     cx[m] = x; cy[m] = y; cz[m] = z;
                     sx += x; sy += y; sz += z;
                     sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
@@ -600,12 +679,19 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
             sxx = row_sum(sxx); sxy = row_sum(sxy); sxz = row_sum(sxz);
             syy = row_sum(syy); syz = row_sum(syz); szz = row_sum(szz);
             fqx = row_sum(fqx); fqy = row_sum(fqy); fqz = row_sum(fqz);       // exactly one lane is non-zero
-            if (sub == r) {
-                res_n = n;
-                res_S = Vec3{sx, sy, sz};
-                res_SS = Sym3{sxx, sxy, sxz, syy, syz, szz};
-                res_q = Vec3{fqx, fqy, fqz};
+            // hand the keypoint's (n, sum p, sum p p^T, farthest) over to its owner lane through the per-keypoint
+            // scratch record (13 doubles, L2-resident): nothing of it stays in registers across the rounds
+            {
+                const int kp_r = tile * kp_per_wave + row * rounds + r;
+                if (sub == 0 && kp_r < kp.n) {
+                    double *o = kp.res + (size_t) kp_r * 13;
+                    o[0] = (double) n;
+                    o[1] = sx; o[2] = sy; o[3] = sz;
+                    o[4] = sxx; o[5] = sxy; o[6] = sxz; o[7] = syy; o[8] = syz; o[9] = szz;
+                    o[10] = fqx; o[11] = fqy; o[12] = fqz;
+                }
             }
+            CTGN_TICK(5)
         }
 
         // ---------------- phase C: lane per keypoint — normal, gates, residual, u
@@ -613,7 +699,15 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
         bool used = false;
         Vec3 nrm{0, 0, 0};
         double a2d = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // the records were written by other lanes of this wave
         if (own) {
+            const double *in = kp.res + (size_t) my_kp * 13;
+            const int res_n = (int) in[0];
+            const Vec3 res_S{in[1], in[2], in[3]}, res_q{in[10], in[11], in[12]};
+            const Sym3 res_SS{in[4], in[5], in[6], in[7], in[8], in[9]};
+            const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+            const Vec3 p{W.px[lane], W.py[lane], W.pz[lane]};
+            const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
             used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;
@@ -623,6 +717,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
                 dbg.used[my_kp] = used ? 1 : 0;
             }
         }
+        CTGN_TICK(6)
         // ---------------- phase D: packed u u^T | -u r | count, lanes own entries (LDS-transposed sum)
         {
             double *my = W.rec + lane * 13;          // aliases the row scratch: phase B is finished for this wave
@@ -637,7 +732,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
             }
             if (e1kind == 2 && lane == 26) acc1 += (double) __popcll(ub);
         }
+        CTGN_TICK(7)
     }
+    if (PROF && lane == 0) {
+        for (int q = 0; q < 8; ++q) atomicAdd(&prof[q], pc[q]);
+    }
+#undef CTGN_TICK
     // ---------------- block combine: fixed order over the waves
     __syncthreads();
     double *comb = reinterpret_cast<double *>(smem);      // [ROW_WAVES][SYS_N]
@@ -647,7 +747,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void k_accumulate_rows(MapView map, KpVi
     if (tid < SYS_N) {
         double s = 0.0;
         for (int w = 0; w < ROW_WAVES; ++w) s += comb[w * SYS_N + tid];
-        partials[(size_t) blockIdx.x * SYS_N + tid] = s;
+        partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
     }
 }
 
@@ -658,54 +758,139 @@ inline size_t rows_kernel_smem() {
 }
 
 // ================================================================================================
-// k_reduce_solve — partials -> packed system -> (normalise, prior, LDL^T, pose update, stop test)
+// k_reduce_solve — partials -> packed system -> (normalise, motion prior, LDL^T, pose update, stop test)
 //   mode 0: reduce + solve   1: reduce only (multi-GPU: the all-reduce sits in between)   2: solve only
+// One block of 1024 threads. Reduction: wave w sums entries w, w+16, ... over the blocks with a fixed
+// lane-strided order and a fixed shuffle tree (deterministic). Solve: the 12 x 12 system lives in LDS and lanes
+// 0..11 of wave 0 own one row each (Eigen's diagonally pivoted, left-looking LDL^T, ct_icp.cpp:914).
 // ================================================================================================
-__global__ __launch_bounds__(128) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
-                                                      GnParams prm, int mode, int min_used) {
+constexpr int SOLVE_BLOCK = 1024;
+
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);  v += __shfl_xor(v, 2);  v += __shfl_xor(v, 1);
+    return v;
+}
+
+__global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
+                                                              GnParams prm, int mode, int min_used) {
     __shared__ double s_sys[SYS_N];
+    __shared__ double s_m[144];
+    __shared__ double s_temp[12];
+    __shared__ double s_x[12];
     if (st->done) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (mode != 2) {
-        if (tid < SYS_N) {
+        for (int e = wave; e < SYS_N; e += SOLVE_BLOCK / 64) {
             double s = 0.0;
-            for (int b = 0; b < nblocks; ++b) s += partials[(size_t) b * SYS_N + tid];     // fixed order
-            sys[tid] = s;
-            s_sys[tid] = s;
+            for (int b = lane; b < nblocks; b += 64) s += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
+            s = wave_sum_fixed(s);
+            if (lane == 0) { sys[e] = s; s_sys[e] = s; }
         }
     } else {
         if (tid < SYS_N) s_sys[tid] = sys[tid];
     }
     __syncthreads();
-    if (mode == 1 || tid != 0) return;
+    if (mode == 1 || wave != 0) return;
 
+    // ---- wave 0 only from here
     const int n_used = (int) (s_sys[90] + 0.5);
-    st->n_used = n_used;
     if (n_used < min_used) {              // ct_icp.cpp:860-871 — soft failure, pose untouched
-        st->failed = 1;
-        st->done = 1;
+        if (lane == 0) { st->n_used = n_used; st->failed = 1; st->done = 1; }
         return;
     }
-    double A[144], b[12], x[12];
     const double dn = (double) n_used;
-    for (int e = 0; e < 78; ++e) {
-        int i = c_tri_i[e], j = c_tri_j[e];
-        double v = s_sys[e] / dn;                                   // :877-882
-        A[12 * i + j] = v;
-        A[12 * j + i] = v;
+    // A = sum / n (ct_icp.cpp:877-882), full symmetric matrix in LDS; b in a register of lane i
+    for (int e = lane; e < 78; e += 64) {
+        const int i = c_tri_i[e], j = c_tri_j[e];
+        const double v = s_sys[e] / dn;
+        s_m[12 * i + j] = v;
+        s_m[12 * j + i] = v;
     }
-    for (int i = 0; i < 12; ++i) b[i] = s_sys[78 + i] / dn;
-    if (prm.has_prior) {                                            // :885-910
-        for (int c = 0; c < 3; ++c) {
-            double diff_traj = st->pose[4 + c] - st->pose[11 + c];
-            A[13 * (3 + c)] += prm.beta_c;
-            b[3 + c] -= prm.beta_c * diff_traj;
-            double diff_ego = st->pose[11 + c] - st->pose[4 + c] - prm.prev_e[c] + prm.prev_b[c];
-            A[13 * (9 + c)] += prm.beta_e;
-            b[9 + c] -= prm.beta_e * diff_ego;
+    double bi = (lane < 12) ? s_sys[78 + lane] / dn : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (prm.has_prior && lane < 3) {                              // ct_icp.cpp:885-910
+        const int c = lane;
+        s_m[13 * (3 + c)] += prm.beta_c;
+        s_m[13 * (9 + c)] += prm.beta_e;
+    }
+    if (prm.has_prior) {
+        if (lane >= 3 && lane < 6) {
+            const int c = lane - 3;
+            bi -= prm.beta_c * (st->pose[4 + c] - st->pose[11 + c]);
+        } else if (lane >= 9 && lane < 12) {
+            const int c = lane - 9;
+            bi -= prm.beta_e * (st->pose[11 + c] - st->pose[4 + c] - prm.prev_e[c] + prm.prev_b[c]);
         }
     }
-    ldlt_solve12(A, b, x);                                          // :914
+    __builtin_amdgcn_wave_barrier();
+    volatile double *m = s_m;
+    volatile double *temp = s_temp;
+    const int i = lane;                   // row owned by this lane (valid for lane < 12)
+    int transp_mine = i;                  // transposition chosen at step k == lane
+    for (int k = 0; k < 12; ++k) {
+        // pivot: first index of the largest |diagonal| among k..11
+        double dv = (i >= k && i < 12) ? fabs(m[13 * i]) : -1.0;
+        int di = i;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            double ov = __shfl_xor(dv, off);
+            int oi = __shfl_xor(di, off);
+            if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }
+        }
+        const int big = __shfl(di, 0);
+        if (i == k) transp_mine = big;
+        if (big != k) {                   // symmetric swap on the lower triangle
+            if (i < k) { double t = m[12 * k + i]; m[12 * k + i] = m[12 * big + i]; m[12 * big + i] = t; }
+            if (i > big && i < 12) { double t = m[12 * i + k]; m[12 * i + k] = m[12 * i + big]; m[12 * i + big] = t; }
+            if (i > k && i < big) { double t = m[12 * i + k]; m[12 * i + k] = m[12 * big + i]; m[12 * big + i] = t; }
+            if (i == 0) { double t = m[13 * k]; m[13 * k] = m[13 * big]; m[13 * big] = t; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i < k) temp[i] = m[13 * i] * m[12 * k + i];
+        __builtin_amdgcn_wave_barrier();
+        if (i >= k && i < 12) {
+            double a2 = 0.0;
+            for (int j = 0; j < k; ++j) a2 += m[12 * i + j] * temp[j];
+            m[12 * i + k] -= a2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double akk = m[13 * k];
+        if (i > k && i < 12 && fabs(akk) > 0.0) m[12 * i + k] /= akk;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // solve: y = P b ; L^-1 ; D^-1 ; L^-T ; P^T — lane i keeps y_i in a register
+    double y = bi;
+    for (int k = 0; k < 12; ++k) {
+        const int tk = __shfl(transp_mine, k);
+        if (tk != k) {
+            const double yk = __shfl(y, k), yt = __shfl(y, tk);
+            if (i == k) y = yt; else if (i == tk) y = yk;
+        }
+    }
+    for (int j = 0; j < 12; ++j) {          // forward: after step j, y_j is final
+        const double yj = __shfl(y, j);
+        if (i > j && i < 12) y -= m[12 * i + j] * yj;
+    }
+    if (i < 12) { const double d = m[13 * i]; y = (fabs(d) > DBL_MIN) ? y / d : 0.0; }
+    for (int j = 11; j >= 0; --j) {         // backward with L^T
+        const double yj = __shfl(y, j);
+        if (i < j) y -= m[12 * j + i] * yj;
+    }
+    for (int k = 11; k >= 0; --k) {
+        const int tk = __shfl(transp_mine, k);
+        if (tk != k) {
+            const double yk = __shfl(y, k), yt = __shfl(y, tk);
+            if (i == k) y = yt; else if (i == tk) y = yk;
+        }
+    }
+    if (i < 12) s_x[i] = y;
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+
+    double x[12];
+    for (int c = 0; c < 12; ++c) x[c] = s_x[c];
+    st->n_used = n_used;
     double Rb[9], Re[9], Q[9], P[9];
     euler_rotation(x[0], x[1], x[2], Rb);                           // :916-932
     euler_rotation(x[6], x[7], x[8], Re);                           // :935-947
@@ -724,7 +909,7 @@ __global__ __launch_bounds__(128) void k_reduce_solve(const double *partials, in
     SlerpPair sp = slerp_prepare(qb, qe);
     st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
     double nrm = 0.0;
-    for (int i = 0; i < 12; ++i) { nrm += x[i] * x[i]; st->x[i] = x[i]; }
+    for (int c = 0; c < 12; ++c) { nrm += x[c] * x[c]; st->x[c] = x[c]; }
     nrm = sqrt(nrm);
     st->step_norm = nrm;
     st->iter += 1;

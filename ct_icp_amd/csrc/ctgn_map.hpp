@@ -83,7 +83,7 @@ struct VoxelLevel {
         min_distance = min_dist;
         blk = max_pts < 1 ? 1 : max_pts;
         uint64_t cap = 1024;
-        while (cap < 4 * initial_voxels) cap <<= 1;
+        while (cap < 8 * initial_voxels) cap <<= 1;
         slots.assign(cap, Slot{KEY_EMPTY, 0, 0});
         mask = (uint32_t) (cap - 1);
         nblocks_cap = (uint32_t) (initial_voxels > 256 ? initial_voxels : 256);
@@ -198,9 +198,11 @@ struct VoxelLevel {
             log_slot(i);
             num_voxels++;
             num_points++;
-            if ((num_voxels + num_tombs) * 2 > (uint64_t) mask + 1) {
-                uint64_t cap = (uint64_t) mask + 1;
-                while (cap < 4 * num_voxels) cap <<= 1;
+            // load factor (live + tombstones) kept in [1/8, 1/4]: a miss then ends after ~1.2 probes on average,
+            // which matters because a wave waits for the slowest of its 64 concurrent probes
+            if ((num_voxels + num_tombs) * 4 > (uint64_t) mask + 1) {
+                uint64_t cap = 1024;
+                while (cap < 8 * num_voxels) cap <<= 1;
                 rehash(cap);
             }
             return 1;

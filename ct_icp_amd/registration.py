@@ -184,6 +184,11 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_kernel_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def phase_cycles(self, reset=False):
+        out = (C.c_uint64 * 8)()
+        L.check(self._h, L.lib().ctgn_phase_cycles(self._h, out, int(reset)))
+        return [int(x) for x in out]
+
     def set_variant(self, v: int):
         L.check(self._h, L.lib().ctgn_set_variant(self._h, v))
 
