@@ -1,0 +1,60 @@
+// adapter_check — compiles the C++ adapter against libctgn.so and runs one registration through it.
+// Reference-style caller code (cf. Odometry::TryRegister, reference src/ct_icp/odometry.cpp:573-579):
+//     auto summary = registration.Register(*map, keypoints, frame, &motion_model);
+// Output (one line): "adapter ok n_used=<int> iters=<int> tr=<x y z> ..." or "adapter no-device" on a box without a GPU.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "ct_icp_gpu.hpp"
+
+using namespace ct_icp_gpu;
+
+int main() {
+    GpuVoxelMap::Options mo;
+    mo.resolutions = {{0.5, 0.05, 20}};
+    mo.default_radius = 0.8;
+    try {
+        GpuVoxelMap map(mo);
+        // a closed 8 m box sampled on its six faces
+        std::mt19937_64 g(5489);
+        std::uniform_real_distribution<double> u(-4.0, 4.0);
+        std::vector<double> pts;
+        for (int i = 0; i < 60000; ++i) {
+            double p[3] = {u(g), u(g), u(g)};
+            int ax = i % 3;
+            p[ax] = (i / 3) % 2 ? 4.0 : -4.0;
+            pts.insert(pts.end(), p, p + 3);
+        }
+        map.InsertPoints(pts.data(), pts.size() / 3);
+        // keypoints: points of the same faces seen from a sensor displaced by a small rigid motion
+        const double shift[3] = {0.03, -0.02, 0.01};
+        std::vector<WPoint3D> kps;
+        for (int i = 0; i < 3000; ++i) {
+            WPoint3D w{};
+            double p[3] = {u(g) * 0.8, u(g) * 0.8, u(g) * 0.8};
+            int ax = i % 3;
+            p[ax] = (i / 3) % 2 ? 4.0 : -4.0;
+            for (int c = 0; c < 3; ++c) { w.raw_point[c] = p[c] - shift[c]; w.world_point[c] = w.raw_point[c]; }
+            w.timestamp = (double) i / 3000.0;
+            kps.push_back(w);
+        }
+        TrajectoryFrame frame;
+        frame.begin_pose.dest_timestamp = 0.0;
+        frame.end_pose.dest_timestamp = 1.0;
+        CT_ICP_Registration reg;
+        reg.Options().solver = GN;
+        reg.Options().num_iters_icp = 10;
+        reg.Options().debug_print = false;
+        ICPSummary s = reg.Register(map, kps, frame, nullptr);
+        double err = 0;
+        for (int c = 0; c < 3; ++c) err = std::fmax(err, std::fabs(frame.end_pose.tr[c] - shift[c]));
+        std::printf("adapter %s n_used=%d iters=%d tr=%.6f %.6f %.6f err=%.2e map_points=%zu\n",
+                    (s.success && err < 1e-6) ? "ok" : "FAIL", s.num_residuals_used, s.num_iters, frame.end_pose.tr[0],
+                    frame.end_pose.tr[1], frame.end_pose.tr[2], err, map.NumPoints());
+        return (s.success && err < 1e-6) ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::printf("adapter no-device (%s)\n", e.what());
+        return 0;
+    }
+}

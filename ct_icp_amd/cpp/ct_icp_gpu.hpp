@@ -1,0 +1,246 @@
+// ct_icp_gpu.hpp — C++ host adapter over the C ABI of libctgn.so (include/ctgn.h).
+//
+// It mirrors, name for name, the part of the reference's C++ API that the GN path touches, so that reference-style
+// caller code (Odometry::TryRegister, src/ct_icp/odometry.cpp:573-579) reads the same against this backend:
+//
+//   ct_icp::CT_ICP_Registration::Register(map, keypoints, frame, motion_model, strategy) -> ICPSummary
+//                                                        (reference include/ct_icp/ct_icp.h:180-190)
+//   ct_icp::ISlamMap subset: InsertPointCloud, RemoveElementsFarFromLocation, ClearMap, NumPoints, MapAsPointCloud,
+//                            ComputeNeighborhoods / RadiusSearch      (reference include/ct_icp/map.h:14-83)
+//   slam::WPoint3D (64-byte record), slam::Pose, ct_icp::TrajectoryFrame, CTICPOptions, ICPSummary,
+//   PreviousFrameMotionModel (the fields GN reads).
+//
+// The header is Eigen-free (Eigen is not installed in this image): vectors are double[3] / double[4] with Eigen's
+// memory layout (quaternion coeffs x,y,z,w), so inside the reference tree `Eigen::Map` views over the same bytes are
+// free. INTEGRATION.md shows the ~40-line glue that makes this a `ct_icp::ISlamMap` + the `case GN:` hook.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ctgn.h"
+
+namespace ct_icp_gpu {
+
+// slam::WPoint3D (include/SlamCore/types.h:35-60): raw xyz @0, timestamp @24, world xyz @32, index_frame @56.
+struct WPoint3D {
+    double raw_point[3];
+    double timestamp;
+    double world_point[3];
+    uint32_t index_frame = (uint32_t) -1;
+    uint32_t _pad = 0;
+};
+static_assert(sizeof(WPoint3D) == 64, "WPoint3D must keep the reference's 64-byte layout");
+
+// slam::Pose (include/SlamCore/types.h:161-274): quaternion coeffs (x, y, z, w), translation, destination timestamp.
+struct Pose {
+    double quat[4] = {0, 0, 0, 1};
+    double tr[3] = {0, 0, 0};
+    double dest_timestamp = -1.0;
+    double ref_timestamp = 0.0;
+    int64_t dest_frame_id = -1, ref_frame_id = 0;
+};
+
+// ct_icp::TrajectoryFrame (include/ct_icp/types.h:31-61)
+struct TrajectoryFrame {
+    Pose begin_pose, end_pose;
+    const double *BeginTr() const { return begin_pose.tr; }
+    const double *EndTr() const { return end_pose.tr; }
+    const double *BeginQuat() const { return begin_pose.quat; }
+    const double *EndQuat() const { return end_pose.quat; }
+};
+
+enum CT_ICP_SOLVER { GN, CERES, ROBUST };                    // include/ct_icp/ct_icp.h:35-39
+
+// The fields of ct_icp::CTICPOptions DoRegisterGaussNewton reads (include/ct_icp/ct_icp.h:56-153), same defaults.
+struct CTICPOptions {
+    int num_iters_icp = 5;
+    CT_ICP_SOLVER solver = CERES;
+    int max_number_neighbors = 20;
+    int min_number_neighbors = 20;
+    double threshold_orientation_norm = 0.0001;
+    double max_dist_to_plane_ct_icp = 0.3;
+    bool debug_print = true;
+};
+
+// ct_icp::ICPSummary (include/ct_icp/ct_icp.h:155-169)
+struct ICPSummary {
+    bool success = false;
+    int num_residuals_used = 0;
+    int num_iters = 0;
+    std::string error_log;
+    double duration_total = 0., duration_init = 0., avg_duration_iter = 0., avg_duration_neighborhood = 0.,
+           avg_duration_solve = 0.;
+};
+
+// The part of ct_icp::PreviousFrameMotionModel GN reads (src/ct_icp/ct_icp.cpp:888-908).
+struct PreviousFrameMotionModel {
+    struct Options {
+        double beta_location_consistency = 0.001;
+        double beta_constant_velocity = 0.001;
+    } options;
+    TrajectoryFrame previous_frame;
+    const TrajectoryFrame &PreviousFrame() const { return previous_frame; }
+    void UpdateState(const TrajectoryFrame &optimized, int /*frame_index*/) { previous_frame = optimized; }
+};
+
+struct Neighborhood {            // slam::Neighborhood::points, farthest first (include/ct_icp/map.h:508-513)
+    std::vector<double> points;  // 3 * n
+    size_t size() const { return points.size() / 3; }
+};
+
+// "GPU_VOXEL_HASHMAP": the ISlamMap implementation that keeps the voxel map resident on the GPU.
+class GpuVoxelMap {
+public:
+    struct ResolutionParam {
+        double resolution = 0.5, min_distance_between_points = 0.1;
+        int max_num_points = 40;
+    };
+    struct Options {                                          // MultipleResolutionVoxelMap::Options (map.h:115-133)
+        std::vector<ResolutionParam> resolutions = {{0.2, 0.03, 50}, {0.5, 0.1, 40}, {1.5, 0.15, 40}};
+        double default_radius = 0.8;
+        int device = 0;
+        static std::string Type() { return "GPU_VOXEL_HASHMAP"; }
+    };
+
+    GpuVoxelMap() : GpuVoxelMap(Options()) {}
+    explicit GpuVoxelMap(const Options &options) : options_(options) {
+        ctgn_map_options mo;
+        ctgn_map_options_default(&mo);
+        mo.num_resolutions = (int32_t) options.resolutions.size();
+        mo.device = options.device;
+        mo.default_radius = options.default_radius;
+        for (size_t i = 0; i < options.resolutions.size() && i < CTGN_MAX_RESOLUTIONS; ++i)
+            mo.resolutions[i] = ctgn_resolution_param{options.resolutions[i].resolution,
+                                                      options.resolutions[i].min_distance_between_points,
+                                                      options.resolutions[i].max_num_points, 0};
+        ctgn_status st = ctgn_create(&mo, &h_);
+        if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn_create: ") + ctgn_status_string(st));
+    }
+    ~GpuVoxelMap() { ctgn_destroy(h_); }
+    GpuVoxelMap(const GpuVoxelMap &) = delete;
+    GpuVoxelMap &operator=(const GpuVoxelMap &) = delete;
+
+    // InsertPointCloud(pointcloud, out_selected_points) on the world points of a frame (map.h:296-300 -> :153-254)
+    void InsertPointCloud(const std::vector<WPoint3D> &frame, std::vector<size_t> &out_selected_points) {
+        std::vector<uint8_t> kept(frame.size());
+        check(ctgn_map_insert(h_, frame.empty() ? nullptr : frame[0].world_point, sizeof(WPoint3D), CTGN_F64, frame.size(),
+                              kept.data()));
+        out_selected_points.clear();
+        for (size_t i = 0; i < kept.size(); ++i)
+            if (kept[i]) out_selected_points.push_back(i);
+    }
+    void InsertPoints(const double *xyz, size_t n, size_t stride_bytes = 24) {
+        check(ctgn_map_insert(h_, xyz, stride_bytes, CTGN_F64, n, nullptr));
+    }
+    void RemoveElementsFarFromLocation(const double location[3], double distance) {
+        check(ctgn_map_remove_far(h_, location, distance));
+    }
+    void ClearMap() { check(ctgn_map_clear(h_)); }
+    size_t NumPoints() const {
+        uint64_t n = 0;
+        ctgn_map_num_points(h_, &n);
+        return (size_t) n;
+    }
+    std::vector<double> MapAsPointCloud(int resolution_index = 0) const {
+        uint64_t n = 0;
+        ctgn_map_export(h_, resolution_index, nullptr, 0, &n);
+        std::vector<double> out(3 * n);
+        ctgn_map_export(h_, resolution_index, out.data(), n, &n);
+        return out;
+    }
+    // ComputeNeighborhoods(queries, max_num_neighbors) (map.h:532-541), batched on the GPU
+    std::vector<Neighborhood> ComputeNeighborhoods(const std::vector<double> &queries_xyz, int max_num_neighbors,
+                                                   double radius = -1.0) {
+        const size_t n = queries_xyz.size() / 3;
+        std::vector<double> out(n * (size_t) max_num_neighbors * 3);
+        std::vector<int32_t> cnt(n);
+        check(ctgn_map_radius_search(h_, queries_xyz.data(), n, radius, max_num_neighbors, out.data(), cnt.data()));
+        std::vector<Neighborhood> res(n);
+        for (size_t i = 0; i < n; ++i)
+            res[i].points.assign(out.begin() + i * max_num_neighbors * 3, out.begin() + (i * max_num_neighbors + cnt[i]) * 3);
+        return res;
+    }
+    Neighborhood RadiusSearch(const double query[3], double radius, int max_num_neighbors) {
+        return ComputeNeighborhoods(std::vector<double>(query, query + 3), max_num_neighbors, radius)[0];
+    }
+
+    ctgn_handle handle() const { return h_; }
+    const Options &GetOptions() const { return options_; }
+
+private:
+    void check(ctgn_status st) const {
+        if (st != CTGN_OK) throw std::runtime_error(std::string("libctgn: ") + ctgn_last_error(h_));
+    }
+    Options options_;
+    ctgn_handle h_ = nullptr;
+};
+
+// ct_icp::CT_ICP_Registration for `solver: GN`.
+class CT_ICP_Registration {
+public:
+    CTICPOptions &Options() { return options_; }
+    const CTICPOptions &Options() const { return options_; }
+
+    // Register(voxel_map, keypoints, trajectory_frame, motion_model, strategy) — the vector<slam::WPoint3D> overload
+    // (src/ct_icp/ct_icp.cpp:1026-1037). Updates the frame's poses and the keypoints' world points in place.
+    ICPSummary Register(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &keypoints, TrajectoryFrame &trajectory_frame,
+                        const PreviousFrameMotionModel *motion_model = nullptr, void * /*strategy: unused by GN*/ = nullptr) {
+        if (options_.solver != GN) throw std::runtime_error("Unsupported Solver Type");      // ct_icp.cpp:1022
+        ctgn_options o;
+        ctgn_options_default(&o);
+        o.num_iters_icp = options_.num_iters_icp;
+        o.min_number_neighbors = options_.min_number_neighbors;
+        o.max_number_neighbors = options_.max_number_neighbors;
+        o.debug_print = options_.debug_print ? 1 : 0;
+        o.max_dist_to_plane_ct_icp = options_.max_dist_to_plane_ct_icp;
+        o.threshold_orientation_norm = options_.threshold_orientation_norm;
+        ctgn_motion_prior prior, *pp = nullptr;
+        if (motion_model) {                                                                  // ct_icp.cpp:885-889
+            prior.beta_location_consistency = motion_model->options.beta_location_consistency;
+            prior.beta_constant_velocity = motion_model->options.beta_constant_velocity;
+            std::memcpy(prior.previous_begin_tr, motion_model->PreviousFrame().BeginTr(), 24);
+            std::memcpy(prior.previous_end_tr, motion_model->PreviousFrame().EndTr(), 24);
+            pp = &prior;
+        }
+        double pose[14];
+        std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
+        std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
+        std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
+        std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+        const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
+        const size_t n = keypoints.size();
+        WPoint3D dummy{};
+        WPoint3D *base = n ? keypoints.data() : &dummy;
+        ctgn_view raw{base->raw_point, sizeof(WPoint3D), CTGN_F64, 0};
+        ctgn_view ts{&base->timestamp, sizeof(WPoint3D), CTGN_F64, 0};
+        ctgn_summary s;
+        ctgn_status st = ctgn_register(voxel_map.handle(), raw, base->world_point, sizeof(WPoint3D), CTGN_F64, ts, n, pose, tbe,
+                                       &o, pp, &s);
+        ICPSummary out;
+        if (st != CTGN_OK) {                 // hard errors of the reference (CHECK aborts) and HIP errors: soft failure
+            out.success = false;
+            out.error_log = ctgn_last_error(voxel_map.handle());
+            return out;
+        }
+        std::memcpy(trajectory_frame.begin_pose.quat, pose, 32);
+        std::memcpy(trajectory_frame.begin_pose.tr, pose + 4, 24);
+        std::memcpy(trajectory_frame.end_pose.quat, pose + 7, 32);
+        std::memcpy(trajectory_frame.end_pose.tr, pose + 11, 24);
+        out.success = s.success != 0;
+        out.num_residuals_used = s.num_residuals_used;
+        out.num_iters = s.num_iters;
+        out.error_log = s.error_log;
+        out.duration_total = s.duration_total_ms * 1e-3;
+        out.avg_duration_iter = s.num_iters ? s.duration_device_ms * 1e-3 / s.num_iters : 0.0;
+        return out;
+    }
+
+private:
+    CTICPOptions options_;
+};
+
+}  // namespace ct_icp_gpu

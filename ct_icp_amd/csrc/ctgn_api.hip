@@ -304,38 +304,27 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
         hipLaunchKernelGGL(k_accumulate_lane, dim3(grid), dim3(LANE_BLOCK), lane_kernel_smem(), h->stream, mv, kv,
                            h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0);
     } else {
-        const bool hist = h->variant != 2;
-        if (h->variant == 3 && mv.nb == 1) {
-            const int rb = std::min(resident_blocks(h, k_accumulate_rows<1, true, true>, ROW_BLOCK, rows_kernel_smem<1>()), MAX_PARTIAL_BLOCKS);
+        // one instantiation per (sweep half-width, selection flavour, instrumentation, waves per SIMD)
+        auto launch = [&](auto kernel, size_t smem, unsigned long long *prof) {
+            const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
-            hipLaunchKernelGGL((k_accumulate_rows<1, true, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
-                               mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, h->d_prof);
-            HIPCHK(h, hipGetLastError());
-            if (ev) HIPCHK(h, hipEventRecord(ev->stop, h->stream));
-            h->last_grid = grid;
-            return CTGN_OK;
-        }
-        int res_blocks;
-        if (mv.nb == 1) res_blocks = hist ? resident_blocks(h, k_accumulate_rows<1, true>, ROW_BLOCK, rows_kernel_smem<1>())
-                                          : resident_blocks(h, k_accumulate_rows<1, false>, ROW_BLOCK, rows_kernel_smem<1>());
-        else res_blocks = hist ? resident_blocks(h, k_accumulate_rows<2, true>, ROW_BLOCK, rows_kernel_smem<2>())
-                               : resident_blocks(h, k_accumulate_rows<2, false>, ROW_BLOCK, rows_kernel_smem<2>());
-        res_blocks = std::min(res_blocks, MAX_PARTIAL_BLOCKS);
-        const int rounds = pick_rounds(h->n_kp, res_blocks * ROW_WAVES);
-        const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
-        grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, res_blocks));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
+                               dv, first_iter ? 1 : 0, rounds, prof);
+        };
         if (mv.nb == 1) {
-            if (hist) hipLaunchKernelGGL((k_accumulate_rows<1, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
-                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
-            else hipLaunchKernelGGL((k_accumulate_rows<1, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<1>(), h->stream,
-                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
+            const size_t sm = rows_kernel_smem<1>();
+            switch (h->variant) {
+                case 2: launch(k_accumulate_rows<1, false, false, 3>, sm, nullptr); break;
+                case 3: launch(k_accumulate_rows<1, true, true, 3>, sm, h->d_prof); break;
+                case 4: launch(k_accumulate_rows<1, true, false, 4>, sm, nullptr); break;
+                default: launch(k_accumulate_rows<1, true, false, 3>, sm, nullptr); break;
+            }
         } else {
-            if (hist) hipLaunchKernelGGL((k_accumulate_rows<2, true>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
-                                         mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
-            else hipLaunchKernelGGL((k_accumulate_rows<2, false>), dim3(grid), dim3(ROW_BLOCK), rows_kernel_smem<2>(), h->stream,
-                                    mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds, nullptr);
+            const size_t sm = rows_kernel_smem<2>();
+            if (h->variant == 2) launch(k_accumulate_rows<2, false, false, 3>, sm, nullptr);
+            else launch(k_accumulate_rows<2, true, false, 3>, sm, nullptr);
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -741,6 +730,9 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
     h->gn_active = false;
     const GnState &s = *h->h_state;
     if (h->profiling) harvest_events(h, s.iter + (s.failed ? 1 : 0));
+    if (h->gn_opts.debug_print > 1)
+        std::fprintf(stderr, "[ctgn] k_reduce_solve clocks: reduce %llu factorise %llu substitute %llu update %llu\n",
+                     s.solve_cycles[0], s.solve_cycles[1], s.solve_cycles[2], s.solve_cycles[3]);
     if (pose_out) for (int i = 0; i < 14; ++i) pose_out[i] = s.pose[i];
     if (summary) {
         std::memset(summary, 0, sizeof(*summary));
@@ -884,7 +876,7 @@ ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[8], int32_t reset) {
 }
 
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant) {
-    if (!h || variant < 0 || variant > 3) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h || variant < 0 || variant > 4) return CTGN_ERR_INVALID_ARGUMENT;
     h->variant = variant;
     return CTGN_OK;
 }

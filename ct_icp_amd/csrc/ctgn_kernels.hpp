@@ -72,6 +72,7 @@ struct GnState {
     int done;                // stop flag: converged, failed or error
     int failed;              // fewer than 100 keypoints contributed (ct_icp.cpp:860-871)
     int n_used;
+    unsigned long long solve_cycles[4];   // shader clocks of the last k_reduce_solve: reduce | factorise | substitute | pose update
 };
 
 struct DebugView {
@@ -356,6 +357,59 @@ __device__ __forceinline__ int row_scan_i32(int v) {
     return v;
 }
 
+// Order in which the row kernel probes the (2 NB + 1)^3 sweep voxels: by squared offset from the query's voxel
+// (centre, faces, edges, corners, ...), ties by the reference's x-major sweep index. The VALUES are those sweep
+// indices v = (ox+NB)*S*S + (oy+NB)*S + (oz+NB): they — not the probing order — define the visit order used for
+// tie-breaking, so any probing order yields the reference's result. 255 pads the last batch of 16.
+template <int NB>
+struct SweepOrder {
+    uint8_t v[(((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 15) / 16) * 16];
+};
+template <int NB>
+constexpr SweepOrder<NB> make_sweep_order() {
+    constexpr int S = 2 * NB + 1, V = S * S * S, PAD = ((V + 15) / 16) * 16;
+    SweepOrder<NB> t{};
+    int key[PAD] = {};
+    for (int i = 0; i < PAD; ++i) { t.v[i] = 255; key[i] = 1 << 30; }
+    for (int v = 0; v < V; ++v) {
+        const int ox = v / (S * S) - NB, oy = (v / S) % S - NB, oz = v % S - NB;
+        const int kv = (ox * ox + oy * oy + oz * oz) * 256 + v;
+        int pos = v;                                   // insertion sort
+        while (pos > 0 && key[pos - 1] > kv) { key[pos] = key[pos - 1]; t.v[pos] = t.v[pos - 1]; --pos; }
+        key[pos] = kv;
+        t.v[pos] = (uint8_t) v;
+    }
+    return t;
+}
+__constant__ SweepOrder<1> c_sweep1 = make_sweep_order<1>();
+__constant__ SweepOrder<2> c_sweep2 = make_sweep_order<2>();
+
+// Distance from q to the interval of coordinates that Voxel::Coordinates maps to index `vox` (int(p / res) truncates
+// toward zero, so index 0 is (-res, res) and a negative index v is ((v-1) res, v res]; src/SlamCore/types.cxx:13-20).
+__device__ __forceinline__ double axis_gap(double q, int vox, double res) {
+    double lo, hi;
+    if (vox > 0) { lo = vox * res; hi = lo + res; }
+    else if (vox < 0) { hi = vox * res; lo = hi - res; }
+    else { lo = -res; hi = res; }
+    return fmax(fmax(lo - q, q - hi), 0.0);
+}
+
+// Issue the hash probe of this lane's voxel of probe batch `it`: sweep index v (255 = none), skipped when the
+// keypoint has no search or when the whole voxel lies farther than the radius from the query (exact: no point of
+// such a voxel can pass map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
+template <int NB>
+__device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
+                                             double qx, double qy, double qz, int &v_out) {
+    constexpr int S = 2 * NB + 1;
+    const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
+    v_out = v;
+    const int vv = (v == 255) ? 0 : v;
+    const int vx = kx + vv / (S * S) - NB, vy = ky + (vv / S) % S - NB, vz = kz + vv % S - NB;
+    const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
+    const bool reachable = gx * gx + gy * gy + gz * gz <= m.r2thr * (1.0 + 1e-8);
+    return probe_issue(m, searching && v != 255 && reachable, vx, vy, vz);
+}
+
 // the 16 ballot bits of DPP row `row`
 __device__ __forceinline__ uint32_t row_bits(unsigned long long ballot, int row) {
     return (uint32_t) (ballot >> (16 * row)) & 0xffffu;
@@ -389,70 +443,70 @@ struct WaveScratch {
 };
 
 // k nearest of the row's list (d2, vis)[0..Ln) under the total order (d2, vis); winners are written back
-// sorted ascending at [0..min(Ln,k)). HIST: first cut the list with a 16-bin histogram of d2 over [0, hi].
+// sorted ascending at [0..min(Ln,k)). HIST: first cut the list with a 16-bin histogram of d2 over [0, hi]
+// (one bin per lane): only the bins up to the one in which the running count reaches k can hold winners.
+// All loops run to the wave-uniform maximum over the 4 rows; loads are unconditional (indices stay inside the
+// arrays) and masked afterwards, so the code is branch-light.
 template <int OCC, bool HIST>
 __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int sub, int row, double hi) {
-    // wave-uniform loop bounds (rows differ): the max over the wave
     int maxLn = max_over_rows(Ln);
     if (maxLn <= k) return Ln;
-    double od2[MAXOWN];
-    uint32_t ovis[MAXOWN];
-#pragma unroll
-    for (int m = 0; m < MAXOWN; ++m) {
-        int e = sub + 16 * m;
-        bool ok = e < Ln;
-        od2[m] = ok ? R.d2[e] : __longlong_as_double(0x7ff0000000000000ll);
-        ovis[m] = ok ? R.vis[e] : 0xffffffffu;
-    }
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const uint32_t lt_mask = (1u << sub) - 1u;
     if (HIST) {
-        // 16-bin histogram of d2 over [0, hi]; keep only the bins up to the one where the count reaches k
         R.hist[sub] = 0;
         const double scale = hi > 0.0 ? 16.0 / hi : 0.0;
-        int bin[MAXOWN];
-#pragma unroll
-        for (int m = 0; m < MAXOWN; ++m) {
-            int e = sub + 16 * m;
-            int b = (int) (od2[m] * scale);
-            bin[m] = b > 15 ? 15 : b;
-            if (e < Ln && Ln > k) atomicAdd(&R.hist[bin[m]], 1u);
+        const int nown = (maxLn + 15) >> 4;
+        const bool cut = Ln > k;
+        for (int m = 0; m < nown; ++m) {
+            const int e = sub + 16 * m;
+            const int b = min(15, (int) (R.d2[e] * scale));
+            if (cut && e < Ln) atomicAdd(&R.hist[b], 1u);
         }
-        int cum = row_scan_i32((int) R.hist[sub]);
-        unsigned long long reach = __ballot(cum >= k);
-        uint32_t rowmask = (uint32_t) (reach >> (16 * row)) & 0xffffu;
-        int bb = rowmask ? (__ffs(rowmask) - 1) : 15;
-        if (Ln > k) {
-            // stable in-place compaction of the entries with bin <= bb (all owned entries are in registers)
-            int base = 0;
-#pragma unroll
-            for (int m = 0; m < MAXOWN; ++m) {
-                int e = sub + 16 * m;
-                bool keep = (e < Ln) && (bin[m] <= bb);
-                uint32_t km = row_bits(__ballot(keep), row);
-                int pos = base + __popc(km & ((1u << sub) - 1u));
-                if (keep) { R.d2[pos] = od2[m]; R.vis[pos] = ovis[m]; }
-                base += __popc(km);
+        const int cum = row_scan_i32((int) R.hist[sub]);
+        const uint32_t reach = row_bits(__ballot(cum >= k), row);
+        const int bb = reach ? (__ffs(reach) - 1) : 15;
+        // stable in-place compaction of the entries with bin <= bb: step m reads 16 entries, then writes at
+        // positions <= the ones it read (LDS operations of a wave execute in order)
+        int base = 0;
+        for (int m = 0; m < nown; ++m) {
+            const int e = sub + 16 * m;
+            const double d = R.d2[e];
+            const uint32_t vv = R.vis[e];
+            const bool keep = (e < Ln) && (!cut || min(15, (int) (d * scale)) <= bb);
+            const uint32_t km = row_bits(__ballot(keep), row);
+            if (keep) {
+                const int pos = base + __popc(km & lt_mask);
+                R.d2[pos] = d;
+                R.vis[pos] = vv;
             }
-            Ln = base;
+            base += __popc(km);
         }
+        Ln = base;
         maxLn = max_over_rows(Ln);
-#pragma unroll
-        for (int m = 0; m < MAXOWN; ++m) {
-            int e = sub + 16 * m;
-            bool ok = e < Ln;
-            od2[m] = ok ? R.d2[e] : __longlong_as_double(0x7ff0000000000000ll);
-            ovis[m] = ok ? R.vis[e] : 0xffffffffu;
-        }
     }
     // rank sort: rank(e) = #{f : key_f < key_e}; ranks are distinct, winners land at their rank
+    double od2[MAXOWN];
+    uint32_t ovis[MAXOWN];
     int rank[MAXOWN];
 #pragma unroll
-    for (int m = 0; m < MAXOWN; ++m) rank[m] = 0;
+    for (int m = 0; m < MAXOWN; ++m) {
+        const int e = sub + 16 * m;
+        const bool ok = e < Ln;
+        const double d = R.d2[e];
+        const uint32_t vv = R.vis[e];
+        od2[m] = ok ? d : INF;
+        ovis[m] = ok ? vv : 0xffffffffu;
+        rank[m] = 0;
+    }
     const int mcount = (maxLn + 15) >> 4;
 #pragma unroll 4
     for (int f = 0; f < maxLn; ++f) {
-        bool fv = f < Ln;
-        double fd2 = fv ? R.d2[f] : __longlong_as_double(0x7ff0000000000000ll);
-        uint32_t fvis = fv ? R.vis[f] : 0xffffffffu;
+        const bool fv = f < Ln;
+        const double fdr = R.d2[f];
+        const uint32_t fvr = R.vis[f];
+        const double fd2 = fv ? fdr : INF;
+        const uint32_t fvis = fv ? fvr : 0xffffffffu;
 #pragma unroll
         for (int m = 0; m < MAXOWN; ++m) {
             if (m < mcount) rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
@@ -461,7 +515,7 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
     // every row is written back sorted (rows with <= k entries keep them all)
 #pragma unroll
     for (int m = 0; m < MAXOWN; ++m) {
-        int e = sub + 16 * m;
+        const int e = sub + 16 * m;
         if (e < Ln && rank[m] < k) { R.d2[rank[m]] = od2[m]; R.vis[rank[m]] = ovis[m]; }
     }
     return Ln < k ? Ln : k;
@@ -471,8 +525,8 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
 // PROF: per-phase shader-clock accounting (s_memtime) summed over waves into prof[0..7]:
 //   0 phase A (transform, voxel) | 1 hash probes + chunk lists | 2 candidate streaming | 3 in-stream prunes |
 //   4 final selection | 5 covariance sums | 6 phase C (normal, residual, u) | 7 phase D (u u^T accumulation)
-template <int NB, bool HIST, bool PROF = false>
-__global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
+template <int NB, bool HIST, bool PROF = false, int WPS = 4>
+__global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
                                                                unsigned long long *prof = nullptr) {
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
@@ -533,10 +587,11 @@ __global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, K
 
         // ---------------- phase B: the row works on the keypoint owned by its lane `r`
         Probe nxt;
+        int nxt_v;
         {
             const int src0 = row * 16;
-            const int kx0 = W.kx[src0], ky0 = W.ky[src0], kz0 = W.kz[src0];
-            nxt = probe_issue(map, kx0 != INT_MIN, kx0 + sub / (S * S) - NB, ky0 + (sub / S) % S - NB, kz0 + sub % S - NB);
+            const int kx0 = W.kx[src0];
+            nxt = issue_batch<NB>(map, 0, sub, kx0 != INT_MIN, kx0, W.ky[src0], W.kz[src0], W.px[src0], W.py[src0], W.pz[src0], nxt_v);
         }
         for (int r = 0; r < rounds; ++r) {
             const int src = row * 16 + r;
@@ -544,34 +599,30 @@ __global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, K
             const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
             const bool searching = kx != INT_MIN;
 
-            // B1 + B2, interleaved per batch of 16 sweep voxels:
-            //   probe 16 voxels (one per lane) -> occupied ones appended to R.occ in sweep order (x-major, as the
-            //   reference's loops, map.h:470-472) -> one chunk per 16 points of each occupied voxel -> the row streams
-            //   the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
+            // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
+            //   probe 16 voxels (one per lane) -> R.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
+            //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
             //   loads of chunk c+1 in flight while chunk c is tested against the radius / current k-th best and
-            //   compacted into the row's LDS candidate list.
-            int occ_n = 0, Ln = 0;
-            double kth_d2 = map.r2thr;
-            uint32_t kth_vis = 0xffffffffu;       // (r2thr, +inf): "d2 <= r2thr" until a k-th best is known
+            //   compacted into the row's LDS candidate list. A candidate's visit index is (sweep index v << 6) | slot:
+            //   the reference's x-major sweep + insertion order (map.h:470-480), whatever the probing order.
+            int Ln = 0;
+            double kth_d2 = map.r2thr;            // admission bound of the stream: the radius, then the k-th best so far
             const uint32_t lt_mask = (1u << sub) - 1u;
 #pragma unroll
             for (int it = 0; it < VIT; ++it) {
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
                 // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
                 Probe cur = nxt;
+                const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
-                    const int v = (it + 1) * 16 + sub;
-                    nxt = probe_issue(map, searching && v < V, kx + v / (S * S) - NB, ky + (v / S) % S - NB, kz + v % S - NB);
+                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v);
                 } else if (r + 1 < rounds) {
                     const int src2 = row * 16 + r + 1;
-                    const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
-                    nxt = probe_issue(map, kx2 != INT_MIN, kx2 + sub / (S * S) - NB, ky2 + (sub / S) % S - NB, kz2 + sub % S - NB);
+                    const int kx2 = W.kx[src2];
+                    nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v);
                 }
                 const uint32_t bc = probe_resolve(map, cur);
-                const uint32_t fm = row_bits(__ballot(bc != 0), row);
-                const int myj = occ_n + __popc(fm & lt_mask);
-                if (bc) R.occ[myj] = bc;
-                occ_n += __popc(fm);
+                if (bc) R.occ[cur_v] = bc;
                 const int cnt_mine = (int) (bc & 127u);
                 const uint32_t off_mine = (bc >> 7) * stride3;
                 int nchunk = 0;
@@ -582,7 +633,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, K
                     if (!hb) break;
                     const uint32_t hm = row_bits(hb, row);
                     if (has) R.chunk[nchunk + __popc(hm & lt_mask)] =
-                            make_uint2(off_mine + 128u * hh, ((((uint32_t) myj << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
+                            make_uint2(off_mine + 128u * hh, ((((uint32_t) cur_v << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
                     nchunk += __popc(hm);
                 }
                 CTGN_TICK(1)
@@ -611,7 +662,9 @@ __global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, K
                     fetch(c + 1);
                     const double dx = x - qx, dy = y - qy, dz = z - qz;
                     const double d2 = dx * dx + dy * dy + dz * dz;
-                    const bool pass = valid && ((d2 < kth_d2) || (d2 == kth_d2 && vis < kth_vis));
+                    // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
+                    // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
+                    const bool pass = valid && d2 <= kth_d2;
                     const uint32_t pm = row_bits(__ballot(pass), row);
                     if (pass) {
                         const int pos = Ln + __popc(pm & lt_mask);
@@ -623,7 +676,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 4) void k_accumulate_rows(MapView map, K
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
                         Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
-                        if (Ln >= k) { kth_d2 = R.d2[k - 1]; kth_vis = R.vis[k - 1]; }
+                        if (Ln >= k) kth_d2 = R.d2[k - 1];
                         CTGN_TICK(3)
                     }
                 }
@@ -772,20 +825,47 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
     return v;
 }
 
+#define WSYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
                                                               GnParams prm, int mode, int min_used) {
     __shared__ double s_sys[SYS_N];
     __shared__ double s_m[144];
     __shared__ double s_temp[12];
     __shared__ double s_x[12];
+    __shared__ double s_b[12];
+    __shared__ int s_perm[12];
+    __shared__ double s_sc[12];
+    __shared__ double s_q[8];
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tc0 = __builtin_readcyclecounter();
     if (mode != 2) {
-        for (int e = wave; e < SYS_N; e += SOLVE_BLOCK / 64) {
-            double s = 0.0;
-            for (int b = lane; b < nblocks; b += 64) s += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
-            s = wave_sum_fixed(s);
-            if (lane == 0) { sys[e] = s; s_sys[e] = s; }
+        // wave w owns entries w, w+16, ..., w+80: six independent lane-strided sums (loads of all six in flight
+        // together), then six fixed shuffle trees
+        constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 4;
+        double acc[EPW];
+#pragma unroll
+        for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
+        for (int b0 = 0; b0 < nblocks; b0 += 64 * RU) {
+            double v[RU][EPW];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {             // RU * 6 independent loads in flight
+                const int b = b0 + 64 * u + lane;
+                const int bb = b < nblocks ? b : 0;
+#pragma unroll
+                for (int q = 0; q < EPW; ++q) v[u][q] = partials[(size_t) (wave + 16 * q) * MAX_PARTIAL_BLOCKS + bb];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const bool ok = b0 + 64 * u + lane < nblocks;
+#pragma unroll
+                for (int q = 0; q < EPW; ++q) acc[q] += ok ? v[u][q] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < EPW; ++q) {
+            const double s = wave_sum_fixed(acc[q]);
+            if (lane == 0) { sys[wave + 16 * q] = s; s_sys[wave + 16 * q] = s; }
         }
     } else {
         if (tid < SYS_N) s_sys[tid] = sys[tid];
@@ -794,6 +874,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     if (mode == 1 || wave != 0) return;
 
     // ---- wave 0 only from here
+    const unsigned long long tc1 = __builtin_readcyclecounter();
     const int n_used = (int) (s_sys[90] + 0.5);
     if (n_used < min_used) {              // ct_icp.cpp:860-871 — soft failure, pose untouched
         if (lane == 0) { st->n_used = n_used; st->failed = 1; st->done = 1; }
@@ -808,7 +889,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
         s_m[12 * j + i] = v;
     }
     double bi = (lane < 12) ? s_sys[78 + lane] / dn : 0.0;
-    __builtin_amdgcn_wave_barrier();
+    WSYNC();
     if (prm.has_prior && lane < 3) {                              // ct_icp.cpp:885-910
         const int c = lane;
         s_m[13 * (3 + c)] += prm.beta_c;
@@ -823,98 +904,114 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
             bi -= prm.beta_e * (st->pose[11 + c] - st->pose[4 + c] - prm.prev_e[c] + prm.prev_b[c]);
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    volatile double *m = s_m;
-    volatile double *temp = s_temp;
+    WSYNC();
+    // LDS traffic of this single wave executes in program order; WSYNC only stops the compiler from moving
+    // accesses across the phase boundaries (no volatile: reads inside a phase can be batched)
+    double *m = s_m;
+    double *temp = s_temp;
+    int *perm = s_perm;                   // perm[p] = original index of the element now at position p
     const int i = lane;                   // row owned by this lane (valid for lane < 12)
-    int transp_mine = i;                  // transposition chosen at step k == lane
+    if (i < 12) { perm[i] = i; s_b[i] = bi; }
+    WSYNC();
     for (int k = 0; k < 12; ++k) {
-        // pivot: first index of the largest |diagonal| among k..11
+        // pivot: first index of the largest |diagonal| among k..11 — DPP butterfly over lanes 0..15 (no LDS round trip)
         double dv = (i >= k && i < 12) ? fabs(m[13 * i]) : -1.0;
         int di = i;
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            double ov = __shfl_xor(dv, off);
-            int oi = __shfl_xor(di, off);
-            if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }
+#define CTGN_PIVOT_STEP(CTRL)                                                                    \
+        {                                                                                        \
+            const double ov = dpp_f64<CTRL>(dv);                                                 \
+            const int oi = __builtin_amdgcn_update_dpp(0, di, CTRL, 0xf, 0xf, false);            \
+            if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }                          \
         }
-        const int big = __shfl(di, 0);
-        if (i == k) transp_mine = big;
+        CTGN_PIVOT_STEP(0xB1) CTGN_PIVOT_STEP(0x4E) CTGN_PIVOT_STEP(0x141) CTGN_PIVOT_STEP(0x140)
+#undef CTGN_PIVOT_STEP
+        const int big = __builtin_amdgcn_readfirstlane(di);
         if (big != k) {                   // symmetric swap on the lower triangle
             if (i < k) { double t = m[12 * k + i]; m[12 * k + i] = m[12 * big + i]; m[12 * big + i] = t; }
             if (i > big && i < 12) { double t = m[12 * i + k]; m[12 * i + k] = m[12 * i + big]; m[12 * i + big] = t; }
             if (i > k && i < big) { double t = m[12 * i + k]; m[12 * i + k] = m[12 * big + i]; m[12 * big + i] = t; }
-            if (i == 0) { double t = m[13 * k]; m[13 * k] = m[13 * big]; m[13 * big] = t; }
+            if (i == 0) {
+                double t = m[13 * k]; m[13 * k] = m[13 * big]; m[13 * big] = t;
+                int pk = perm[k]; perm[k] = perm[big]; perm[big] = pk;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        WSYNC();
         if (i < k) temp[i] = m[13 * i] * m[12 * k + i];
-        __builtin_amdgcn_wave_barrier();
+        WSYNC();
         if (i >= k && i < 12) {
             double a2 = 0.0;
             for (int j = 0; j < k; ++j) a2 += m[12 * i + j] * temp[j];
             m[12 * i + k] -= a2;
         }
-        __builtin_amdgcn_wave_barrier();
+        WSYNC();
         const double akk = m[13 * k];
         if (i > k && i < 12 && fabs(akk) > 0.0) m[12 * i + k] /= akk;
-        __builtin_amdgcn_wave_barrier();
+        WSYNC();
     }
-    // solve: y = P b ; L^-1 ; D^-1 ; L^-T ; P^T — lane i keeps y_i in a register
-    double y = bi;
-    for (int k = 0; k < 12; ++k) {
-        const int tk = __shfl(transp_mine, k);
-        if (tk != k) {
-            const double yk = __shfl(y, k), yt = __shfl(y, tk);
-            if (i == k) y = yt; else if (i == tk) y = yk;
-        }
-    }
+    const unsigned long long tc2 = __builtin_readcyclecounter();
+    // solve: y = P b ; L^-1 ; D^-1 ; L^-T ; x = P^T y. Lane i keeps y_i, row i and column i of L in registers and the
+    // running y_j is broadcast with readlane (SALU) — no LDS traffic in the substitutions.
+    const int ii = (i < 12) ? i : 0;
+    double y = s_b[perm[ii]];
+    double Lrow[12], Lcol[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { Lrow[j] = m[12 * ii + j]; Lcol[j] = m[12 * j + ii]; }
+    const double dii = m[13 * ii];
+#pragma unroll
     for (int j = 0; j < 12; ++j) {          // forward: after step j, y_j is final
-        const double yj = __shfl(y, j);
-        if (i > j && i < 12) y -= m[12 * i + j] * yj;
+        const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), j),
+                                           __builtin_amdgcn_readlane(__double2loint(y), j));
+        if (i > j) y -= Lrow[j] * yj;
     }
-    if (i < 12) { const double d = m[13 * i]; y = (fabs(d) > DBL_MIN) ? y / d : 0.0; }
+    y = (fabs(dii) > DBL_MIN) ? y / dii : 0.0;
+#pragma unroll
     for (int j = 11; j >= 0; --j) {         // backward with L^T
-        const double yj = __shfl(y, j);
-        if (i < j) y -= m[12 * j + i] * yj;
+        const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), j),
+                                           __builtin_amdgcn_readlane(__double2loint(y), j));
+        if (i < j) y -= Lcol[j] * yj;
     }
-    for (int k = 11; k >= 0; --k) {
-        const int tk = __shfl(transp_mine, k);
-        if (tk != k) {
-            const double yk = __shfl(y, k), yt = __shfl(y, tk);
-            if (i == k) y = yt; else if (i == tk) y = yk;
-        }
+    if (i < 12) s_x[perm[i]] = y;
+    WSYNC();
+    const unsigned long long tc3 = __builtin_readcyclecounter();
+    // pose update (ct_icp.cpp:916-962), spread over a few lanes: the six sin/cos pairs on lanes 0..5, the begin and
+    // end quaternion updates on lanes 0 and 1, the bookkeeping on lane 0
+    if (lane < 6) {
+        double sn, cs;
+        sincos(s_x[lane < 3 ? lane : lane + 3], &sn, &cs);
+        s_sc[2 * lane] = sn;
+        s_sc[2 * lane + 1] = cs;
     }
-    if (i < 12) s_x[i] = y;
-    __builtin_amdgcn_wave_barrier();
+    WSYNC();
+    if (lane < 2) {
+        const int e = lane;               // 0: begin pose, 1: end pose
+        const double *sc = s_sc + 6 * e;
+        double Rd[9], Q[9], P[9];
+        euler_rotation_sc(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], Rd);          // :919-932 / :939-947
+        const Quat q0{st->pose[7 * e], st->pose[7 * e + 1], st->pose[7 * e + 2], st->pose[7 * e + 3]};
+        quat_to_matrix(q0, Q);
+        mat3_mul(Rd, Q, P);
+        const Quat q = quat_normalized(matrix_to_quat(P));                        // :950-955, :961-962
+        st->pose[7 * e] = q.x; st->pose[7 * e + 1] = q.y; st->pose[7 * e + 2] = q.z; st->pose[7 * e + 3] = q.w;
+        for (int c = 0; c < 3; ++c) st->pose[7 * e + 4 + c] += s_x[6 * e + 3 + c];
+        s_q[4 * e] = q.x; s_q[4 * e + 1] = q.y; s_q[4 * e + 2] = q.z; s_q[4 * e + 3] = q.w;
+    }
+    WSYNC();
     if (lane != 0) return;
-
-    double x[12];
-    for (int c = 0; c < 12; ++c) x[c] = s_x[c];
     st->n_used = n_used;
-    double Rb[9], Re[9], Q[9], P[9];
-    euler_rotation(x[0], x[1], x[2], Rb);                           // :916-932
-    euler_rotation(x[6], x[7], x[8], Re);                           // :935-947
-    quat_to_matrix(st_qb(st), Q);
-    mat3_mul(Rb, Q, P);
-    Quat qb = quat_normalized(matrix_to_quat(P));                   // :950-951, :961
-    quat_to_matrix(st_qe(st), Q);
-    mat3_mul(Re, Q, P);
-    Quat qe = quat_normalized(matrix_to_quat(P));                   // :953-954, :962
-    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
-    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
-    for (int c = 0; c < 3; ++c) {
-        st->pose[4 + c] += x[3 + c];                                // :952
-        st->pose[11 + c] += x[9 + c];                               // :955
-    }
+    const Quat qb{s_q[0], s_q[1], s_q[2], s_q[3]}, qe{s_q[4], s_q[5], s_q[6], s_q[7]};
     SlerpPair sp = slerp_prepare(qb, qe);
     st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
     double nrm = 0.0;
-    for (int c = 0; c < 12; ++c) { nrm += x[c] * x[c]; st->x[c] = x[c]; }
+    for (int c = 0; c < 12; ++c) { const double xc = s_x[c]; nrm += xc * xc; st->x[c] = xc; }
     nrm = sqrt(nrm);
     st->step_norm = nrm;
     st->iter += 1;
     if (nrm < prm.thr_norm) st->done = 1;                           // :978-980
+    st->solve_cycles[0] = tc1 - tc0; st->solve_cycles[1] = tc2 - tc1; st->solve_cycles[2] = tc3 - tc2;
+    st->solve_cycles[3] = __builtin_readcyclecounter() - tc3;
 }
+
+#undef WSYNC
 
 // Re-transform every keypoint with the final pose (ct_icp.cpp:964-966 of the last executed iteration).
 __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st) {

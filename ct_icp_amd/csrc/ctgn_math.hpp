@@ -130,6 +130,11 @@ CTGN_HD Quat matrix_to_quat(const double R[9]) {
 }
 
 // Rz(gamma) Ry(beta) Rx(alpha) exactly as spelled at reference src/ct_icp/ct_icp.cpp:919-932.
+CTGN_HD void euler_rotation_sc(double sa, double ca, double sb, double cb, double sg, double cg, double R[9]) {
+    R[0] = cg * cb; R[1] = -sg * ca + cg * sb * sa; R[2] = sg * sa + cg * sb * ca;
+    R[3] = sg * cb; R[4] = cg * ca + sg * sb * sa;  R[5] = -cg * sa + sg * sb * ca;
+    R[6] = -sb;     R[7] = cb * sa;                 R[8] = cb * ca;
+}
 CTGN_HD void euler_rotation(double al, double be, double ga, double R[9]) {
     double sa = sin(al), ca = cos(al), sb = sin(be), cb = cos(be), sg = sin(ga), cg = cos(ga);
     R[0] = cg * cb; R[1] = -sg * ca + cg * sb * sa; R[2] = sg * sa + cg * sb * ca;

@@ -229,7 +229,8 @@ ctgn_status ctgn_set_profiling(ctgn_handle h, int32_t enable);
 ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t *launches, int32_t reset);
 /* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
  * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection,
- * 3 = variant 0 instrumented with per-phase shader clocks (see ctgn_phase_cycles). Test / measurement hook. */
+ * 3 = variant 0 instrumented with per-phase shader clocks (see ctgn_phase_cycles), 4 = variant 0 compiled for
+ * 4 waves per SIMD instead of 3 (A/B hook). Test / measurement hook. */
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,

@@ -14,8 +14,9 @@ for v in ${VARIANTS:-0 2 1}; do
 done
 if [ "${PROFILE:-1}" = "1" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 20 --warmup 3 --no-cpu-baseline) > gpurun_out/rocprof.log 2>&1
-  find gpurun_out/prof -name "*kernel_stats*" | head -3 | xargs -r head -20 >> gpurun_out/rocprof.log 2>&1
-  find gpurun_out/prof -name "*kernel_trace*" -size +2M -delete
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 20 --warmup 3 --no-cpu-baseline) > gpurun_out/rocprof.log 2>&1
+  find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r cat > gpurun_out/kernel_stats.csv
+  find gpurun_out/prof -name "*kernel_trace.csv" -delete
+  cut -c1-160 gpurun_out/kernel_stats.csv
 fi
-tail -n 5 gpurun_out/smoke.log; tail -n 30 gpurun_out/pytest_gpu.log; for f in gpurun_out/bench_v*.log; do tail -n 2 $f | cut -c1-1500; done; tail -n 25 gpurun_out/rocprof.log
+tail -n 5 gpurun_out/smoke.log; tail -n 30 gpurun_out/pytest_gpu.log; for f in gpurun_out/bench_v*.log; do tail -n 2 $f | cut -c1-1500; done; true

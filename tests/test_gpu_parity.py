@@ -327,3 +327,14 @@ def test_full_size_properties(config_b_full):
     s.set_keypoints(sc.raw, world0, sc.t)
     probed, hit, pts = s.count_traffic()
     assert probed == 27 * n and 0 < hit < probed and pts > 20 * n
+
+
+def test_cpp_adapter_program():
+    """The C++ host adapter (ct_icp_amd/cpp/ct_icp_gpu.hpp: the reference's class names over the C ABI) registers a scan
+    and recovers the known rigid offset."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ct_icp_amd", "cpp", "adapter_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("adapter ok"), out.stdout + out.stderr
