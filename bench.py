@@ -26,6 +26,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 B_KP, B_SLOT, B_PT = 32, 16, 24    # algorithmic bytes: keypoint record, hash slot, map point (FP64 xyz storage)
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per accumulate launch from the committed rocprofv3 PMC passes of this workload (bench.py itself
+    cannot collect PMCs): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE,
+    both reported in KB. Returns (bytes or None, source string)."""
+    import glob
+    import re
+    fetch = write = None
+    src = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pass*.txt"))):
+        txt = open(path).read()
+        blk = txt.split("ctgn::k_reduce_solve")[0]
+        if "k_accumulate_rows" not in blk:
+            continue
+        m = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", blk)
+        if m:
+            fetch, _ = float(m.group(1)), src.append(os.path.basename(path))
+        m = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", blk)
+        if m:
+            write, _ = float(m.group(1)), src.append(os.path.basename(path))
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, "profiles/" + "+".join(sorted(set(src[-2:]))) + " (2*FETCH_SIZE + WRITE_SIZE)"
+
+
 def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
     """Deterministic config-B inputs: map insert list (world points of `map_frames` preceding sweeps after the 0.5 m
     frame grid) + the sweep to register. Cached as .npz because ray-casting 21 sweeps in NumPy takes ~30 s."""
@@ -149,6 +173,7 @@ def main():
     if rank == 0:
         value = total_kp * args.steps / dt
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes() if args.variant == 0 and world == 1 else (None, None)
         result = {
             "metric": "registered keypoints/sec per GN iter", "value": value, "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -162,7 +187,7 @@ def main():
                        "kernel_variant": args.variant},
             "frames_per_sec_equiv": 1.0 / (dt / args.steps * 5) if dt > 0 else None,   # 5 GN iterations per frame (driving profile)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_accumulate_rows" if args.variant != 1 else "k_accumulate_lane",
                          "kernel_ms_avg": kern_ms, "kernel_launches": kern_launches,
                          "alg_bytes_per_launch": alg_bytes,
