@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--map-frames", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--presort", action="store_true", help="experiment: sort the keypoints by home voxel on the host")
     ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
     args = ap.parse_args()
 
@@ -129,6 +130,10 @@ def main():
     else:
         solver = cia.GnSolver(gm)
         run = lambda iters: solver.solve(pose0, inp["tbe"], options(iters), mm)[:2] + (None,)
+    if args.presort:
+        vox = np.trunc(world0 / 0.8).astype(np.int64)
+        order = np.lexsort((vox[:, 2], vox[:, 1], vox[:, 0]))
+        raw, t, world0 = raw[order], t[order], world0[order]
     solver.set_variant(args.variant)
     solver.set_keypoints(raw, world0, t)                       # inputs resident in HBM before the timed region
     probed, hit, points = solver.count_traffic()
@@ -153,10 +158,14 @@ def main():
     kern_ms, kern_launches = solver.kernel_timing(reset=True)
     solver.set_profiling(False)
     if args.variant == 3 and rank == 0:
-        pcs = solver.phase_cycles(reset=True)
+        pcs_all = solver.phase_cycles(reset=True)
+        pcs, fast_rounds, all_rounds = pcs_all[:8], pcs_all[8], pcs_all[9]
+        print(f"fast-path rounds: {fast_rounds} of {all_rounds}", file=sys.stderr)
         tot = float(sum(pcs)) or 1.0
         names = ["A transform", "B1 probes", "B2 stream", "B2 prunes", "B3 select", "B4 sums", "C normal/jac", "D accumulate"]
-        print("phase cycles: " + ", ".join(f"{n}={100 * c / tot:.1f}%" for n, c in zip(names, pcs)), file=sys.stderr)
+        print("phase cycles: " + ", ".join(f"{n}={100 * c / tot:.1f}%" for n, c in zip(names, pcs)) +
+              f" | total Mcycles/launch={tot / 1e6 / max(kern_launches, 1):.1f} abs=" +
+              ",".join(f"{c / 1e6 / max(kern_launches, 1):.1f}" for c in pcs), file=sys.stderr)
     assert summ.success and summ.num_iters == args.steps, summ
 
     if dist is not None:

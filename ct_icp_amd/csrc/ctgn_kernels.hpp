@@ -421,15 +421,29 @@ __device__ __forceinline__ int max_over_rows(int v) {
     return max(max(a, b), max(c, d));
 }
 
-// per-row LDS scratch
-template <int OCC>
-struct RowScratch {
+// per-row candidate list (always live during phase B)
+struct RowList {
     double d2[LCAP];
-    uint32_t vis[LCAP];       // (occupied-voxel index << 6) | slot : the visit order, and the way back to the point
-    uint32_t occ[OCC];        // block*128 + count of the occupied voxels, in sweep order
+    uint32_t vis[LCAP];       // (sweep voxel index << 6) | slot : the visit order, and the way back to the point
     uint32_t hist[16];
+};
+// per-row probe scratch of the generic path
+template <int OCC>
+struct RowProbe {
+    uint32_t occ[OCC];        // block*128 + count per sweep voxel of this row's keypoint
     uint2 chunk[64];          // per 16-point chunk of the probe batch in flight: .x = byte offset of its first x,
                               // .y = (visit index of its first point << 8) | points in the chunk (1..16)
+};
+// wave-shared neighbourhood of the fast path (NB = 1, BLK <= 32): when the four keypoints of a round live in the same
+// home voxel their 27-voxel neighbourhood is probed ONCE per wave and flattened into a dense candidate table, so the
+// rows stream 16 real candidates per step (no per-voxel padding) and all rows run the same number of steps. The table
+// stays valid for the following rounds with the same home voxel (keypoints are sorted by home voxel on upload).
+constexpr int STAGE_CAP = 27 * 32;
+struct SharedStage {
+    uint32_t off[STAGE_CAP];  // byte offset of candidate c's x in the block storage
+    uint16_t vis[STAGE_CAP];  // its visit index (sweep voxel << 6) | slot
+    uint32_t occ[28];         // block*128 + count per sweep voxel
+    uint2 chunk[56];          // .x = byte offset of the chunk's first x; .y = (visit base << 15) | (flat position << 5) | points
 };
 
 template <int OCC>
@@ -437,7 +451,13 @@ struct WaveScratch {
     double px[64], py[64], pz[64];     // world point of the tile's keypoints
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
     union {
-        RowScratch<OCC> row[4];
+        struct {
+            RowList list[4];
+            union {
+                RowProbe<OCC> probe[4];
+                SharedStage stage;
+            };
+        };
         double rec[64 * 13];           // phase D: u[12] | r per keypoint
     };
 };
@@ -447,8 +467,8 @@ struct WaveScratch {
 // (one bin per lane): only the bins up to the one in which the running count reaches k can hold winners.
 // All loops run to the wave-uniform maximum over the 4 rows; loads are unconditional (indices stay inside the
 // arrays) and masked afterwards, so the code is branch-light.
-template <int OCC, bool HIST>
-__device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int sub, int row, double hi) {
+template <bool HIST>
+__device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, int row, double hi) {
     int maxLn = max_over_rows(Ln);
     if (maxLn <= k) return Ln;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
@@ -484,6 +504,34 @@ __device__ __forceinline__ int row_select(RowScratch<OCC> &R, int Ln, int k, int
         }
         Ln = base;
         maxLn = max_over_rows(Ln);
+    }
+    if (HIST && maxLn <= 32) {
+        // Fast rank for <= 32 surviving entries per row: every lane owns entries `sub` and `sub + 16` and keeps their
+        // float32 keys (monotone roundings of d2) in registers; the keys are rotated round the DPP row 15 times and
+        // counted against the owned ones — no LDS traffic. float32 cannot separate every pair of doubles: a key that
+        // ties another one sends the whole wave to the exact rank below (rare).
+        const float FINF = __int_as_float(0x7f800000);
+        const int e0 = sub, e1 = sub + 16;
+        const double d0 = R.d2[e0], d1 = R.d2[e1];
+        const uint32_t v0 = R.vis[e0], v1 = R.vis[e1];
+        const float k0 = e0 < Ln ? (float) d0 : FINF, k1 = e1 < Ln ? (float) d1 : FINF;
+        int lt0 = (k1 < k0) ? 1 : 0, lt1 = (k0 < k1) ? 1 : 0;       // the lane's own pair
+        int le0 = (k1 <= k0) ? 1 : 0, le1 = (k0 <= k1) ? 1 : 0;
+        float r0 = k0, r1 = k1;
+        for (int step = 0; step < 15; ++step) {
+            r0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r0), 0x121, 0xf, 0xf, false));     // row_ror:1
+            r1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r1), 0x121, 0xf, 0xf, false));
+            lt0 += (r0 < k0) + (r1 < k0);
+            le0 += (r0 <= k0) + (r1 <= k0);
+            lt1 += (r0 < k1) + (r1 < k1);
+            le1 += (r0 <= k1) + (r1 <= k1);
+        }
+        const bool tie = (k0 < FINF && le0 != lt0) || (k1 < FINF && le1 != lt1);
+        if (!__any(tie)) {
+            if (e0 < Ln && lt0 < k) { R.d2[lt0] = d0; R.vis[lt0] = v0; }
+            if (e1 < Ln && lt1 < k) { R.d2[lt1] = d1; R.vis[lt1] = v1; }
+            return Ln < k ? Ln : k;
+        }
     }
     // rank sort: rank(e) = #{f : key_f < key_e}; ranks are distinct, winners land at their rank
     double od2[MAXOWN];
@@ -534,7 +582,9 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
     WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
-    RowScratch<OCC> &R = W.row[row];
+    RowList &R = W.list[row];
+    RowProbe<OCC> &RP = W.probe[row];
+    SharedStage &SH = W.stage;
     const int k = prm.max_nb;
     const int blk = map.blk;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
@@ -542,7 +592,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;      // uniform bases: scalar-base + 32-bit lane offset loads
 
     double acc0 = 0.0, acc1 = 0.0;     // packed-system entries `lane` and `lane + 64`
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds
     unsigned long long tprev = 0;
     if (PROF) tprev = __builtin_readcyclecounter();
 #define CTGN_TICK(slot)                                                  \
@@ -560,8 +610,9 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
     for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
-        // ---------------- phase A: lane (row, sub < rounds) owns keypoint tile*4*rounds + row*rounds + sub
-        const int my_kp = tile * kp_per_wave + row * rounds + sub;
+        // ---------------- phase A: lane (row, sub < rounds) owns keypoint tile*4*rounds + sub*4 + row, i.e. round r
+        // works on four CONSECUTIVE keypoints (sorted by home voxel on upload, so they usually share it)
+        const int my_kp = tile * kp_per_wave + sub * 4 + row;
         const bool own = (sub < rounds) && (my_kp < kp.n);
         {
         Vec3 p{0, 0, 0};
@@ -587,27 +638,127 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
 
         // ---------------- phase B: the row works on the keypoint owned by its lane `r`
         Probe nxt;
-        int nxt_v;
-        {
-            const int src0 = row * 16;
-            const int kx0 = W.kx[src0];
-            nxt = issue_batch<NB>(map, 0, sub, kx0 != INT_MIN, kx0, W.ky[src0], W.kz[src0], W.px[src0], W.py[src0], W.pz[src0], nxt_v);
-        }
+        int nxt_v = 255, nxt_round = -1;            // generic path: probe batch already in flight for round nxt_round
+        int st_kx = INT_MIN, st_ky = 0, st_kz = 0, st_P = 0;   // fast path: home voxel whose neighbourhood is staged, its size
         for (int r = 0; r < rounds; ++r) {
             const int src = row * 16 + r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
             const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
             const bool searching = kx != INT_MIN;
+            const uint32_t lt_mask = (1u << sub) - 1u;
+            int Ln = 0;
+            double kth_d2 = map.r2thr;            // admission bound of the stream: the radius, then the k-th best so far
 
+            // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
+            bool uniform_home = false;
+            if (NB == 1 && blk <= 32) {
+                const int ax = __builtin_amdgcn_readlane(kx, 0), bx_ = __builtin_amdgcn_readlane(kx, 16),
+                          cx_ = __builtin_amdgcn_readlane(kx, 32), dx_ = __builtin_amdgcn_readlane(kx, 48);
+                const int ay = __builtin_amdgcn_readlane(ky, 0), by_ = __builtin_amdgcn_readlane(ky, 16),
+                          cy_ = __builtin_amdgcn_readlane(ky, 32), dy_ = __builtin_amdgcn_readlane(ky, 48);
+                const int az = __builtin_amdgcn_readlane(kz, 0), bz_ = __builtin_amdgcn_readlane(kz, 16),
+                          cz_ = __builtin_amdgcn_readlane(kz, 32), dz_ = __builtin_amdgcn_readlane(kz, 48);
+                uniform_home = ax != INT_MIN && ax == bx_ && ax == cx_ && ax == dx_ && ay == by_ && ay == cy_ && ay == dy_ &&
+                               az == bz_ && az == cz_ && az == dz_;
+            }
+            const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
+            if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
+
+            if (uniform_home) {
+                // ===== fast path: shared, flattened neighbourhood =====
+                occ_tab = SH.occ;
+                if (!(kx == st_kx && ky == st_ky && kz == st_kz)) {
+                    // probe the 27 sweep voxels once for the wave (lane v < 27 takes sweep voxel v)
+                    uint32_t bc = 0;
+                    if (lane < 27) bc = map_lookup(map, kx + lane / 9 - 1, ky + (lane / 3) % 3 - 1, kz + lane % 3 - 1);
+                    const int cnt = (int) (bc & 127u);
+                    const int inc = row_scan_i32(cnt);                       // inclusive prefix within each DPP row
+                    const int tot0 = __builtin_amdgcn_readlane(inc, 15), tot1 = __builtin_amdgcn_readlane(inc, 31);
+                    const int pre = inc - cnt + (row == 1 ? tot0 : 0);       // flat position of this voxel's first point
+                    if (lane < 28) SH.occ[lane] = bc;
+                    int nchunk = 0;
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int left = cnt - 16 * hh;
+                        const bool has = left > 0;
+                        const unsigned long long hb = __ballot(has);
+                        if (!hb) break;
+                        if (has) SH.chunk[nchunk + __popcll(hb & ((1ull << lane) - 1ull))] =
+                                make_uint2((bc >> 7) * stride3 + 128u * hh,
+                                           ((((uint32_t) lane << 6) | (16u * hh)) << 15) | ((uint32_t) (pre + 16 * hh) << 5) | (uint32_t) min(left, 16));
+                        nchunk += __popcll(hb);
+                    }
+                    // flatten: 4 chunks per step, one per row; candidate c of the table = (offset of its x, visit index)
+                    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+                        const int c = c0 + row;
+                        if (c < nchunk) {
+                            const uint2 ch = SH.chunk[c];
+                            const uint32_t n16 = ch.y & 31u, dest = (ch.y >> 5) & 1023u, visb = ch.y >> 15;
+                            if ((uint32_t) sub < n16) {
+                                SH.off[dest + sub] = ch.x + 8u * (uint32_t) sub;
+                                SH.vis[dest + sub] = (uint16_t) (visb + (uint32_t) sub);
+                            }
+                        }
+                    }
+                    st_kx = kx; st_ky = ky; st_kz = kz;
+                    st_P = tot0 + tot1;
+                }
+                CTGN_TICK(1)
+                // two register sets in ping-pong: the loads of the next 16 candidates are in flight while the current 16
+                // are tested (no copies between the sets, so the wait only covers the set being consumed)
+                struct Cand { double x, y, z; uint32_t vis; bool valid; };
+                auto fetch = [&](int c0, Cand &o) {
+                    const int c = c0 + sub;
+                    o.valid = c < st_P;
+                    const int cc = o.valid ? c : 0;
+                    const uint32_t off = SH.off[cc];
+                    o.vis = SH.vis[cc];
+                    o.x = *reinterpret_cast<const double *>(pbase + off);
+                    o.y = *reinterpret_cast<const double *>(pbase_y + off);
+                    o.z = *reinterpret_cast<const double *>(pbase_z + off);
+                };
+                auto test = [&](const Cand &cnd) {
+                    const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
+                    // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
+                    const bool pass = cnd.valid && d2 <= kth_d2;
+                    const uint32_t pm = row_bits(__ballot(pass), row);
+                    if (pass) {
+                        const int pos = Ln + __popc(pm & lt_mask);
+                        R.d2[pos] = d2;
+                        R.vis[pos] = cnd.vis;
+                    }
+                    Ln += __popc(pm);
+                };
+                Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
+                if (st_P > 0) fetch(0, ca);
+                for (int c0 = 0; c0 < st_P; c0 += 32) {
+                    const bool more = c0 + 16 < st_P;
+                    if (more) fetch(c0 + 16, cb);
+                    test(ca);
+                    if (more) {
+                        if (c0 + 32 < st_P) fetch(c0 + 32, ca);
+                        test(cb);
+                    }
+                    if (__any(Ln > LCAP - 32)) {
+                        // list nearly full somewhere in the wave: cut every row back to its k best
+                        CTGN_TICK(2)
+                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
+                        if (Ln >= k) kth_d2 = R.d2[k - 1];
+                        CTGN_TICK(3)
+                    }
+                }
+                CTGN_TICK(2)
+            } else {
+            // ===== generic path: every row probes and streams its own keypoint's neighbourhood =====
+            st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
+            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
-            //   probe 16 voxels (one per lane) -> R.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
+            //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
             //   loads of chunk c+1 in flight while chunk c is tested against the radius / current k-th best and
             //   compacted into the row's LDS candidate list. A candidate's visit index is (sweep index v << 6) | slot:
             //   the reference's x-major sweep + insertion order (map.h:470-480), whatever the probing order.
-            int Ln = 0;
-            double kth_d2 = map.r2thr;            // admission bound of the stream: the radius, then the k-th best so far
-            const uint32_t lt_mask = (1u << sub) - 1u;
 #pragma unroll
             for (int it = 0; it < VIT; ++it) {
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
@@ -620,9 +771,10 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     const int src2 = row * 16 + r + 1;
                     const int kx2 = W.kx[src2];
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v);
+                    nxt_round = r + 1;
                 }
                 const uint32_t bc = probe_resolve(map, cur);
-                if (bc) R.occ[cur_v] = bc;
+                if (bc) RP.occ[cur_v] = bc;
                 const int cnt_mine = (int) (bc & 127u);
                 const uint32_t off_mine = (bc >> 7) * stride3;
                 int nchunk = 0;
@@ -632,58 +784,58 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     const unsigned long long hb = __ballot(has);
                     if (!hb) break;
                     const uint32_t hm = row_bits(hb, row);
-                    if (has) R.chunk[nchunk + __popc(hm & lt_mask)] =
+                    if (has) RP.chunk[nchunk + __popc(hm & lt_mask)] =
                             make_uint2(off_mine + 128u * hh, ((((uint32_t) cur_v << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
                     nchunk += __popc(hm);
                 }
                 CTGN_TICK(1)
-                double nx, ny, nz;
-                uint32_t nvis;
-                bool nvalid;
-                auto fetch = [&](int c) {
-                    nvalid = false;
-                    nx = ny = nz = 0.0;
-                    nvis = 0u;
+                struct Cand { double x, y, z; uint32_t vis; bool valid; };
+                auto fetch = [&](int c, Cand &o) {
+                    o.valid = false;
+                    o.x = o.y = o.z = 0.0;
+                    o.vis = 0u;
                     if (c < nchunk) {
-                        const uint2 ch = R.chunk[c];
-                        nvalid = (uint32_t) sub < (ch.y & 0xffu);
-                        const uint32_t off = ch.x + (nvalid ? (uint32_t) sub * 8u : 0u);      // legal address either way
-                        nx = *reinterpret_cast<const double *>(pbase + off);
-                        ny = *reinterpret_cast<const double *>(pbase_y + off);
-                        nz = *reinterpret_cast<const double *>(pbase_z + off);
-                        nvis = (ch.y >> 8) + (uint32_t) sub;
+                        const uint2 ch = RP.chunk[c];
+                        o.valid = (uint32_t) sub < (ch.y & 0xffu);
+                        const uint32_t off = ch.x + (o.valid ? (uint32_t) sub * 8u : 0u);      // legal address either way
+                        o.x = *reinterpret_cast<const double *>(pbase + off);
+                        o.y = *reinterpret_cast<const double *>(pbase_y + off);
+                        o.z = *reinterpret_cast<const double *>(pbase_z + off);
+                        o.vis = (ch.y >> 8) + (uint32_t) sub;
                     }
                 };
-                fetch(0);
-                for (int c = 0; __any(c < nchunk); ++c) {
-                    const double x = nx, y = ny, z = nz;
-                    const uint32_t vis = nvis;
-                    const bool valid = nvalid;
-                    fetch(c + 1);
-                    const double dx = x - qx, dy = y - qy, dz = z - qz;
+                auto test = [&](const Cand &cnd) {
+                    const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
                     const double d2 = dx * dx + dy * dy + dz * dz;
-                    // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
-                    // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
-                    const bool pass = valid && d2 <= kth_d2;
+                    const bool pass = cnd.valid && d2 <= kth_d2;
                     const uint32_t pm = row_bits(__ballot(pass), row);
                     if (pass) {
                         const int pos = Ln + __popc(pm & lt_mask);
                         R.d2[pos] = d2;
-                        R.vis[pos] = vis;
+                        R.vis[pos] = cnd.vis;
                     }
                     Ln += __popc(pm);
-                    if (__any(Ln > LCAP - 16)) {
+                };
+                Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
+                fetch(0, ca);
+                for (int c = 0; __any(c < nchunk); c += 2) {
+                    fetch(c + 1, cb);
+                    test(ca);
+                    fetch(c + 2, ca);
+                    test(cb);
+                    if (__any(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
-                        Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
+                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
                         if (Ln >= k) kth_d2 = R.d2[k - 1];
                         CTGN_TICK(3)
                     }
                 }
                 CTGN_TICK(2)
             }
+            }
             // B3: final selection -> list sorted ascending, [0..n)
-            Ln = row_select<OCC, HIST>(R, Ln, k, sub, row, kth_d2);
+            Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
             const int n = Ln;
             CTGN_TICK(4)
             // if the list was never cut it is still in visit order: find the farthest by rank sort too
@@ -702,7 +854,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 if (e < n) {
                     const uint32_t vis = R.vis[e];
                     const double d2 = R.d2[e];
-                    const uint32_t bc = R.occ[vis >> 6];
+                    const uint32_t bc = occ_tab[vis >> 6];
                     const uint32_t off = (bc >> 7) * stride3 + (vis & 63u) * 8u;
                     const double x = *reinterpret_cast<const double *>(pbase + off);
                     const double y = *reinterpret_cast<const double *>(pbase_y + off);
@@ -735,7 +887,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // hand the keypoint's (n, sum p, sum p p^T, farthest) over to its owner lane through the per-keypoint
             // scratch record (13 doubles, L2-resident): nothing of it stays in registers across the rounds
             {
-                const int kp_r = tile * kp_per_wave + row * rounds + r;
+                const int kp_r = tile * kp_per_wave + r * 4 + row;
                 if (sub == 0 && kp_r < kp.n) {
                     double *o = kp.res + (size_t) kp_r * 13;
                     o[0] = (double) n;
@@ -788,7 +940,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         CTGN_TICK(7)
     }
     if (PROF && lane == 0) {
-        for (int q = 0; q < 8; ++q) atomicAdd(&prof[q], pc[q]);
+        for (int q = 0; q < 10; ++q) atomicAdd(&prof[q], pc[q]);
     }
 #undef CTGN_TICK
     // ---------------- block combine: fixed order over the waves
