@@ -45,7 +45,7 @@ struct ctgn_context {
     // keypoints: one device allocation of 7 arrays [rx ry rz t wx wy wz] x cap_kp
     int n_kp = 0, cap_kp = 0;
     double *d_kp = nullptr;
-    double *d_res = nullptr;            // [cap_kp][13] row-phase -> lane-phase hand-over records
+    uint32_t *d_res = nullptr;          // [cap_kp][SEL_STRIDE] row-phase -> lane-phase hand-over records
     double *h_kp = nullptr;             // pinned staging, same layout
     double t_min = 0, t_max = 0;
 
@@ -85,6 +85,7 @@ struct ctgn_context {
     double acc_ms = 0.0;
     int acc_launches = 0;
 
+    int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
     std::string last_error;
@@ -234,7 +235,7 @@ KpView kp_view(ctgn_handle h) {
     const size_t c = (size_t) h->cap_kp;
     v.rx = h->d_kp; v.ry = h->d_kp + c; v.rz = h->d_kp + 2 * c; v.t = h->d_kp + 3 * c;
     v.wx = h->d_kp + 4 * c; v.wy = h->d_kp + 5 * c; v.wz = h->d_kp + 6 * c;
-    v.res = h->d_res;
+    v.sel = h->d_res;
     v.n = h->n_kp;
     return v;
 }
@@ -311,7 +312,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
-                               dv, first_iter ? 1 : 0, rounds, prof);
+                               dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
         };
         if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();
@@ -602,7 +603,7 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), cap * 7 * sizeof(double)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), cap * 13 * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), cap * SEL_STRIDE * sizeof(uint32_t)));
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), cap * 7 * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
@@ -872,6 +873,12 @@ ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[10], int32_t reset) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->d_prof, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 10 * sizeof(unsigned long long)));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    h->ablate = mask;
     return CTGN_OK;
 }
 

@@ -34,6 +34,7 @@ constexpr int SYS_N = 96;            // packed system: 78 upper-tri JtJ | 12 Jtr
 constexpr int SYS_USED = 91;
 constexpr int KMAX = 32;             // CTGN_MAX_NEIGHBORS
 constexpr int MAX_PARTIAL_BLOCKS = 2048;
+constexpr int SEL_STRIDE = 36;       // 1 + KMAX, rounded to a 16-byte multiple
 
 struct MapView {
     const Slot *slots;
@@ -48,7 +49,7 @@ struct MapView {
 struct KpView {
     const double *rx, *ry, *rz, *t;
     double *wx, *wy, *wz;
-    double *res;             // [n][13] per-keypoint hand-over between the row phase and the lane phase of k_accumulate_rows
+    uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: count, then the byte offsets of the kept points
     int n;
 };
 
@@ -399,15 +400,15 @@ __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
 // such a voxel can pass map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
 template <int NB>
 __device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
-                                             double qx, double qy, double qz, int &v_out) {
+                                             double qx, double qy, double qz, int &v_out, int ablate = 0) {
     constexpr int S = 2 * NB + 1;
     const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
     v_out = v;
     const int vv = (v == 255) ? 0 : v;
     const int vx = kx + vv / (S * S) - NB, vy = ky + (vv / S) % S - NB, vz = kz + vv % S - NB;
     const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
-    const bool reachable = gx * gx + gy * gy + gz * gz <= m.r2thr * (1.0 + 1e-8);
-    return probe_issue(m, searching && v != 255 && reachable, vx, vy, vz);
+    const bool reachable = (ablate & 64) || gx * gx + gy * gy + gz * gz <= m.r2thr * (1.0 + 1e-8);
+    return probe_issue(m, searching && v != 255 && reachable && !(ablate & 16), vx, vy, vz);
 }
 
 // the 16 ballot bits of DPP row `row`
@@ -470,10 +471,10 @@ struct WaveScratch {
 template <bool HIST>
 __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, int row, double hi) {
     int maxLn = max_over_rows(Ln);
-    if (maxLn <= k) return Ln;
+    if (maxLn == 0) return 0;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const uint32_t lt_mask = (1u << sub) - 1u;
-    if (HIST) {
+    if (HIST && maxLn > k) {
         R.hist[sub] = 0;
         const double scale = hi > 0.0 ? 16.0 / hi : 0.0;
         const int nown = (maxLn + 15) >> 4;
@@ -569,6 +570,17 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
     return Ln < k ? Ln : k;
 }
 
+// true iff the four rows of the wave hold the same, valid voxel (kx, ky, kz are row-uniform values)
+__device__ __forceinline__ bool rows_share_home(int kx, int ky, int kz) {
+    const int ax = __builtin_amdgcn_readlane(kx, 0), ay = __builtin_amdgcn_readlane(ky, 0), az = __builtin_amdgcn_readlane(kz, 0);
+    bool same = ax != INT_MIN;
+#pragma unroll
+    for (int l = 16; l < 64; l += 16)
+        same = same && __builtin_amdgcn_readlane(kx, l) == ax && __builtin_amdgcn_readlane(ky, l) == ay &&
+               __builtin_amdgcn_readlane(kz, l) == az;
+    return same;
+}
+
 // NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection.
 // PROF: per-phase shader-clock accounting (s_memtime) summed over waves into prof[0..7]:
 //   0 phase A (transform, voxel) | 1 hash probes + chunk lists | 2 candidate streaming | 3 in-stream prunes |
@@ -576,7 +588,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
 template <int NB, bool HIST, bool PROF = false, int WPS = 4>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
-                                                               unsigned long long *prof = nullptr) {
+                                                               unsigned long long *prof = nullptr, int ablate = 0) {
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (st->done) return;
@@ -640,6 +652,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         Probe nxt;
         int nxt_v = 255, nxt_round = -1;            // generic path: probe batch already in flight for round nxt_round
         int st_kx = INT_MIN, st_ky = 0, st_kz = 0, st_P = 0;   // fast path: home voxel whose neighbourhood is staged, its size
+        Probe snxt;                                 // fast path: the wave's 27 probes for round snxt_round, already in flight
+        int snxt_round = -1;
         for (int r = 0; r < rounds; ++r) {
             const int src = row * 16 + r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
@@ -650,17 +664,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             double kth_d2 = map.r2thr;            // admission bound of the stream: the radius, then the k-th best so far
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
-            bool uniform_home = false;
-            if (NB == 1 && blk <= 32) {
-                const int ax = __builtin_amdgcn_readlane(kx, 0), bx_ = __builtin_amdgcn_readlane(kx, 16),
-                          cx_ = __builtin_amdgcn_readlane(kx, 32), dx_ = __builtin_amdgcn_readlane(kx, 48);
-                const int ay = __builtin_amdgcn_readlane(ky, 0), by_ = __builtin_amdgcn_readlane(ky, 16),
-                          cy_ = __builtin_amdgcn_readlane(ky, 32), dy_ = __builtin_amdgcn_readlane(ky, 48);
-                const int az = __builtin_amdgcn_readlane(kz, 0), bz_ = __builtin_amdgcn_readlane(kz, 16),
-                          cz_ = __builtin_amdgcn_readlane(kz, 32), dz_ = __builtin_amdgcn_readlane(kz, 48);
-                uniform_home = ax != INT_MIN && ax == bx_ && ax == cx_ && ax == dx_ && ay == by_ && ay == cy_ && ay == dy_ &&
-                               az == bz_ && az == cz_ && az == dz_;
-            }
+            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
@@ -669,8 +673,9 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 occ_tab = SH.occ;
                 if (!(kx == st_kx && ky == st_ky && kz == st_kz)) {
                     // probe the 27 sweep voxels once for the wave (lane v < 27 takes sweep voxel v)
-                    uint32_t bc = 0;
-                    if (lane < 27) bc = map_lookup(map, kx + lane / 9 - 1, ky + (lane / 3) % 3 - 1, kz + lane % 3 - 1);
+                    if (snxt_round != r)
+                        snxt = probe_issue(map, lane < 27 && !(ablate & 16), kx + lane / 9 - 1, ky + (lane / 3) % 3 - 1, kz + lane % 3 - 1);
+                    const uint32_t bc = probe_resolve(map, snxt);
                     const int cnt = (int) (bc & 127u);
                     const int inc = row_scan_i32(cnt);                       // inclusive prefix within each DPP row
                     const int tot0 = __builtin_amdgcn_readlane(inc, 15), tot1 = __builtin_amdgcn_readlane(inc, 31);
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 };
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
                 if (st_P > 0) fetch(0, ca);
-                for (int c0 = 0; c0 < st_P; c0 += 32) {
+                for (int c0 = 0; c0 < ((ablate & 1) ? 0 : st_P); c0 += 32) {
                     const bool more = c0 + 16 < st_P;
                     if (more) fetch(c0 + 16, cb);
                     test(ca);
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             } else {
             // ===== generic path: every row probes and streams its own keypoint's neighbourhood =====
             st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
-            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v);
+            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
@@ -766,11 +771,11 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 Probe cur = nxt;
                 const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
-                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v);
+                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate);
                 } else if (r + 1 < rounds) {
                     const int src2 = row * 16 + r + 1;
                     const int kx2 = W.kx[src2];
-                    nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v);
+                    nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate);
                     nxt_round = r + 1;
                 }
                 const uint32_t bc = probe_resolve(map, cur);
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 };
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
                 fetch(0, ca);
-                for (int c = 0; __any(c < nchunk); c += 2) {
+                for (int c = 0; !(ablate & 1) && __any(c < nchunk); c += 2) {
                     fetch(c + 1, cb);
                     test(ca);
                     fetch(c + 2, ca);
@@ -834,66 +839,36 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 CTGN_TICK(2)
             }
             }
-            // B3: final selection -> list sorted ascending, [0..n)
-            Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
-            const int n = Ln;
-            CTGN_TICK(4)
-            // if the list was never cut it is still in visit order: find the farthest by rank sort too
-            // (row_select returns early when every row has <= k entries) -> sort those rows here.
-            // A list of <= k entries in arbitrary order: the farthest is the max under the total order.
-            // B4: covariance sums + farthest point, reduced over the row with DPP butterflies
-            double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-            // farthest: argmax of (d2, vis) over the kept entries
-            double fd2 = -1.0;
-            uint32_t fvis = 0;
-            double cx[2], cy[2], cz[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int e = sub + 16 * m;
-                cx[m] = cy[m] = cz[m] = 0.0;
-                if (e < n) {
-                    const uint32_t vis = R.vis[e];
-                    const double d2 = R.d2[e];
-                    const uint32_t bc = occ_tab[vis >> 6];
-                    const uint32_t off = (bc >> 7) * stride3 + (vis & 63u) * 8u;
-                    const double x = *reinterpret_cast<const double *>(pbase + off);
-                    const double y = *reinterpret_cast<const double *>(pbase_y + off);
-                    const double z = *reinterpret_cast<const double *>(pbase_z + off);
-                    cx[m] = x; cy[m] = y; cz[m] = z;
-                    sx += x; sy += y; sz += z;
-                    sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
-                    if (d2 > fd2 || (d2 == fd2 && vis > fvis)) { fd2 = d2; fvis = vis; }
+            // the next round's shared probes go out now, so their latency hides behind this round's selection and sums
+            if (NB == 1 && blk <= 32 && r + 1 < rounds) {
+                const int src2 = row * 16 + r + 1;
+                const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
+                if (rows_share_home(kx2, ky2, kz2) && !(uniform_home && kx2 == kx && ky2 == ky && kz2 == kz)) {
+                    snxt = probe_issue(map, lane < 27 && !(ablate & 16), kx2 + lane / 9 - 1, ky2 + (lane / 3) % 3 - 1, kz2 + lane % 3 - 1);
+                    snxt_round = r + 1;
                 }
             }
-            // row argmax of (fd2, fvis): compare-exchange butterflies on the pair
-#define CTGN_ARGMAX_STEP(CTRL)                                                                      \
-            {                                                                                        \
-                double od = dpp_f64<CTRL>(fd2);                                                      \
-                uint32_t ov = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) fvis, CTRL, 0xf, 0xf, false); \
-                if (od > fd2 || (od == fd2 && ov > fvis)) { fd2 = od; fvis = ov; }                   \
-            }
-            CTGN_ARGMAX_STEP(0xB1) CTGN_ARGMAX_STEP(0x4E) CTGN_ARGMAX_STEP(0x141) CTGN_ARGMAX_STEP(0x140)
-#undef CTGN_ARGMAX_STEP
-            double fqx = 0, fqy = 0, fqz = 0;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int e = sub + 16 * m;
-                if (e < n && R.vis[e] == fvis) { fqx = cx[m]; fqy = cy[m]; fqz = cz[m]; }
-            }
-            sx = row_sum(sx); sy = row_sum(sy); sz = row_sum(sz);
-            sxx = row_sum(sxx); sxy = row_sum(sxy); sxz = row_sum(sxz);
-            syy = row_sum(syy); syz = row_sum(syz); szz = row_sum(szz);
-            fqx = row_sum(fqx); fqy = row_sum(fqy); fqz = row_sum(fqz);       // exactly one lane is non-zero
-            // hand the keypoint's (n, sum p, sum p p^T, farthest) over to its owner lane through the per-keypoint
-            // scratch record (13 doubles, L2-resident): nothing of it stays in registers across the rounds
+            // B3: final selection -> list sorted ascending, [0..n)
+            if (!(ablate & 2)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
+            const int n = (ablate & 2) ? min(Ln, k) : Ln;
+            CTGN_TICK(4)
+            // B4: hand the keypoint's neighbour set over to its owner lane: the block-storage byte offsets of the n kept
+            // points, nearest first (the list is sorted), in a per-keypoint record (L2-resident). The covariance sums
+            // are then taken by the owner lane in phase C — no cross-lane reductions and no point loads here.
             {
                 const int kp_r = tile * kp_per_wave + r * 4 + row;
-                if (sub == 0 && kp_r < kp.n) {
-                    double *o = kp.res + (size_t) kp_r * 13;
-                    o[0] = (double) n;
-                    o[1] = sx; o[2] = sy; o[3] = sz;
-                    o[4] = sxx; o[5] = sxy; o[6] = sxz; o[7] = syy; o[8] = syz; o[9] = szz;
-                    o[10] = fqx; o[11] = fqy; o[12] = fqz;
+                if (kp_r < kp.n && !(ablate & 4)) {
+                    uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
+                    if (sub == 0) o[0] = (uint32_t) n;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int e = sub + 16 * m;
+                        if (e < n) {
+                            const uint32_t vis = R.vis[e];
+                            const uint32_t bc = occ_tab[vis >> 6];
+                            o[1 + e] = (bc >> 7) * stride3 + (vis & 63u) * 8u;
+                        }
+                    }
                 }
             }
             CTGN_TICK(5)
@@ -906,14 +881,26 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         double a2d = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // the records were written by other lanes of this wave
         if (own) {
-            const double *in = kp.res + (size_t) my_kp * 13;
-            const int res_n = (int) in[0];
-            const Vec3 res_S{in[1], in[2], in[3]}, res_q{in[10], in[11], in[12]};
-            const Sym3 res_SS{in[4], in[5], in[6], in[7], in[8], in[9]};
+            const uint32_t *in = kp.sel + (size_t) my_kp * SEL_STRIDE;
+            const int res_n = (ablate & 4) ? 0 : (int) in[0];
+            // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
+            // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240)
+            Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
+            Sym3 res_SS{0, 0, 0, 0, 0, 0};
+            for (int j = res_n - 1; j >= 0; --j) {
+                const uint32_t off = in[1 + j];
+                const double x = *reinterpret_cast<const double *>(pbase + off);
+                const double y = *reinterpret_cast<const double *>(pbase_y + off);
+                const double z = *reinterpret_cast<const double *>(pbase_z + off);
+                if (j == res_n - 1) res_q = Vec3{x, y, z};             // points[0]: the farthest kept (ct_icp.cpp:791)
+                res_S.x += x; res_S.y += y; res_S.z += z;
+                res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
+                res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+            }
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
             const Vec3 p{W.px[lane], W.py[lane], W.pz[lane]};
             const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
-            used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
+            if (!(ablate & 8)) used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;
                 dbg.normal[3 * my_kp] = nrm.x; dbg.normal[3 * my_kp + 1] = nrm.y; dbg.normal[3 * my_kp + 2] = nrm.z;
@@ -930,7 +917,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
             my[12] = used ? rr : 0.0;
             const unsigned long long ub = __ballot(used);
-            for (int j = 0; j < 64; ++j) {
+            for (int j = 0; j < ((ablate & 128) ? 0 : 64); ++j) {
                 const double *rj = W.rec + j * 13;
                 acc0 += rj[e0i] * rj[e0j];
                 if (e1kind != 2) acc1 += e1sign * rj[e1i] * rj[e1j];

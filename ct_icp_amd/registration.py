@@ -189,6 +189,9 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_phase_cycles(self._h, out, int(reset)))
         return [int(x) for x in out]
 
+    def set_ablation(self, mask: int):
+        L.check(self._h, L.lib().ctgn_set_ablation(self._h, mask))
+
     def set_variant(self, v: int):
         L.check(self._h, L.lib().ctgn_set_variant(self._h, v))
 

@@ -232,6 +232,10 @@ ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t
  * 3 = variant 0 instrumented with per-phase shader clocks (see ctgn_phase_cycles), 4 = variant 0 compiled for
  * 4 waves per SIMD instead of 3 (A/B hook). Test / measurement hook. */
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
+/* Measurement hook: skip phases of the row kernel (bit 0 candidate streaming, 1 selection, 2 covariance sums,
+ * 3 normal/residual/Jacobian, 5 shared-home-voxel fast path). Results are INVALID while a mask is set; only timings
+ * are meaningful (ablation profiling). */
+ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel
