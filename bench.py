@@ -80,6 +80,34 @@ def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, 
     return out
 
 
+def make_inputs_dense(rank: int, length: float = 2400.0, seed: int = 3):
+    """Config-D-like dense workload built analytically (no ray casting): a 2.4 km street whose ground and two facades are
+    sampled densely enough to fill the 0.5 m x 40-point voxels, so the device map is ~0.5 GB (>> 256 MB Infinity Cache), and
+    ~1 M keypoints spread over the WHOLE map, so one accumulate launch touches the whole working set."""
+    rng = np.random.default_rng(seed)
+    def plane(n, fixed_axis, fixed_val, r0, r1):
+        p = np.empty((n, 3))
+        free = [a for a in range(3) if a != fixed_axis]
+        p[:, free[0]] = rng.uniform(r0[0], r0[1], n)
+        p[:, free[1]] = rng.uniform(r1[0], r1[1], n)
+        p[:, fixed_axis] = fixed_val + rng.normal(0, 0.01, n)
+        return p
+    dens = 260                                                  # points / m^2: ~65 per 0.5 m voxel face before the min-distance rule
+    ground = plane(int(length * 24 * dens), 2, 0.0, (0, length), (-12, 12))
+    wall_l = plane(int(length * 8 * dens), 1, 12.0, (0, length), (0, 8))
+    wall_r = plane(int(length * 8 * dens), 1, -12.0, (0, length), (0, 8))
+    map_points = np.concatenate([ground, wall_l, wall_r])
+    n_kp = 1_000_000
+    kp = np.concatenate([plane(n_kp // 2, 2, 0.0, (5, length - 5), (-11.5, 11.5)),
+                         plane(n_kp // 4, 1, 12.0, (5, length - 5), (0.3, 7.7)),
+                         plane(n_kp // 4, 1, -12.0, (5, length - 5), (0.3, 7.7))])
+    kp = kp[np.random.default_rng(seed + 17 * rank + 1).permutation(len(kp))]
+    # identity begin/end pose at the origin: raw == world, the solver then estimates a small correction
+    pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], float)
+    t = np.linspace(0.0, 1.0, len(kp))
+    return dict(map_points=map_points, raw=kp, t=t, pose_gt=pose, tbe=np.array([0.0, 1.0]), prev_b=np.zeros(3), prev_e=np.zeros(3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +116,10 @@ def main():
     ap.add_argument("--map-frames", type=int, default=20)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="B2", choices=["B2", "B1", "D"],
+                    help="B2: all returns of the HDL-64E sweep as keypoints (default, throughput regime); B1: the reference's "
+                         "keypoint count (1.5 m grid of the 0.5 m-subsampled frame, latency regime); D: dense synthetic workload "
+                         "whose map working set exceeds the 256 MB Infinity Cache (HBM-bound evidence)")
     ap.add_argument("--ablate", type=int, default=0, help="measurement hook: skip kernel phases (invalid results)")
     ap.add_argument("--presort", action="store_true", help="experiment: sort the keypoints by home voxel on the host")
     ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
@@ -108,12 +140,21 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    inp = make_inputs(rank, args.map_frames)
-    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75,
-                                                device=local_rank))
-    gm.InsertPointCloud(inp["map_points"])
+    if args.workload == "D":
+        inp = make_inputs_dense(rank)
+        res_param, radius = cia.ResolutionParam(0.5, 0.03, 40), 0.8          # config D map: {0.5 m, 40 pts, 0.03 m}
+    else:
+        inp = make_inputs(rank, args.map_frames)
+        res_param, radius = cia.ResolutionParam(0.8, 0.1, 30), 0.75         # driving profile
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[res_param], default_radius=radius, device=local_rank))
+    for s0 in range(0, len(inp["map_points"]), 2_000_000):
+        gm.InsertPointCloud(inp["map_points"][s0:s0 + 2_000_000])
     gm.Sync()
     raw, t = inp["raw"], inp["t"]
+    if args.workload == "B1":                                  # the reference's two-stage grid sampling (odometry.cpp:349,538)
+        sel = syn.grid_sample_indices(raw, 0.5)
+        sel = sel[syn.grid_sample_indices(raw[sel], 1.5)]
+        raw, t = raw[sel], t[sel]
     n_kp = len(t)
     pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
     world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
@@ -206,7 +247,13 @@ def main():
                          "voxels_probed_per_keypoint": probed / n_kp, "voxels_hit_per_keypoint": hit / n_kp,
                          "points_scanned_per_keypoint": points / n_kp},
         }
-        if not args.no_cpu_baseline:
+        result["config"]["workload_id"] = args.workload
+        if args.workload != "B2":
+            result["config"]["workload"] = {"B1": "config B1: same sweep and map, keypoints = 1.5 m grid of the 0.5 m-subsampled frame "
+                                                  "(the reference's keypoint count; latency regime)",
+                                            "D": "config D-like: dense analytic street, map {0.5 m, 40 pts} ~0.5 GB (> Infinity Cache), "
+                                                 "1 M keypoints spread over the whole map, radius 0.8 (125 voxels), k=20"}[args.workload]
+        if not args.no_cpu_baseline and args.workload == "B2":
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
