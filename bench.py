@@ -121,6 +121,7 @@ def main():
                          "keypoint count (1.5 m grid of the 0.5 m-subsampled frame, latency regime); D: dense synthetic workload "
                          "whose map working set exceeds the 256 MB Infinity Cache (HBM-bound evidence)")
     ap.add_argument("--ablate", type=int, default=0, help="measurement hook: skip kernel phases (invalid results)")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded (all-reduce) loop even with one rank")
     ap.add_argument("--presort", action="store_true", help="experiment: sort the keypoints by home voxel on the host")
     ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
     args = ap.parse_args()
@@ -136,8 +137,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "D":
@@ -164,7 +167,7 @@ def main():
     def options(iters):   # threshold 0: no early stop, exactly `iters` GN iterations
         return cia.CTICPOptions(solver=cia.GN, num_iters_icp=iters, threshold_orientation_norm=0.0, debug_print=False)
 
-    if world > 1:
+    if dist is not None:
         from ct_icp_amd.distributed import ShardedGnSolver
         sh = ShardedGnSolver(gm)
         solver = sh.solver

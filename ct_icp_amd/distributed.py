@@ -58,6 +58,18 @@ class ShardedGnSolver:
         self.solver.set_stream(torch.cuda.current_stream().cuda_stream)
         self.solver.gn_set_system_buffer(self.system.data_ptr())
 
+    def close(self):
+        """Give the library its own packed-system buffer back (the tensor may be freed afterwards)."""
+        if self.solver is not None:
+            self.solver.gn_set_system_buffer(None)
+            self.solver = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def set_keypoints(self, raw, world, t):
         self.solver.set_keypoints(raw, world, t)
 

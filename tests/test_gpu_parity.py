@@ -338,3 +338,37 @@ def test_cpp_adapter_program():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("adapter ok"), out.stdout + out.stderr
+
+
+def test_sharded_loop_single_rank_equals_fused(box_case):
+    """The multi-GPU loop (accumulate -> all-reduce of the 96-double system over RCCL -> solve, ct_icp_amd/distributed.py)
+    on one rank gives bit-identical results to the fused loop: exercises the external stream / external system buffer."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from ct_icp_amd.distributed import ShardedGnSolver
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.5)
+    o = _opts(num_iters_icp=4, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    pose_f, summ_f, _ = s.solve(pose0, sc.t_begin_end, o)
+    w_f = s.world_points()
+    created = False
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        sh = ShardedGnSolver(gm)
+        sh.set_keypoints(raw, world0, t)
+        pose_s, summ_s, _ = sh.solve(pose0, sc.t_begin_end, o)
+        torch.cuda.synchronize()
+        assert np.array_equal(pose_f, pose_s) and summ_s.num_iters == 4
+        assert np.array_equal(w_f, sh.solver.world_points())
+        A, b, n = sh.solver.get_system()
+        assert n == summ_s.num_residuals_used
+        sh.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
