@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctgn.so")
+LIB_PATH = os.environ.get("CTGN_LIB_PATH") or os.path.join(_HERE, "libctgn.so")   # override: A/B timing of two builds
 
 CTGN_MAX_RESOLUTIONS = 8
 CTGN_SYSTEM_DOUBLES = 96
