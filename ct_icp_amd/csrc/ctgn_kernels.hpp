@@ -715,7 +715,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     const int c = c0 + sub;
                     o.valid = c < st_P;
                     const int cc = o.valid ? c : 0;
-                    const uint32_t off = SH.off[cc];
+                    const uint32_t off = o.valid ? SH.off[cc] : 0u;       // masked lanes read the start of the block storage
                     o.vis = SH.vis[cc];
                     o.x = *reinterpret_cast<const double *>(pbase + off);
                     o.y = *reinterpret_cast<const double *>(pbase_y + off);
@@ -735,16 +735,15 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     }
                     Ln += __popc(pm);
                 };
+                // straight-line loop body: the fetches are unconditional (out-of-range lanes re-read candidate 0 and are
+                // masked), so the compiler's s_waitcnt covers exactly the set being consumed, not the one in flight
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
-                if (st_P > 0) fetch(0, ca);
+                fetch(0, ca);
                 for (int c0 = 0; c0 < ((ablate & 1) ? 0 : st_P); c0 += 32) {
-                    const bool more = c0 + 16 < st_P;
-                    if (more) fetch(c0 + 16, cb);
+                    fetch(c0 + 16, cb);
                     test(ca);
-                    if (more) {
-                        if (c0 + 32 < st_P) fetch(c0 + 32, ca);
-                        test(cb);
-                    }
+                    fetch(c0 + 32, ca);
+                    test(cb);
                     if (__any(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
@@ -796,18 +795,16 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 CTGN_TICK(1)
                 struct Cand { double x, y, z; uint32_t vis; bool valid; };
                 auto fetch = [&](int c, Cand &o) {
-                    o.valid = false;
-                    o.x = o.y = o.z = 0.0;
-                    o.vis = 0u;
-                    if (c < nchunk) {
-                        const uint2 ch = RP.chunk[c];
-                        o.valid = (uint32_t) sub < (ch.y & 0xffu);
-                        const uint32_t off = ch.x + (o.valid ? (uint32_t) sub * 8u : 0u);      // legal address either way
-                        o.x = *reinterpret_cast<const double *>(pbase + off);
-                        o.y = *reinterpret_cast<const double *>(pbase_y + off);
-                        o.z = *reinterpret_cast<const double *>(pbase_z + off);
-                        o.vis = (ch.y >> 8) + (uint32_t) sub;
-                    }
+                    // unconditional (straight-line) fetch: past the end of the row's chunk list it reads offset 0 with
+                    // zero valid points, so no control flow sits between the loads and the waits that cover them
+                    uint2 ch = RP.chunk[c & 63];
+                    if (c >= nchunk) ch = make_uint2(0u, 0u);
+                    o.valid = (uint32_t) sub < (ch.y & 0xffu);
+                    const uint32_t off = ch.x + (o.valid ? (uint32_t) sub * 8u : 0u);          // legal address either way
+                    o.x = *reinterpret_cast<const double *>(pbase + off);
+                    o.y = *reinterpret_cast<const double *>(pbase_y + off);
+                    o.z = *reinterpret_cast<const double *>(pbase_z + off);
+                    o.vis = (ch.y >> 8) + (uint32_t) sub;
                 };
                 auto test = [&](const Cand &cnd) {
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
