@@ -206,7 +206,8 @@ def main():
     if args.variant == 3 and rank == 0:
         pcs_all = solver.phase_cycles(reset=True)
         pcs, fast_rounds, all_rounds = pcs_all[:8], pcs_all[8], pcs_all[9]
-        print(f"fast-path rounds: {fast_rounds} of {all_rounds}", file=sys.stderr)
+        print(f"fast-path rounds: {fast_rounds} of {all_rounds}; slowest wave {pcs_all[10] / 1e3:.0f} kclk vs mean "
+              f"{sum(pcs) / max(pcs_all[11], 1) / 1e3:.0f} kclk over {pcs_all[11]} wave-launches", file=sys.stderr)
         tot = float(sum(pcs)) or 1.0
         names = ["A transform", "B1 probes", "B2 stream", "B2 prunes", "B3 select", "B4 sums", "C normal/jac", "D accumulate"]
         print("phase cycles: " + ", ".join(f"{n}={100 * c / tot:.1f}%" for n, c in zip(names, pcs)) +

@@ -442,8 +442,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
-             hipMalloc(reinterpret_cast<void **>(&h->d_prof), 10 * sizeof(unsigned long long)) == hipSuccess &&
-             hipMemsetAsync(h->d_prof, 0, 10 * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_prof), 12 * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemsetAsync(h->d_prof, 0, 12 * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
              hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_sys_own, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
@@ -867,12 +867,12 @@ ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_ms, int32_t *launches,
     return CTGN_OK;
 }
 
-ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[10], int32_t reset) {
+ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset) {
     NEED_DEVICE(h);
     if (!out) return CTGN_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->d_prof, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 10 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemcpy(out, h->d_prof, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 12 * sizeof(unsigned long long)));
     return CTGN_OK;
 }
 

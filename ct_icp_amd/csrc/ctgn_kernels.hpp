@@ -622,9 +622,12 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
     for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
-        // ---------------- phase A: lane (row, sub < rounds) owns keypoint tile*4*rounds + sub*4 + row, i.e. round r
-        // works on four CONSECUTIVE keypoints (sorted by home voxel on upload, so they usually share it)
-        const int my_kp = tile * kp_per_wave + sub * 4 + row;
+        // ---------------- phase A: lane (row, sub < rounds) owns keypoint (sub * ntiles + tile) * 4 + row: round r of a
+        // tile works on four CONSECUTIVE keypoints (neighbours in the scan usually share their home voxel), while the
+        // rounds of one tile are spread over the whole scan with stride 4 * ntiles. Every tile is thereby a uniform
+        // sample of the scan, which levels the per-wave work (dense and sparse regions differ ~4x in candidates per
+        // keypoint; with contiguous tiles the slowest wave ran 1.8x the mean).
+        const int my_kp = (sub * ntiles + tile) * 4 + row;
         const bool own = (sub < rounds) && (my_kp < kp.n);
         {
         Vec3 p{0, 0, 0};
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // points, nearest first (the list is sorted), in a per-keypoint record (L2-resident). The covariance sums
             // are then taken by the owner lane in phase C — no cross-lane reductions and no point loads here.
             {
-                const int kp_r = tile * kp_per_wave + r * 4 + row;
+                const int kp_r = (r * ntiles + tile) * 4 + row;
                 if (kp_r < kp.n && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
                     if (sub == 0) o[0] = (uint32_t) n;
@@ -884,15 +887,28 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240)
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
-            for (int j = res_n - 1; j >= 0; --j) {
-                const uint32_t off = in[1 + j];
-                const double x = *reinterpret_cast<const double *>(pbase + off);
-                const double y = *reinterpret_cast<const double *>(pbase_y + off);
-                const double z = *reinterpret_cast<const double *>(pbase_z + off);
-                if (j == res_n - 1) res_q = Vec3{x, y, z};             // points[0]: the farthest kept (ct_icp.cpp:791)
-                res_S.x += x; res_S.y += y; res_S.z += z;
-                res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
-                res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+            // gathers in groups of four (12 independent loads in flight), sums strictly in order
+            for (int j0 = res_n - 1; j0 >= 0; j0 -= 4) {
+                uint32_t off[4];
+                double gx[4], gy[4], gz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) off[q] = (j0 - q >= 0) ? in[1 + j0 - q] : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gx[q] = *reinterpret_cast<const double *>(pbase + off[q]);
+                    gy[q] = *reinterpret_cast<const double *>(pbase_y + off[q]);
+                    gz[q] = *reinterpret_cast<const double *>(pbase_z + off[q]);
+                }
+                if (j0 == res_n - 1) res_q = Vec3{gx[0], gy[0], gz[0]};    // points[0]: the farthest kept (ct_icp.cpp:791)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (j0 - q >= 0) {
+                        const double x = gx[q], y = gy[q], z = gz[q];
+                        res_S.x += x; res_S.y += y; res_S.z += z;
+                        res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
+                        res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+                    }
+                }
             }
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
             const Vec3 p{W.px[lane], W.py[lane], W.pz[lane]};
@@ -924,7 +940,10 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         CTGN_TICK(7)
     }
     if (PROF && lane == 0) {
-        for (int q = 0; q < 10; ++q) atomicAdd(&prof[q], pc[q]);
+        unsigned long long tot_ = 0;
+        for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
+        atomicMax(&prof[10], tot_);            // slowest wave
+        atomicAdd(&prof[11], 1ull);            // waves
     }
 #undef CTGN_TICK
     // ---------------- block combine: fixed order over the waves

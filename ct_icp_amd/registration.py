@@ -185,7 +185,7 @@ class GnSolver:
         return ms.value, n.value
 
     def phase_cycles(self, reset=False):
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 12)()
         L.check(self._h, L.lib().ctgn_phase_cycles(self._h, out, int(reset)))
         return [int(x) for x in out]
 

@@ -239,8 +239,8 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel
- * fast path, 9 = rounds (counts, per wave). */
-ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[10], int32_t reset);
+ * fast path, 9 = rounds (counts, per wave), 10 = clocks of the slowest wave (max), 11 = waves. */
+ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset);
 
 #ifdef __cplusplus
 }
