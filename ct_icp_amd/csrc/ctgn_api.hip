@@ -310,9 +310,15 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
             const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
-            grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
+            const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
+            hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
+            if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
+            ev = nullptr;
+            // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
+            grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, MAX_PARTIAL_BLOCKS));
+            hipLaunchKernelGGL(k_residual_reduce, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm,
+                               h->d_partials, dv, h->ablate);
         };
         if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();

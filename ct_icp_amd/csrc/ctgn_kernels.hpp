@@ -603,7 +603,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     const uint32_t blk8 = (uint32_t) blk * 8u, stride3 = 3u * blk8;
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;      // uniform bases: scalar-base + 32-bit lane offset loads
 
-    double acc0 = 0.0, acc1 = 0.0;     // packed-system entries `lane` and `lane + 64`
     unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds
     unsigned long long tprev = 0;
     if (PROF) tprev = __builtin_readcyclecounter();
@@ -613,12 +612,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         pc[slot] += now_ - tprev;                                        \
         tprev = now_;                                                    \
     }
-    // entry descriptors: e0 = lane (< 78: upper-tri product), e1 = lane + 64 (product | -u_i * r | count | none)
-    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
-    int e1i = 0, e1j = 0, e1kind = 2;          // kind 0: product, 1: -u*r, 2: count / none
-    double e1sign = 1.0;
-    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
-    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; e1sign = -1.0; }
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
     for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
@@ -852,8 +845,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (!(ablate & 2)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
             const int n = (ablate & 2) ? min(Ln, k) : Ln;
             CTGN_TICK(4)
-            // B4: hand the keypoint's neighbour set over to its owner lane: the block-storage byte offsets of the n kept
-            // points, nearest first (the list is sorted), in a per-keypoint record (L2-resident). The covariance sums
+            // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST
+            // first (the reference's neighbour order; the list is sorted nearest first), in a per-keypoint record. The covariance sums
             // are then taken by the owner lane in phase C — no cross-lane reductions and no point loads here.
             {
                 const int kp_r = (r * ntiles + tile) * 4 + row;
@@ -866,7 +859,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                         if (e < n) {
                             const uint32_t vis = R.vis[e];
                             const uint32_t bc = occ_tab[vis >> 6];
-                            o[1 + e] = (bc >> 7) * stride3 + (vis & 63u) * 8u;
+                            o[n - e] = (bc >> 7) * stride3 + (vis & 63u) * 8u;      // slot 1 = farthest kept ... slot n = nearest
                         }
                     }
                 }
@@ -874,45 +867,96 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             CTGN_TICK(5)
         }
 
-        // ---------------- phase C: lane per keypoint — normal, gates, residual, u
+    }
+    if (PROF && lane == 0) {
+        unsigned long long tot_ = 0;
+        for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
+        atomicMax(&prof[10], tot_);            // slowest wave
+        atomicAdd(&prof[11], 1ull);            // waves
+    }
+#undef CTGN_TICK
+}
+
+template <int NB>
+inline size_t rows_kernel_smem() {
+    constexpr int S = 2 * NB + 1, V = S * S * S, OCC = (V + 3) & ~3;
+    return sizeof(WaveScratch<OCC>) * ROW_WAVES;
+}
+
+// ================================================================================================
+// k_residual_reduce — second half of the accumulate step for the row kernel: one lane per keypoint.
+//   reads the keypoint's neighbour set (count + block-storage offsets, nearest first) left by k_accumulate_rows,
+//   gathers the points, sums mean / covariance in the reference's order, 3x3 eigen-solve -> normal + a2D, gates,
+//   residual, 12-vector u (ct_icp.cpp:769-841), then the packed u u^T | -u r | count per block (:843-850).
+// Splitting it off keeps the neighbour-search kernel free of the eigen-solver's registers and runs this part with
+// all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
+// ================================================================================================
+constexpr int RES_BLOCK = 256;
+
+__global__ __launch_bounds__(RES_BLOCK) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                                 double *partials, DebugView dbg, int ablate) {
+    __shared__ double s_rec[RES_BLOCK / 64][64 * 13];
+    __shared__ double s_comb[RES_BLOCK / 64][SYS_N];
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char *pbase = reinterpret_cast<const char *>(map.blocks);
+    const uint32_t blk8 = (uint32_t) map.blk * 8u;
+    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
+    // entry descriptors: e0 = lane (< 78: upper-tri product), e1 = lane + 64 (product | -u_i * r | count | none)
+    double acc0 = 0.0, acc1 = 0.0;
+    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
+    int e1i = 0, e1j = 0, e1kind = 2;          // kind 0: product, 1: -u*r, 2: count / none
+    double e1sign = 1.0;
+    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
+    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; e1sign = -1.0; }
+    const int ntiles = (kp.n + RES_BLOCK - 1) / RES_BLOCK;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int my_kp = tile * RES_BLOCK + tid;
         double u[12], rr = 0.0;
         bool used = false;
-        Vec3 nrm{0, 0, 0};
-        double a2d = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // the records were written by other lanes of this wave
-        if (own) {
-            const uint32_t *in = kp.sel + (size_t) my_kp * SEL_STRIDE;
-            const int res_n = (ablate & 4) ? 0 : (int) in[0];
+        if (my_kp < kp.n) {
+            // the whole 144-byte record in nine independent 16-byte loads
+            const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
+            uint32_t rec32[SEL_STRIDE];
+#pragma unroll
+            for (int q = 0; q < SEL_STRIDE / 4; ++q) {
+                const uint4 v4 = in4[q];
+                rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
+            }
+            const int res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
-            // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240)
+            // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240).
+            // Gathers in groups of eight (24 independent loads in flight), sums strictly in order.
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
-            // gathers in groups of four (12 independent loads in flight), sums strictly in order
-            for (int j0 = res_n - 1; j0 >= 0; j0 -= 4) {
-                uint32_t off[4];
-                double gx[4], gy[4], gz[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) off[q] = (j0 - q >= 0) ? in[1 + j0 - q] : 0u;
+            for (int g = 0; g < KMAX / 8; ++g) {
+                if (8 * g < res_n) {
+                    double gx[8], gy[8], gz[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    gx[q] = *reinterpret_cast<const double *>(pbase + off[q]);
-                    gy[q] = *reinterpret_cast<const double *>(pbase_y + off[q]);
-                    gz[q] = *reinterpret_cast<const double *>(pbase_z + off[q]);
-                }
-                if (j0 == res_n - 1) res_q = Vec3{gx[0], gy[0], gz[0]};    // points[0]: the farthest kept (ct_icp.cpp:791)
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t off = (8 * g + q < res_n) ? rec32[1 + 8 * g + q] : 0u;
+                        gx[q] = *reinterpret_cast<const double *>(pbase + off);
+                        gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
+                        gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
+                    }
+                    if (g == 0) res_q = Vec3{gx[0], gy[0], gz[0]};      // points[0]: the farthest kept (ct_icp.cpp:791)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (j0 - q >= 0) {
-                        const double x = gx[q], y = gy[q], z = gz[q];
-                        res_S.x += x; res_S.y += y; res_S.z += z;
-                        res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
-                        res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+                    for (int q = 0; q < 8; ++q) {
+                        if (8 * g + q < res_n) {
+                            const double x = gx[q], y = gy[q], z = gz[q];
+                            res_S.x += x; res_S.y += y; res_S.z += z;
+                            res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
+                            res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+                        }
                     }
                 }
             }
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
-            const Vec3 p{W.px[lane], W.py[lane], W.pz[lane]};
+            const Vec3 p{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};       // written (or taken as given) by phase A
             const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+            Vec3 nrm{0, 0, 0};
+            double a2d = 0.0;
             if (!(ablate & 8)) used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;
@@ -922,47 +966,30 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 dbg.used[my_kp] = used ? 1 : 0;
             }
         }
-        CTGN_TICK(6)
-        // ---------------- phase D: packed u u^T | -u r | count, lanes own entries (LDS-transposed sum)
-        {
-            double *my = W.rec + lane * 13;          // aliases the row scratch: phase B is finished for this wave
+        // packed u u^T | -u r | count: each wave stages its 64 records in LDS and every lane sums the 1-2 packed
+        // entries it owns over them (LDS-transposed accumulation; fixed order)
+        double *rec = s_rec[wave];
+        double *my = rec + lane * 13;
 #pragma unroll
-            for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
-            my[12] = used ? rr : 0.0;
-            const unsigned long long ub = __ballot(used);
-            for (int j = 0; j < ((ablate & 128) ? 0 : 64); ++j) {
-                const double *rj = W.rec + j * 13;
-                acc0 += rj[e0i] * rj[e0j];
-                if (e1kind != 2) acc1 += e1sign * rj[e1i] * rj[e1j];
-            }
-            if (e1kind == 2 && lane == 26) acc1 += (double) __popcll(ub);
+        for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
+        my[12] = used ? rr : 0.0;
+        const unsigned long long ub = __ballot(used);
+        for (int j = 0; j < ((ablate & 128) ? 0 : 64); ++j) {
+            const double *rj = rec + j * 13;
+            acc0 += rj[e0i] * rj[e0j];
+            if (e1kind != 2) acc1 += e1sign * rj[e1i] * rj[e1j];
         }
-        CTGN_TICK(7)
+        if (e1kind == 2 && lane == 26) acc1 += (double) __popcll(ub);
     }
-    if (PROF && lane == 0) {
-        unsigned long long tot_ = 0;
-        for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
-        atomicMax(&prof[10], tot_);            // slowest wave
-        atomicAdd(&prof[11], 1ull);            // waves
-    }
-#undef CTGN_TICK
-    // ---------------- block combine: fixed order over the waves
-    __syncthreads();
-    double *comb = reinterpret_cast<double *>(smem);      // [ROW_WAVES][SYS_N]
-    comb[wave * SYS_N + lane] = acc0;
-    if (lane < SYS_N - 64) comb[wave * SYS_N + 64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+    // block combine: fixed order over the waves
+    s_comb[wave][lane] = acc0;
+    if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
     __syncthreads();
     if (tid < SYS_N) {
         double s = 0.0;
-        for (int w = 0; w < ROW_WAVES; ++w) s += comb[w * SYS_N + tid];
+        for (int w = 0; w < RES_BLOCK / 64; ++w) s += s_comb[w][tid];
         partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
     }
-}
-
-template <int NB>
-inline size_t rows_kernel_smem() {
-    constexpr int S = 2 * NB + 1, V = S * S * S, OCC = (V + 3) & ~3;
-    return sizeof(WaveScratch<OCC>) * ROW_WAVES;
 }
 
 // ================================================================================================
