@@ -244,7 +244,8 @@ def main():
             "frames_per_sec_equiv": 1.0 / (dt / args.steps * 5) if dt > 0 else None,   # 5 GN iterations per frame (driving profile)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_accumulate_rows" if args.variant != 1 else "k_accumulate_lane",
+                         "kernel": "k_accumulate_rows (voxel-hash neighbour search + k-nearest selection)" if args.variant != 1
+                                   else "k_accumulate_lane",
                          "kernel_ms_avg": kern_ms, "kernel_launches": kern_launches,
                          "alg_bytes_per_launch": alg_bytes,
                          "alg_bytes_per_keypoint": alg_bytes / n_kp,
