@@ -258,6 +258,8 @@ def main():
                                                   "(the reference's keypoint count; latency regime)",
                                             "D": "config D-like: dense analytic street, map {0.5 m, 40 pts} ~0.5 GB (> Infinity Cache), "
                                                  "1 M keypoints spread over the whole map, radius 0.8 (125 voxels), k=20"}[args.workload]
+        if args.workload == "B2" and world == 1 and not args.ablate:
+            result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
         if not args.no_cpu_baseline and args.workload == "B2":
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
@@ -285,6 +287,32 @@ def usable_cores() -> int:
         except (OSError, ValueError, IndexError):
             pass
     return max(1, n)
+
+
+def measure_frames_per_sec(cia, gm, inp, syn, se3, mm, reps: int = 30):
+    """M2 of SURVEY.md 8d: frames/s = 1 / wall time of one whole `CT_ICP_Registration::Register` call through the C ABI
+    (host WPoint3D buffer in, H2D, all GN iterations to the stop test, pose + world points out) with the driving profile
+    (5 iterations, stop at ||x|| < 0.1, config/odometry/driving_config.yaml:58-83) on the reference's keypoint count
+    (1.5 m grid of the 0.5 m-subsampled sweep)."""
+    raw, t = inp["raw"], inp["t"]
+    sel = syn.grid_sample_indices(raw, 0.5)
+    sel = sel[syn.grid_sample_indices(raw[sel], 1.5)]
+    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
+    kps = np.zeros(len(sel), dtype=cia.WPOINT3D_DTYPE)
+    kps["raw_point"], kps["t"] = raw[sel], t[sel]
+    world0 = se3.ct_transform(pose0, inp["tbe"], t[sel], raw[sel])
+    reg = cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.GN, num_iters_icp=5, threshold_orientation_norm=0.1, debug_print=False))
+    times, iters = [], []
+    for _ in range(reps):
+        kps["world_point"] = world0
+        frame = cia.TrajectoryFrame.from_pose14(pose0, *inp["tbe"])
+        t0 = time.perf_counter()
+        summ = reg.Register(gm, kps, frame, mm)
+        times.append(time.perf_counter() - t0)
+        iters.append(summ.num_iters)
+    med = float(np.median(times[3:]))
+    return {"value": 1.0 / med, "unit": "frames/s", "ms_per_frame": med * 1e3, "keypoints": int(len(sel)),
+            "gn_iterations": int(np.median(iters)), "includes": "host WPoint3D buffer -> H2D -> GN loop -> pose + world points D2H"}
 
 
 def cpu_baseline(inp, pose0, world0, args):

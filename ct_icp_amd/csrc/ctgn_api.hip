@@ -85,6 +85,7 @@ struct ctgn_context {
     double acc_ms = 0.0;
     int acc_launches = 0;
 
+    int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
@@ -316,7 +317,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
             ev = nullptr;
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
-            grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, MAX_PARTIAL_BLOCKS));
+            grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
             hipLaunchKernelGGL(k_residual_reduce, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm,
                                h->d_partials, dv, h->ablate);
         };

@@ -372,3 +372,46 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def nclt_case():
+    """Config-C-like (BASELINE.json configs[2]): HDL-32E pattern, jittery Segway-like motion, the NCLT profile's three-resolution
+    map (0.5 / 1 / 2 m x 30 pts; default radius 0.8 => the 0.5 m level, 125 voxels per query), min_number_neighbors 10,
+    20 iterations, <= 1500 keypoints (reference config/odometry/nclt_config.yaml:19-104)."""
+    scene = syn.street_scene(150.0, seed=2, half_width=(7.0, 9.0))
+    dirs, rel_t = syn.lidar_pattern("hdl32", azimuth_steps=900)
+    knots = syn.driving_trajectory(10, dt=0.1, speed=2.0, yaw_rate=0.3, height=1.0, jitter=0.02, seed=2, start_x=20.0)
+    scans = [syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), max_range=60.0, noise=0.02,
+                               seed=200 + j) for j in range(9)]
+    return dict(scene=scene, knots=knots, scans=scans, resolutions=[(0.5, 0.08, 30), (1.0, 0.08, 30), (2.0, 0.08, 30)],
+                default_radius=0.8)
+
+
+def test_config_c_nclt_profile_matches_oracle(nclt_case):
+    case = nclt_case
+    om, gm = build_maps(case, 8, with_gpu=True)
+    assert gm.SearchParamsFromRadiusSearch() == (0, 0.5, 2) == om.search_params()
+    sc = case["scans"][8]
+    sel = syn.grid_sample_indices(sc.raw, 0.8)[:1500]                 # max_num_keypoints 1500
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.01, 0.05, seed=7)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    o = _opts(num_iters_icp=20, min_number_neighbors=10, threshold_orientation_norm=1e-4)
+    mm, op = _prior(case, 8)
+    s = cia.GnSolver(gm)
+    s.set_debug(True)
+    s.set_keypoints(raw, world0, t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o, mm)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    assert summ.success and so.success and summ.num_iters == so.num_iters
+    assert summ.num_residuals_used == so.num_residuals_used > 300
+    tr, rot = se3.pose_error(pose1, pose_o)
+    assert tr < 1e-7 and rot < 1e-7, (tr, rot)
+    assert np.abs(s.world_points() - world_o).max() < 1e-7
+    # neighbourhoods with 10..19 points are used under this profile (min 10 < max 20)
+    nn = s.get_debug()["n_neighbors"]
+    assert ((nn >= 10) & (nn < 20)).sum() > 0
+    # all three resolutions of the host mirror agree with the oracle map
+    for li in range(3):
+        assert gm.NumVoxels(li) == om.num_voxels(li)
