@@ -1095,7 +1095,45 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     const int i = lane;                   // row owned by this lane (valid for lane < 12)
     if (i < 12) { perm[i] = i; s_b[i] = bi; }
     WSYNC();
-    for (int k = 0; k < 12; ++k) {
+    // Fast factorisation: un-pivoted, right-looking LDL^T with row i of the (symmetric) matrix in the registers of lane
+    // i; the pivot row is broadcast with v_readlane, no LDS traffic. For a positive definite system it agrees with the
+    // pivoted factorisation to rounding. Taken only when every pivot is safely positive relative to the largest
+    // diagonal entry; otherwise the Eigen-style diagonally pivoted factorisation below runs on the untouched s_m.
+    bool fast_ok = true;
+    {
+        const int ii0 = (i < 12) ? i : 0;
+        double rowr[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) rowr[j] = m[12 * ii0 + j];
+        double dmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const double djj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rowr[j]), j),
+                                                __builtin_amdgcn_readlane(__double2loint(rowr[j]), j));
+            dmax = fmax(dmax, fabs(djj));
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rowr[k]), k),
+                                               __builtin_amdgcn_readlane(__double2loint(rowr[k]), k));
+            fast_ok = fast_ok && (dk > 1e-10 * dmax);
+            const double lik = (i > k) ? rowr[k] / dk : 0.0;
+#pragma unroll
+            for (int j = k + 1; j < 12; ++j) {
+                const double vkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rowr[j]), k),
+                                                    __builtin_amdgcn_readlane(__double2loint(rowr[j]), k));
+                if (i > k) rowr[j] -= lik * vkj;
+            }
+            if (i > k) rowr[k] = lik;
+        }
+        fast_ok = fast_ok && (dmax > 0.0);
+        if (fast_ok && i < 12) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) m[12 * i + j] = rowr[j];       // lower triangle: L, diagonal: D (upper: scratch)
+        }
+    }
+    WSYNC();
+    for (int k = 0; k < (fast_ok ? 0 : 12); ++k) {
         // pivot: first index of the largest |diagonal| among k..11 — DPP butterfly over lanes 0..15 (no LDS round trip)
         double dv = (i >= k && i < 12) ? fabs(m[13 * i]) : -1.0;
         int di = i;
