@@ -1024,24 +1024,30 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     if (mode != 2) {
         // wave w owns entries w, w+16, ..., w+80: six independent lane-strided sums (loads of all six in flight
         // together), then six fixed shuffle trees
-        constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 4;
+        constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 3;
         double acc[EPW];
 #pragma unroll
         for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
-        for (int b0 = 0; b0 < nblocks; b0 += 64 * RU) {
-            double v[RU][EPW];
+        // 16-byte loads: a lane takes blocks 2*lane and 2*lane + 1 of each 128-block span; with <= 640 blocks (the
+        // usual case) all 5 x 6 loads of a lane are in flight at once, so the reduction costs one memory round trip
+        for (int b0 = 0; b0 < nblocks; b0 += 128 * RU) {
+            double2 v[RU][EPW];
 #pragma unroll
-            for (int u = 0; u < RU; ++u) {             // RU * 6 independent loads in flight
-                const int b = b0 + 64 * u + lane;
+            for (int u = 0; u < RU; ++u) {
+                const int b = b0 + 128 * u + 2 * lane;
                 const int bb = b < nblocks ? b : 0;
 #pragma unroll
-                for (int q = 0; q < EPW; ++q) v[u][q] = partials[(size_t) (wave + 16 * q) * MAX_PARTIAL_BLOCKS + bb];
+                for (int q = 0; q < EPW; ++q)
+                    v[u][q] = *reinterpret_cast<const double2 *>(partials + (size_t) (wave + 16 * q) * MAX_PARTIAL_BLOCKS + bb);
             }
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                const bool ok = b0 + 64 * u + lane < nblocks;
+                const int b = b0 + 128 * u + 2 * lane;
 #pragma unroll
-                for (int q = 0; q < EPW; ++q) acc[q] += ok ? v[u][q] : 0.0;
+                for (int q = 0; q < EPW; ++q) {
+                    acc[q] += (b < nblocks) ? v[u][q].x : 0.0;
+                    acc[q] += (b + 1 < nblocks) ? v[u][q].y : 0.0;
+                }
             }
         }
 #pragma unroll
