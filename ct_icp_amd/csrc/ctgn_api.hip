@@ -49,6 +49,10 @@ struct ctgn_context {
     double *h_kp = nullptr;             // pinned staging, same layout
     double t_min = 0, t_max = 0;
 
+    // undistortion staging (ctgn_transform_points): 7 x tp_cap doubles on the device, 4 x tp_cap pinned
+    double *d_tp = nullptr, *h_tp = nullptr;
+    size_t tp_cap = 0;
+
     // solver
     GnState *d_state = nullptr;
     GnState *h_state = nullptr;         // pinned
@@ -473,6 +477,8 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->stream) hipStreamSynchronize(h->stream);
         for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
         if (h->d_kp) hipFree(h->d_kp);
+        if (h->d_tp) hipFree(h->d_tp);
+        if (h->h_tp) hipHostFree(h->h_tp);
         if (h->d_res) hipFree(h->d_res);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
@@ -783,6 +789,53 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
         return st;
     }
     return ctgn_gn_end(h, pose_io, summary);
+}
+
+ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const double pose[14], const double tbe[2],
+                                  void *out_base, size_t out_stride, ctgn_dtype out_dtype) {
+    NEED_DEVICE(h);
+    if (!pose || !tbe || (n && (!raw.base || !ts.base || !out_base))) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CTGN_OK;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n > h->tp_cap) {
+        if (h->d_tp) HIPCHK(h, hipFree(h->d_tp));
+        if (h->h_tp) HIPCHK(h, hipHostFree(h->h_tp));
+        h->d_tp = nullptr; h->h_tp = nullptr; h->tp_cap = 0;
+        const size_t cap = n + n / 4 + 1024;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_tp), cap * 7 * sizeof(double)));      // x y z t | out x y z
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_tp), cap * 4 * sizeof(double), hipHostMallocDefault));
+        h->tp_cap = cap;
+    }
+    const size_t c = h->tp_cap;
+    bool in_range = true;
+    for (size_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) h->h_tp[a * c + i] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
+        const double t = read_elem(ts.base, ts.stride_bytes, ts.dtype, i, 0);
+        h->h_tp[3 * c + i] = t;
+        in_range = in_range && (tbe[0] <= t && t <= tbe[1]);
+    }
+    if (!in_range) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
+    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int a = 0; a < 4; ++a)
+        HIPCHK(h, hipMemcpyAsync(h->d_tp + a * c, h->h_tp + a * c, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int grid = (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_transform_points, dim3(grid), dim3(256), 0, h->stream, h->d_tp, h->d_tp + 4 * c, (int) n, c, h->d_pose_in,
+                       tbe[0], tbe[1]);
+    HIPCHK(h, hipGetLastError());
+    for (int a = 0; a < 3; ++a)
+        HIPCHK(h, hipMemcpyAsync(h->h_tp + a * c, h->d_tp + (4 + a) * c, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; ++i) {
+        char *p = static_cast<char *>(out_base) + i * out_stride;
+        for (int a = 0; a < 3; ++a) {
+            const double v = h->h_tp[a * c + i];
+            if (out_dtype == CTGN_F64) reinterpret_cast<double *>(p)[a] = v;
+            else reinterpret_cast<float *>(p)[a] = (float) v;
+        }
+    }
+    return CTGN_OK;
 }
 
 ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t world_stride, ctgn_dtype world_dtype,

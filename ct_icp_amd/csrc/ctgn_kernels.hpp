@@ -1250,6 +1250,29 @@ __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st)
     }
 }
 
+// Full-scan undistortion (reference src/ct_icp/odometry.cpp:461-486): out = InterpolatePose(t) * raw for n points given as
+// SoA arrays [x | y | z | t] with stride `cap`; pose = begin|end (14 doubles), slerp constants computed per thread block.
+__global__ __launch_bounds__(256) void k_transform_points(const double *in, double *out, int n, size_t cap, const double *pose,
+                                                          double tb, double te) {
+    __shared__ GnState s;
+    if (threadIdx.x == 0) {
+        const Quat qb = quat_normalized(Quat{pose[0], pose[1], pose[2], pose[3]});
+        const Quat qe = quat_normalized(Quat{pose[7], pose[8], pose[9], pose[10]});
+        s.pose[0] = qb.x; s.pose[1] = qb.y; s.pose[2] = qb.z; s.pose[3] = qb.w;
+        s.pose[7] = qe.x; s.pose[8] = qe.y; s.pose[9] = qe.z; s.pose[10] = qe.w;
+        for (int c = 0; c < 3; ++c) { s.pose[4 + c] = pose[4 + c]; s.pose[11 + c] = pose[11 + c]; }
+        const SlerpPair sp = slerp_prepare(qb, qe);
+        s.slerp_theta = sp.theta; s.slerp_sin = sp.sin_theta; s.slerp_linear = sp.linear; s.slerp_negate = sp.negate;
+    }
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Vec3 raw{in[i], in[cap + i], in[2 * cap + i]};
+        const double alpha = alpha_timestamp(in[3 * cap + i], tb, te);
+        const Vec3 p = ct_transform(&s, alpha, raw);
+        out[i] = p.x; out[cap + i] = p.y; out[2 * cap + i] = p.z;
+    }
+}
+
 // GnState initialisation on the device (pose normalisation :716-717 + slerp constants).
 __global__ void k_state_init(GnState *st, const double *pose_in, double tb, double te) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -79,6 +79,22 @@ class CT_ICP_Registration:
         return _summary(s)
 
 
+def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end) -> np.ndarray:
+    """Full-scan continuous-time undistortion on the GPU (reference src/ct_icp/odometry.cpp:461-486): world[i] =
+    begin.InterpolatePose(end, t[i]) * raw[i]."""
+    raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+    pose = np.ascontiguousarray(pose14, dtype=np.float64)
+    tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+    out = np.zeros_like(raw)
+    dp = C.POINTER(C.c_double)
+    h = voxel_map.handle
+    L.check(h, L.lib().ctgn_transform_points(h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0),
+                                            len(t), pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), out.ctypes.data, 24,
+                                            L.CTGN_F64))
+    return out
+
+
 class GnSolver:
     """Array-level access to the same entry points (resident keypoints, repeated solves, stepwise GN for the
     sharded multi-GPU mode, introspection). Used by bench.py, ct_icp_amd.distributed and the parity tests."""

@@ -176,6 +176,13 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double t_begin_e
 ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride_bytes, ctgn_dtype dtype,
                                   size_t n);
 
+/* Continuous-time transform of an arbitrary point set with a begin|end pose — the step right after the path:
+ * the full-scan undistortion of Odometry::DoRegister (reference src/ct_icp/odometry.cpp:461-486,
+ * out[i] = begin.InterpolatePose(end, t[i]) * raw[i], include/SlamCore/types.h:413-419,453-470). Timestamps outside
+ * [t_begin, t_end] return CTGN_ERR_TIMESTAMP_RANGE (the reference CHECK-aborts). In and out may alias. */
+ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const double pose[14],
+                                  const double t_begin_end[2], void *out_base, size_t out_stride_bytes, ctgn_dtype out_dtype);
+
 /* One-shot drop-in for `case GN:` of SELECT_SOLVER (ct_icp.cpp:1008-1014) =
  * ctgn_set_keypoints + ctgn_solve + ctgn_get_world_points (world points are rewritten in place). */
 ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw_xyz, void *world_base, size_t world_stride_bytes,

@@ -415,3 +415,18 @@ def test_config_c_nclt_profile_matches_oracle(nclt_case):
     # all three resolutions of the host mirror agree with the oracle map
     for li in range(3):
         assert gm.NumVoxels(li) == om.num_voxels(li)
+
+
+def test_full_scan_undistortion(config_b_full):
+    """the continuous-time transform of a whole sweep (reference src/ct_icp/odometry.cpp:461-486) against
+    the oracle's InterpolatePose * raw, on ~130 k points."""
+    gm, sc = config_b_full
+    pose = syn.perturb_pose(sc.pose_gt, 0.01, 0.05, seed=9)
+    got = cia.transform_points(gm, sc.raw, sc.t, pose, sc.t_begin_end)
+    idx = np.random.default_rng(0).choice(len(sc.t), 3000, replace=False)
+    want = orc.transform_points(pose, sc.t_begin_end, sc.t[idx], sc.raw[idx])
+    assert np.abs(got[idx] - want).max() < 1e-11
+    assert np.abs(got - se3.ct_transform(pose, sc.t_begin_end, sc.t, sc.raw)).max() < 1e-10
+    with pytest.raises(cia.CtgnError) as e:
+        cia.transform_points(gm, sc.raw[:10], sc.t[:10] + 5.0, pose, sc.t_begin_end)
+    assert e.value.status == L.ERR_TIMESTAMP_RANGE
