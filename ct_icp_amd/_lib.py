@@ -75,6 +75,7 @@ SYMBOLS = {
     "ctgn_map_num_voxels": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint64)]),
     "ctgn_map_search_params": (C.c_int, [_H, C.c_double, C.POINTER(C.c_int32), _dp, C.POINTER(C.c_int32)]),
     "ctgn_map_export": (C.c_int, [_H, C.c_int32, _dp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ctgn_map_set_update_mode": (C.c_int, [_H, C.c_int32]),
     "ctgn_map_sync": (C.c_int, [_H]),
     "ctgn_map_radius_search": (C.c_int, [_H, _dp, C.c_size_t, C.c_double, C.c_int32, _dp, C.POINTER(C.c_int32)]),
     "ctgn_set_keypoints": (C.c_int, [_H, View, View, View, C.c_size_t]),

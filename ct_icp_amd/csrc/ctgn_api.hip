@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "ctgn_devmap.hpp"
 #include "ctgn_kernels.hpp"
 
 using namespace ctgn;
@@ -41,6 +42,9 @@ struct ctgn_context {
     ctgn_map_options opts{};
     std::vector<VoxelLevel> levels;
     std::vector<DeviceLevel> dlevels;
+    int update_mode = 0;                // 0: host mirror + delta upload, 1: device-resident maintenance (ctgn_devmap)
+    std::vector<DevLevel> devlevels;
+    DevMapScratch dm;
 
     // keypoints: one device allocation of 7 arrays [rx ry rz t wx wy wz] x cap_kp
     int n_kp = 0, cap_kp = 0;
@@ -221,6 +225,19 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     int map_id, nb;
     double res;
     search_params(h->levels, radius, &map_id, &res, &nb);
+    if (h->update_mode == 1) {
+        const DevLevel &DL = h->devlevels[map_id];
+        if ((size_t) DL.host.next_block * 3 * DL.blk * sizeof(double) >= ((size_t) 1 << 32))
+            return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB (32-bit block offsets in the kernels)");
+        mv->slots = DL.slots;
+        mv->blocks = DL.blocks;
+        mv->mask = (uint32_t) (DL.slots_cap - 1);
+        mv->blk = DL.blk;
+        mv->nb = nb;
+        mv->resolution = res;
+        mv->r2thr = radius_sq_threshold(radius);
+        return CTGN_OK;
+    }
     ctgn_status st = sync_level(h, map_id);
     if (st != CTGN_OK) return st;
     const VoxelLevel &L = h->levels[map_id];
@@ -476,6 +493,8 @@ void ctgn_destroy(ctgn_handle h) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
         for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
+        for (auto &d : h->devlevels) devmap_level_free(d);
+        devmap_scratch_free(h->dm);
         if (h->d_kp) hipFree(h->d_kp);
         if (h->d_tp) hipFree(h->d_tp);
         if (h->h_tp) hipHostFree(h->h_tp);
@@ -501,8 +520,62 @@ void ctgn_destroy(ctgn_handle h) {
 }
 
 // ---------------------------------------------------------------------------------------- map
+#define DMCHK(h, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, e_ == hipErrorOutOfMemory ? CTGN_ERR_OUT_OF_MEMORY : CTGN_ERR_HIP,         \
+                        std::string("[HIP] device map: ") + hipGetErrorString(e_));                   \
+    } while (0)
+
+ctgn_status ctgn_map_set_update_mode(ctgn_handle h, int32_t device_updates) {
+    NEED_DEVICE(h);
+    if (device_updates != 0 && device_updates != 1) return CTGN_ERR_INVALID_ARGUMENT;
+    uint64_t npts = 0;
+    ctgn_map_num_points(h, &npts);
+    if (npts != 0) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "the update mode can only change on an empty map");
+    if (device_updates == 1 && h->devlevels.empty()) {
+        h->devlevels.resize(h->levels.size());
+        for (size_t i = 0; i < h->levels.size(); ++i)
+            DMCHK(h, devmap_level_init(h->devlevels[i], h->levels[i].resolution, h->levels[i].min_distance, h->levels[i].blk, h->stream));
+    }
+    h->update_mode = device_updates;
+    return CTGN_OK;
+}
+
+static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
+    if (n == 0) return CTGN_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DMCHK(h, devmap_scratch_reserve(h->dm, n));
+    DevMapScratch &S = h->dm;
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz_base, stride, dt, i, a);
+    for (int a = 0; a < 3; ++a)
+        HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(S.inserted, 0, n, h->stream));
+    bool range_error = false, overflow = false;
+    for (auto &DL : h->devlevels) {                      // map.h:199-205: every resolution
+        DMCHK(h, devmap_level_insert(DL, S, n, h->stream));
+        range_error = range_error || DL.host.range_error;
+        overflow = overflow || DL.host.overflow;
+    }
+    if (out) {
+        HIPCHK(h, hipMemcpyAsync(S.h_inserted, S.inserted, n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(out, S.h_inserted, n);
+    }
+    if (overflow) return fail(h, CTGN_ERR_HIP, "device map capacity exhausted (internal sizing error)");
+    if (range_error) {
+        for (auto &DL : h->devlevels) (void) hipMemsetAsync(&DL.counters->range_error, 0, sizeof(unsigned int), h->stream);
+        return fail(h, CTGN_ERR_VOXEL_RANGE, "a point fell outside the 21-bit voxel key range and was skipped");
+    }
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
     if (!h || (!xyz_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->update_mode == 1) return devmap_insert(h, xyz_base, stride, dt, n, out);
     bool range_error = false;
     for (size_t i = 0; i < n; ++i) {
         double x = read_elem(xyz_base, stride, dt, i, 0), y = read_elem(xyz_base, stride, dt, i, 1),
@@ -521,12 +594,22 @@ ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, 
 
 ctgn_status ctgn_map_remove_far(ctgn_handle h, const double location[3], double distance) {
     if (!h || !location) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->update_mode == 1) {
+        HIPCHK(h, hipSetDevice(h->device));
+        for (auto &DL : h->devlevels) DMCHK(h, devmap_level_remove_far(DL, location, distance, h->stream));
+        return CTGN_OK;
+    }
     for (auto &L : h->levels) L.remove_far(location, distance);
     return CTGN_OK;
 }
 
 ctgn_status ctgn_map_clear(ctgn_handle h) {
     if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->update_mode == 1) {
+        HIPCHK(h, hipSetDevice(h->device));
+        for (auto &DL : h->devlevels) DMCHK(h, devmap_level_clear(DL, h->stream));
+        return CTGN_OK;
+    }
     for (auto &L : h->levels) {
         bool log = L.log_edits;
         L.clear();
@@ -538,14 +621,15 @@ ctgn_status ctgn_map_clear(ctgn_handle h) {
 ctgn_status ctgn_map_num_points(ctgn_handle h, uint64_t *out) {
     if (!h || !out) return CTGN_ERR_INVALID_ARGUMENT;
     uint64_t s = 0;
-    for (auto &L : h->levels) s += L.num_points;
+    if (h->update_mode == 1) for (auto &DL : h->devlevels) s += DL.host.num_points;
+    else for (auto &L : h->levels) s += L.num_points;
     *out = s;
     return CTGN_OK;
 }
 
 ctgn_status ctgn_map_num_voxels(ctgn_handle h, int32_t li, uint64_t *out) {
     if (!h || !out || li < 0 || li >= (int) h->levels.size()) return CTGN_ERR_INVALID_ARGUMENT;
-    *out = h->levels[li].num_voxels;
+    *out = h->update_mode == 1 ? h->devlevels[li].host.num_voxels : h->levels[li].num_voxels;
     return CTGN_OK;
 }
 
@@ -563,6 +647,11 @@ ctgn_status ctgn_map_search_params(ctgn_handle h, double radius, int32_t *map_id
 
 ctgn_status ctgn_map_export(ctgn_handle h, int32_t li, double *out_xyz, uint64_t cap, uint64_t *out_n) {
     if (!h || li < 0 || li >= (int) h->levels.size()) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->update_mode == 1) {
+        HIPCHK(h, hipSetDevice(h->device));
+        DMCHK(h, devmap_level_export(h->devlevels[li], out_xyz, cap, out_n, h->stream));
+        return CTGN_OK;
+    }
     uint64_t n = h->levels[li].export_points(out_xyz, cap);
     if (out_n) *out_n = n;
     return CTGN_OK;

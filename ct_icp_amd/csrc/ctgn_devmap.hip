@@ -1,0 +1,303 @@
+// ctgn_devmap.hip — device-resident voxel-map maintenance (see ctgn_devmap.hpp). Separate translation unit because of
+// hipcub (rocPRIM radix sort).
+#include "ctgn_devmap.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace ctgn {
+
+#define DM_CHK(call)                          \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) return e_;      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ kernels
+__global__ void k_dm_fill_slots(Slot *slots, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        slots[i] = Slot{KEY_EMPTY, 0u, 0u};
+}
+
+// voxel key of every staged point (Voxel::Coordinates, src/SlamCore/types.cxx:13-20); out-of-range / non-finite points
+// get KEY_EMPTY (they sort to the end and are skipped) and raise the range flag.
+__global__ void k_dm_keys(const double *pts, size_t cap, size_t n, double resolution, uint64_t *keys, uint32_t *idx,
+                          DevCounters *cnt) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = pts[i], y = pts[cap + i], z = pts[2 * cap + i];
+    uint64_t key = KEY_EMPTY;
+    const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+    if (fin) {
+        const int vx = voxel_coord(x, resolution), vy = voxel_coord(y, resolution), vz = voxel_coord(z, resolution);
+        if (vx >= -COORD_LIMIT && vx <= COORD_LIMIT && vy >= -COORD_LIMIT && vy <= COORD_LIMIT && vz >= -COORD_LIMIT && vz <= COORD_LIMIT)
+            key = pack_key(vx, vy, vz);
+    }
+    if (key == KEY_EMPTY) atomicOr(&cnt->range_error, 1u);
+    keys[i] = key;
+    idx[i] = (uint32_t) i;
+}
+
+// One thread per sorted position; the thread at the head of a run of equal keys inserts the whole run, in original
+// order (the sort is stable), with the reference's rule (map.h:261-293).
+__global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk, uint32_t nblocks_cap, uint32_t *free_list,
+                            DevCounters *cnt, const uint64_t *keys, const uint32_t *idx, size_t n, const double *pts, size_t cap,
+                            double min_dist_sq, uint8_t *inserted) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    if (key == KEY_EMPTY) return;
+    if (i > 0 && keys[i - 1] == key) return;              // not the head of its run
+    // find the voxel, or claim an EMPTY slot for it (tombstones are not reused here; the host rehashes when they pile up)
+    uint32_t s = hash_key(key, mask);
+    bool fresh = false;
+    for (uint32_t probes = 0;; ++probes) {
+        const unsigned long long cur = *reinterpret_cast<volatile unsigned long long *>(&slots[s].key);
+        if (cur == key) break;
+        if (cur == KEY_EMPTY) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s].key), KEY_EMPTY, key);
+            if (old == KEY_EMPTY) { fresh = true; break; }
+            if (old == key) break;
+        }
+        s = (s + 1) & mask;
+        if (probes > mask) { atomicOr(&cnt->overflow, 1u); return; }
+    }
+    uint32_t block, count;
+    if (fresh) {
+        const int t = atomicSub(&cnt->free_top, 1) - 1;
+        if (t >= 0) {
+            block = free_list[t];
+        } else {
+            atomicAdd(&cnt->free_top, 1);
+            block = atomicAdd(&cnt->next_block, 1u);
+            if (block >= nblocks_cap) { atomicOr(&cnt->overflow, 2u); slots[s].block = 0; slots[s].count = 0; return; }
+        }
+        count = 0;
+        atomicAdd(&cnt->num_voxels, 1ull);
+    } else {
+        block = slots[s].block;
+        count = slots[s].count;
+    }
+    double *bx = blocks + (size_t) block * 3 * blk, *by = bx + blk, *bz = by + blk;
+    unsigned long long added = 0;
+    for (size_t j = i; j < n && keys[j] == key; ++j) {
+        const uint32_t pi = idx[j];
+        const double px = pts[pi], py = pts[cap + pi], pz = pts[2 * cap + pi];
+        bool take = false;
+        if (count == 0) {
+            take = true;                                                     // map.h:267-273 (new voxel: always)
+        } else if ((int) count < blk) {                                      // map.h:275-291
+            double sq_min = 1.7976931348623157e308;
+            for (uint32_t q = 0; q < count; ++q) {
+                const double dx = bx[q] - px, dy = by[q] - py, dz = bz[q] - pz;
+                const double sq = dx * dx + dy * dy + dz * dz;
+                if (sq < sq_min) sq_min = sq;
+            }
+            take = sq_min > min_dist_sq;
+        }
+        if (take) {
+            bx[count] = px; by[count] = py; bz[count] = pz;
+            ++count;
+            ++added;
+            inserted[pi] = 1;
+        }
+    }
+    slots[s].block = block;
+    slots[s].count = count;
+    if (added) atomicAdd(&cnt->num_points, added);
+}
+
+// RemoveElementsFarFromLocation (map.h:305-322): voxel removed iff ||first point - location|| > distance.
+__global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *blocks, int blk, uint32_t *free_list, DevCounters *cnt,
+                                double lx, double ly, double lz, double distance) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
+        const Slot s = slots[i];
+        if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
+        const double *bx = blocks + (size_t) s.block * 3 * blk;
+        const double dx = bx[0] - lx, dy = bx[blk] - ly, dz = bx[2 * blk] - lz;
+        if (sqrt(dx * dx + dy * dy + dz * dz) > distance) {
+            slots[i] = Slot{KEY_TOMB, 0u, 0u};
+            const int t = atomicAdd(&cnt->free_top, 1);
+            free_list[t] = s.block;
+            atomicAdd(&cnt->num_tombs, 1ull);
+            atomicAdd(&cnt->num_voxels, ~0ull);                   // -1
+            atomicAdd(&cnt->num_points, ~((unsigned long long) s.count) + 1ull);     // -count
+        }
+    }
+}
+
+// rebuild into a larger (tombstone-free) table
+__global__ void k_dm_rehash(const Slot *old_slots, uint64_t old_n, Slot *slots, uint32_t mask) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < old_n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const Slot s = old_slots[i];
+        if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
+        uint32_t d = hash_key(s.key, mask);
+        for (;;) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[d].key), KEY_EMPTY, s.key);
+            if (old == KEY_EMPTY) break;
+            d = (d + 1) & mask;
+        }
+        slots[d].block = s.block;
+        slots[d].count = s.count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static hipError_t read_counters(DevLevel &L, hipStream_t stream) {
+    DM_CHK(hipMemcpyAsync(&L.host, L.counters, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+    return hipStreamSynchronize(stream);
+}
+
+static hipError_t alloc_table(Slot **slots, uint64_t cap, hipStream_t stream) {
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(slots), cap * sizeof(Slot)));
+    hipLaunchKernelGGL(k_dm_fill_slots, dim3((unsigned) std::min<uint64_t>((cap + 255) / 256, 4096)), dim3(256), 0, stream, *slots, cap);
+    return hipGetLastError();
+}
+
+hipError_t devmap_level_init(DevLevel &L, double resolution, double min_distance, int blk, hipStream_t stream) {
+    L.resolution = resolution;
+    L.min_distance = min_distance;
+    L.blk = blk < 1 ? 1 : blk;
+    L.slots_cap = 1 << 14;
+    L.nblocks_cap = 2048;
+    DM_CHK(alloc_table(&L.slots, L.slots_cap, stream));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&L.blocks), (size_t) L.nblocks_cap * 3 * L.blk * sizeof(double)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&L.free_list), (size_t) L.nblocks_cap * sizeof(uint32_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&L.counters), sizeof(DevCounters)));
+    DM_CHK(hipMemsetAsync(L.counters, 0, sizeof(DevCounters), stream));
+    L.host = DevCounters{};
+    return hipStreamSynchronize(stream);
+}
+
+void devmap_level_free(DevLevel &L) {
+    if (L.slots) (void) hipFree(L.slots);
+    if (L.blocks) (void) hipFree(L.blocks);
+    if (L.free_list) (void) hipFree(L.free_list);
+    if (L.counters) (void) hipFree(L.counters);
+    L = DevLevel{};
+}
+
+hipError_t devmap_level_clear(DevLevel &L, hipStream_t stream) {
+    hipLaunchKernelGGL(k_dm_fill_slots, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream,
+                       L.slots, L.slots_cap);
+    DM_CHK(hipGetLastError());
+    DM_CHK(hipMemsetAsync(L.counters, 0, sizeof(DevCounters), stream));
+    L.host = DevCounters{};
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n) {
+    if (n <= S.cap) return hipSuccess;
+    devmap_scratch_free(S);
+    const size_t cap = n + n / 4 + 1024;
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.pts), cap * 3 * sizeof(double)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.keys), cap * sizeof(uint64_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.keys_alt), cap * sizeof(uint64_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx), cap * sizeof(uint32_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx_alt), cap * sizeof(uint32_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.inserted), cap));
+    DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_pts), cap * 3 * sizeof(double), hipHostMallocDefault));
+    DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_inserted), cap, hipHostMallocDefault));
+    size_t tmp = 0;
+    DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) cap, 0, 64, (hipStream_t) 0));
+    DM_CHK(hipMalloc(&S.cub_temp, tmp));
+    S.cub_temp_bytes = tmp;
+    S.cap = cap;
+    return hipSuccess;
+}
+
+void devmap_scratch_free(DevMapScratch &S) {
+    if (S.pts) (void) hipFree(S.pts);
+    if (S.keys) (void) hipFree(S.keys);
+    if (S.keys_alt) (void) hipFree(S.keys_alt);
+    if (S.idx) (void) hipFree(S.idx);
+    if (S.idx_alt) (void) hipFree(S.idx_alt);
+    if (S.inserted) (void) hipFree(S.inserted);
+    if (S.cub_temp) (void) hipFree(S.cub_temp);
+    if (S.h_pts) (void) hipHostFree(S.h_pts);
+    if (S.h_inserted) (void) hipHostFree(S.h_inserted);
+    S = DevMapScratch{};
+}
+
+// make room for up to n new voxels: load factor (live + tombstones) <= 1/4 after the batch, one block per new voxel
+static hipError_t ensure_capacity(DevLevel &L, size_t n, hipStream_t stream) {
+    const uint64_t worst = L.host.num_voxels + L.host.num_tombs + n;
+    if (worst * 4 > L.slots_cap) {
+        uint64_t cap = L.slots_cap;
+        while (cap < 8 * (L.host.num_voxels + n)) cap <<= 1;
+        Slot *fresh = nullptr;
+        DM_CHK(alloc_table(&fresh, cap, stream));
+        hipLaunchKernelGGL(k_dm_rehash, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream,
+                           L.slots, L.slots_cap, fresh, (uint32_t) (cap - 1));
+        DM_CHK(hipGetLastError());
+        DM_CHK(hipMemsetAsync(&L.counters->num_tombs, 0, sizeof(unsigned long long), stream));
+        DM_CHK(hipStreamSynchronize(stream));
+        DM_CHK(hipFree(L.slots));
+        L.slots = fresh;
+        L.slots_cap = cap;
+        L.host.num_tombs = 0;
+    }
+    const uint64_t free_blocks = (uint64_t) std::max(L.host.free_top, 0);
+    if ((uint64_t) L.host.next_block + n > (uint64_t) L.nblocks_cap + free_blocks) {
+        uint64_t want = std::max<uint64_t>((uint64_t) L.nblocks_cap * 2, (uint64_t) L.host.next_block + n);
+        if (want * 3 * L.blk * sizeof(double) >= ((uint64_t) 1 << 32)) want = (((uint64_t) 1 << 32) - 1) / (3ull * L.blk * sizeof(double));
+        if (want < (uint64_t) L.host.next_block + n - free_blocks) return hipErrorOutOfMemory;     // 32-bit block offsets
+        double *nb = nullptr;
+        uint32_t *nf = nullptr;
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&nb), want * 3 * L.blk * sizeof(double)));
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&nf), want * sizeof(uint32_t)));
+        DM_CHK(hipMemcpyAsync(nb, L.blocks, (size_t) L.host.next_block * 3 * L.blk * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (free_blocks) DM_CHK(hipMemcpyAsync(nf, L.free_list, free_blocks * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        DM_CHK(hipStreamSynchronize(stream));
+        DM_CHK(hipFree(L.blocks));
+        DM_CHK(hipFree(L.free_list));
+        L.blocks = nb;
+        L.free_list = nf;
+        L.nblocks_cap = (uint32_t) want;
+    }
+    return hipSuccess;
+}
+
+hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    DM_CHK(ensure_capacity(L, n, stream));
+    const unsigned grid = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_dm_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, L.resolution, S.keys, S.idx, L.counters);
+    DM_CHK(hipGetLastError());
+    size_t tmp = S.cub_temp_bytes;
+    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 64, stream));
+    hipLaunchKernelGGL(k_dm_insert, dim3(grid), dim3(256), 0, stream, L.slots, (uint32_t) (L.slots_cap - 1), L.blocks, L.blk, L.nblocks_cap,
+                       L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.cap, L.min_distance * L.min_distance, S.inserted);
+    DM_CHK(hipGetLastError());
+    return read_counters(L, stream);
+}
+
+hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {
+    hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance);
+    DM_CHK(hipGetLastError());
+    return read_counters(L, stream);
+}
+
+hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream) {
+    DM_CHK(read_counters(L, stream));
+    if (out_n) *out_n = L.host.num_points;
+    if (!out_xyz) return hipSuccess;
+    std::vector<Slot> slots(L.slots_cap);
+    std::vector<double> blocks((size_t) L.host.next_block * 3 * L.blk);
+    DM_CHK(hipMemcpyAsync(slots.data(), L.slots, L.slots_cap * sizeof(Slot), hipMemcpyDeviceToHost, stream));
+    if (!blocks.empty()) DM_CHK(hipMemcpyAsync(blocks.data(), L.blocks, blocks.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipStreamSynchronize(stream));
+    uint64_t k = 0;
+    for (const Slot &s : slots) {
+        if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
+        const double *bx = &blocks[(size_t) s.block * 3 * L.blk];
+        for (uint32_t j = 0; j < s.count; ++j, ++k)
+            if (k < cap_points) { out_xyz[3 * k] = bx[j]; out_xyz[3 * k + 1] = bx[L.blk + j]; out_xyz[3 * k + 2] = bx[2 * L.blk + j]; }
+    }
+    return hipSuccess;
+}
+
+}  // namespace ctgn

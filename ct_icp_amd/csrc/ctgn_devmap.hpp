@@ -1,0 +1,65 @@
+// ctgn_devmap.hpp — device-resident maintenance of the voxel map:
+// insert with per-voxel min-distance test + capacity cap (reference include/ct_icp/map.h:261-293) and far-voxel
+// eviction (:305-322) executed ON the GPU, same slot / block layout as the host mirror (ctgn_map.hpp), so the query
+// kernels do not care which side maintains the map. Opt-in per handle (ctgn_map_set_update_mode).
+//
+// Why the result is identical to the reference's sequential insertion: a point only interacts with the points of its own
+// voxel, so voxels are independent; the batch is stably sorted by voxel key (hipcub radix sort, values = original
+// index) and ONE thread walks a voxel's run in original order applying the reference's rule against the points already
+// in the block. Only block ids differ from a host-maintained map, and those are not observable.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ctgn_map.hpp"
+
+namespace ctgn {
+
+struct DevCounters {
+    unsigned long long num_voxels, num_tombs, num_points;
+    unsigned int next_block;     // bump allocator high-water mark
+    int free_top;                // stack pointer of the free-block list
+    unsigned int range_error;    // a point fell outside the 21-bit key range
+    unsigned int overflow;       // table / block pool exhausted (host sized them: must stay 0)
+};
+
+struct DevLevel {
+    // geometry (host copies)
+    double resolution = 0.5, min_distance = 0.1;
+    int blk = 40;
+    // device storage
+    Slot *slots = nullptr;
+    uint64_t slots_cap = 0;              // power of two
+    double *blocks = nullptr;
+    uint32_t nblocks_cap = 0;
+    uint32_t *free_list = nullptr;       // nblocks_cap entries
+    DevCounters *counters = nullptr;     // device
+    DevCounters host{};                  // last read-back
+};
+
+struct DevMapScratch {                   // per handle, shared by the levels
+    double *pts = nullptr;               // [3][cap] staged points
+    uint64_t *keys = nullptr, *keys_alt = nullptr;
+    uint32_t *idx = nullptr, *idx_alt = nullptr;
+    uint8_t *inserted = nullptr;
+    void *cub_temp = nullptr;
+    size_t cub_temp_bytes = 0;
+    size_t cap = 0;
+    double *h_pts = nullptr;             // pinned
+    uint8_t *h_inserted = nullptr;       // pinned
+};
+
+// All functions return hipSuccess or the failing HIP error; they enqueue on `stream` and synchronise where a read-back
+// is needed.
+hipError_t devmap_level_init(DevLevel &L, double resolution, double min_distance, int blk, hipStream_t stream);
+void devmap_level_free(DevLevel &L);
+hipError_t devmap_level_clear(DevLevel &L, hipStream_t stream);
+hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n);
+void devmap_scratch_free(DevMapScratch &S);
+// points already staged in S.pts (SoA, stride S.cap), n of them; ORs into S.inserted
+hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStream_t stream);
+hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream);
+hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream);
+
+}  // namespace ctgn

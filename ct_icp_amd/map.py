@@ -33,6 +33,7 @@ class GpuVoxelMapOptions:
     default_radius: float = 0.8
     max_frames_to_keep: int = 100
     device: int = 0                  # -1: host-only mirror (no queries possible); tests of the insert rule only
+    device_updates: bool = False     # True: insert / evict rules run on the GPU (no host mirror), SURVEY 8f row 1
     initial_voxel_capacity: int = 0
 
     @staticmethod
@@ -67,6 +68,8 @@ class GpuVoxelMap:
         if st != L.OK:
             raise L.CtgnError(st, lib.ctgn_status_string(st).decode())
         self._h = h
+        if self.options.device_updates:
+            L.check(self._h, lib.ctgn_map_set_update_mode(self._h, 1))
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -109,6 +109,10 @@ ctgn_status ctgn_map_search_params(ctgn_handle h, double radius, int32_t *map_id
 /* MapAsPointCloud for one resolution (map.h:349-407, xyz only). Call with out=NULL to get the count. */
 ctgn_status ctgn_map_export(ctgn_handle h, int32_t resolution_index, double *out_xyz, uint64_t capacity_points,
                             uint64_t *out_num_points);
+/* Who maintains the map. 0 (default): the host mirror applies the insert / evict rules and
+ * the device copy is updated by deltas. 1: the rules run ON the GPU (stable radix sort of the batch by voxel key, one
+ * thread per voxel walks its points in original order) — same results, no host mirror. Only on an empty map. */
+ctgn_status ctgn_map_set_update_mode(ctgn_handle h, int32_t device_updates);
 /* Push pending host-side map edits to the device now (otherwise done lazily by the next query). */
 ctgn_status ctgn_map_sync(ctgn_handle h);
 

@@ -430,3 +430,56 @@ def test_full_scan_undistortion(config_b_full):
     with pytest.raises(cia.CtgnError) as e:
         cia.transform_points(gm, sc.raw[:10], sc.t[:10] + 5.0, pose, sc.t_begin_end)
     assert e.value.status == L.ERR_TIMESTAMP_RANGE
+
+
+def _sorted_rows(a):
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def test_device_resident_map_maintenance(street_case, box_case):
+    """InsertPointInVoxelMap (map.h:261-293) and RemoveElementsFarFromLocation (:305-322) executed ON the
+    GPU (stable sort by voxel key + one thread per voxel in original order) give the oracle's insert decisions, point sets,
+    evictions, neighbour lists and registration — through several table growths, tombstones and block reuse."""
+    case = street_case
+    res = [(0.4, 0.05, 20), (0.8, 0.1, 30), (1.6, 0.15, 40)]
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=0.9,
+                                                device_updates=True))
+    om = orc.Map(resolutions=res, default_radius=0.9)
+    rng = np.random.default_rng(1)
+    for j in range(8):
+        sc = case["scans"][j]
+        pts = sc.world_gt[rng.permutation(len(sc.world_gt))[:20000]]
+        kg, ko = gm.InsertPointCloud(pts), om.insert(pts)
+        assert np.array_equal(kg, ko), f"insert decisions differ in frame {j}"
+        assert gm.NumPoints() == om.num_points()
+        if j >= 2:
+            loc = sc.pose_gt[11:14]
+            gm.RemoveElementsFarFromLocation(loc, 35.0)
+            om.remove_far(loc, 35.0)
+            assert gm.NumPoints() == om.num_points()
+        for li in range(3):
+            assert gm.NumVoxels(li) == om.num_voxels(li)
+    for li in range(3):
+        assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(li)), _sorted_rows(om.export(li)))
+    assert gm.SearchParamsFromRadiusSearch() == om.search_params() == (1, 0.8, 2)
+    qs = case["scans"][8].world_gt[rng.choice(len(case["scans"][8].world_gt), 400, replace=False)]
+    for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):
+        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+    # float32 strided input goes through the same cast as the host path
+    rec = np.zeros(3000, dtype=[("pad", "<f4"), ("xyz", "<f4", 3)])
+    rec["xyz"] = case["scans"][9].world_gt[:3000]
+    assert np.array_equal(gm.InsertPointCloud(rec["xyz"]), om.insert(rec["xyz"].astype(np.float64)))
+    # a registration on the device-maintained map equals the oracle's
+    sc, raw, t, pose0, world0 = _keypoints(case, 9, 0.8)
+    o = _opts(num_iters_icp=4, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
+    pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+    assert summ.num_residuals_used == so.num_residuals_used and se3.pose_error(pose1, pose_o)[0] < 1e-7
+    gm.ClearMap()
+    assert gm.NumPoints() == 0 and len(gm.MapAsPointCloud(1)) == 0
+    gm.InsertPointCloud(box_case["scans"][0].world_gt)
+    om2 = orc.Map(resolutions=res, default_radius=0.9)
+    om2.insert(box_case["scans"][0].world_gt)
+    assert gm.NumPoints() == om2.num_points()
