@@ -81,6 +81,7 @@ SYMBOLS = {
     "ctgn_set_keypoints": (C.c_int, [_H, View, View, View, C.c_size_t]),
     "ctgn_solve": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
     "ctgn_get_world_points": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
+    "ctgn_grid_sampling": (C.c_int, [_H, View, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_transform_points": (C.c_int, [_H, View, View, C.c_size_t, _dp, _dp, C.c_void_p, C.c_size_t, C.c_int]),
     "ctgn_register": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
                                 C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),

@@ -129,6 +129,14 @@ ctgn_status fail(ctgn_handle h, ctgn_status s, const std::string &msg) {
                         std::string("[HIP] ") + #call + " -> " + hipGetErrorString(e_));             \
     } while (0)
 
+#define DMCHK(h, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, e_ == hipErrorOutOfMemory ? CTGN_ERR_OUT_OF_MEMORY : CTGN_ERR_HIP,         \
+                        std::string("[HIP] device map: ") + hipGetErrorString(e_));                   \
+    } while (0)
+
 #define NEED_DEVICE(h)                                                                               \
     do {                                                                                             \
         if (!(h)) return CTGN_ERR_INVALID_ARGUMENT;                                                  \
@@ -520,14 +528,6 @@ void ctgn_destroy(ctgn_handle h) {
 }
 
 // ---------------------------------------------------------------------------------------- map
-#define DMCHK(h, call)                                                                               \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess)                                                                         \
-            return fail(h, e_ == hipErrorOutOfMemory ? CTGN_ERR_OUT_OF_MEMORY : CTGN_ERR_HIP,         \
-                        std::string("[HIP] device map: ") + hipGetErrorString(e_));                   \
-    } while (0)
-
 ctgn_status ctgn_map_set_update_mode(ctgn_handle h, int32_t device_updates) {
     NEED_DEVICE(h);
     if (device_updates != 0 && device_updates != 1) return CTGN_ERR_INVALID_ARGUMENT;
@@ -878,6 +878,23 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
         return st;
     }
     return ctgn_gn_end(h, pose_io, summary);
+}
+
+ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double voxel_size, uint32_t *out_indices, size_t *out_count) {
+    NEED_DEVICE(h);
+    if (!out_count || !(voxel_size > 0) || (n && (!xyz.base || !out_indices))) return CTGN_ERR_INVALID_ARGUMENT;
+    *out_count = 0;
+    if (n == 0) return CTGN_OK;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DMCHK(h, devmap_scratch_reserve(h->dm, n));
+    DevMapScratch &S = h->dm;
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
+    for (int a = 0; a < 3; ++a)
+        HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    DMCHK(h, devmap_grid_sampling(S, n, voxel_size, out_indices, out_count, h->stream));
+    return CTGN_OK;
 }
 
 ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const double pose[14], const double tbe[2],

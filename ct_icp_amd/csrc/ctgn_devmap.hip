@@ -144,6 +144,20 @@ __global__ void k_dm_rehash(const Slot *old_slots, uint64_t old_n, Slot *slots, 
     }
 }
 
+// grid sampling keys: static_cast<short>(p / voxel_size) per axis (ct_icp.cpp:70-72), three int16 packed in 48 bits
+__global__ void k_gs_keys(const double *pts, size_t cap, size_t n, double voxel_size, uint64_t *keys, uint32_t *idx) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint16_t vx = (uint16_t) (short) (int) (pts[i] / voxel_size), vy = (uint16_t) (short) (int) (pts[cap + i] / voxel_size),
+                   vz = (uint16_t) (short) (int) (pts[2 * cap + i] / voxel_size);
+    keys[i] = (uint64_t) vx | ((uint64_t) vy << 16) | ((uint64_t) vz << 32);
+    idx[i] = (uint32_t) i;
+}
+__global__ void k_gs_heads(const uint64_t *keys, size_t n, uint8_t *flags) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static hipError_t read_counters(DevLevel &L, hipStream_t stream) {
     DM_CHK(hipMemcpyAsync(&L.host, L.counters, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
@@ -198,10 +212,14 @@ hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n) {
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx), cap * sizeof(uint32_t)));
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx_alt), cap * sizeof(uint32_t)));
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.inserted), cap));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.sel_out), cap * sizeof(uint32_t)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.sel_count), sizeof(int)));
     DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_pts), cap * 3 * sizeof(double), hipHostMallocDefault));
     DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_inserted), cap, hipHostMallocDefault));
-    size_t tmp = 0;
+    size_t tmp = 0, tmp2 = 0;
     DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) cap, 0, 64, (hipStream_t) 0));
+    DM_CHK(hipcub::DeviceSelect::Flagged(nullptr, tmp2, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) cap, (hipStream_t) 0));
+    tmp = std::max(tmp, tmp2);
     DM_CHK(hipMalloc(&S.cub_temp, tmp));
     S.cub_temp_bytes = tmp;
     S.cap = cap;
@@ -215,6 +233,8 @@ void devmap_scratch_free(DevMapScratch &S) {
     if (S.idx) (void) hipFree(S.idx);
     if (S.idx_alt) (void) hipFree(S.idx_alt);
     if (S.inserted) (void) hipFree(S.inserted);
+    if (S.sel_out) (void) hipFree(S.sel_out);
+    if (S.sel_count) (void) hipFree(S.sel_count);
     if (S.cub_temp) (void) hipFree(S.cub_temp);
     if (S.h_pts) (void) hipHostFree(S.h_pts);
     if (S.h_inserted) (void) hipHostFree(S.h_inserted);
@@ -272,6 +292,30 @@ hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStrea
                        L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.cap, L.min_distance * L.min_distance, S.inserted);
     DM_CHK(hipGetLastError());
     return read_counters(L, stream);
+}
+
+hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, uint32_t *out_idx_host, size_t *out_count,
+                                hipStream_t stream) {
+    *out_count = 0;
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_gs_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, voxel_size, S.keys, S.idx);
+    DM_CHK(hipGetLastError());
+    size_t tmp = S.cub_temp_bytes;
+    // stable sort: inside a run of equal keys the original indices stay ascending, so the head of a run is the
+    // first-inserted point of its voxel (ct_icp.cpp:73-75)
+    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 48, stream));
+    hipLaunchKernelGGL(k_gs_heads, dim3(grid), dim3(256), 0, stream, S.keys_alt, n, S.inserted);
+    DM_CHK(hipGetLastError());
+    tmp = S.cub_temp_bytes;
+    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) n, stream));
+    int count = 0;
+    DM_CHK(hipMemcpyAsync(&count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipStreamSynchronize(stream));
+    DM_CHK(hipMemcpyAsync(out_idx_host, S.sel_out, (size_t) count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipStreamSynchronize(stream));
+    *out_count = (size_t) count;
+    return hipSuccess;
 }
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {

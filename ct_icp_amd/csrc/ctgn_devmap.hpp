@@ -43,6 +43,8 @@ struct DevMapScratch {                   // per handle, shared by the levels
     uint64_t *keys = nullptr, *keys_alt = nullptr;
     uint32_t *idx = nullptr, *idx_alt = nullptr;
     uint8_t *inserted = nullptr;
+    uint32_t *sel_out = nullptr;         // grid sampling: selected indices
+    int *sel_count = nullptr;
     void *cub_temp = nullptr;
     size_t cub_temp_bytes = 0;
     size_t cap = 0;
@@ -60,6 +62,11 @@ void devmap_scratch_free(DevMapScratch &S);
 // points already staged in S.pts (SoA, stride S.cap), n of them; ORs into S.inserted
 hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStream_t stream);
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream);
+// sub_sample_frame / grid_sampling (reference src/ct_icp/ct_icp.cpp:65-101): index of the first point of every voxel of
+// the staged points (voxel = static_cast<short>(p / voxel_size) per axis). Output in voxel-key order (the reference's
+// robin_map iteration order is unspecified). out_idx_host must hold n entries.
+hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, uint32_t *out_idx_host, size_t *out_count,
+                                hipStream_t stream);
 hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream);
 
 }  // namespace ctgn

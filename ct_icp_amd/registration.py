@@ -95,6 +95,18 @@ def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end) -> np.
     return out
 
 
+def grid_sampling(voxel_map: GpuVoxelMap, points, voxel_size: float) -> np.ndarray:
+    """ct_icp::grid_sampling / sub_sample_frame on the GPU (reference src/ct_icp/ct_icp.cpp:65-101): indices of the first
+    point of every voxel, in voxel-key order."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(len(pts), dtype=np.uint32)
+    cnt = C.c_size_t()
+    h = voxel_map.handle
+    L.check(h, L.lib().ctgn_grid_sampling(h, L.View(pts.ctypes.data, 24, L.CTGN_F64, 0), len(pts), float(voxel_size),
+                                         out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
+    return out[:cnt.value].copy()
+
+
 class GnSolver:
     """Array-level access to the same entry points (resident keypoints, repeated solves, stepwise GN for the
     sharded multi-GPU mode, introspection). Used by bench.py, ct_icp_amd.distributed and the parity tests."""

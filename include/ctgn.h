@@ -187,6 +187,12 @@ ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride
 ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const double pose[14],
                                   const double t_begin_end[2], void *out_base, size_t out_stride_bytes, ctgn_dtype out_dtype);
 
+/* sub_sample_frame / grid_sampling on the GPU (reference src/ct_icp/ct_icp.cpp:65-101): keeps the
+ * FIRST point of every voxel of size `voxel_size`, voxel = static_cast<short>(p / voxel_size) per axis. Writes the kept
+ * indices (at most n) to out_indices and their number to out_count. Order: by voxel key (the reference's order is the
+ * unspecified tsl::robin_map iteration order). */
+ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double voxel_size, uint32_t *out_indices, size_t *out_count);
+
 /* One-shot drop-in for `case GN:` of SELECT_SOLVER (ct_icp.cpp:1008-1014) =
  * ctgn_set_keypoints + ctgn_solve + ctgn_get_world_points (world points are rewritten in place). */
 ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw_xyz, void *world_base, size_t world_stride_bytes,

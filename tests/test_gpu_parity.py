@@ -483,3 +483,18 @@ def test_device_resident_map_maintenance(street_case, box_case):
     om2 = orc.Map(resolutions=res, default_radius=0.9)
     om2.insert(box_case["scans"][0].world_gt)
     assert gm.NumPoints() == om2.num_points()
+
+
+def test_grid_sampling_on_device(config_b_full):
+    """sub_sample_frame (reference src/ct_icp/ct_icp.cpp:65-83) on the GPU keeps exactly the points the
+    oracle keeps — the first point of every voxel — for the reference's two stages (0.5 m frame grid, 1.5 m keypoint grid)."""
+    gm, sc = config_b_full
+    for size in (0.5, 1.5, 0.05):
+        got = cia.grid_sampling(gm, sc.raw, size)
+        want = orc.grid_sampling(sc.raw, size)
+        assert len(got) == len(want) <= len(sc.raw)                       # test_A_grid_sampling.cxx:7-23
+        assert np.array_equal(np.sort(got), np.sort(want))
+    sub = sc.raw[cia.grid_sampling(gm, sc.raw, 0.5)]
+    kp = cia.grid_sampling(gm, sub, 1.5)
+    assert np.array_equal(np.sort(kp), np.sort(orc.grid_sampling(sub, 1.5))) and 500 < len(kp) < 5000
+    assert len(cia.grid_sampling(gm, np.zeros((0, 3)), 1.0)) == 0
