@@ -498,3 +498,58 @@ def test_grid_sampling_on_device(config_b_full):
     kp = cia.grid_sampling(gm, sub, 1.5)
     assert np.array_equal(np.sort(kp), np.sort(orc.grid_sampling(sub, 1.5))) and 500 < len(kp) < 5000
     assert len(cia.grid_sampling(gm, np.zeros((0, 3)), 1.0)) == 0
+
+
+def test_sequence_of_frames_end_to_end(street_case):
+    """The per-frame loop of Odometry::DoRegister (reference src/ct_icp/odometry.cpp:386-501) with every data-parallel step on
+    the GPU — frame grid sampling, keypoint grid sampling, GN registration with the previous-frame motion model, full-scan
+    undistortion, map insertion + far-voxel eviction on the device — against the same loop on the CPU oracle, frame by frame
+    over a short sequence: identical keypoint sets, insert decisions and map, poses within 1e-7."""
+    case = street_case
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius,
+                                                device_updates=True))
+    om = orc.Map(resolutions=res, default_radius=radius)
+    o = _opts(num_iters_icp=5, threshold_orientation_norm=1e-4, min_number_neighbors=10)
+    reg = cia.CT_ICP_Registration(o)
+    mm = cia.PreviousFrameMotionModel()
+    # frames 0-4 initialise the map with ground-truth poses (the reference's first frames are inserted as they are)
+    for j in range(5):
+        sc = case["scans"][j]
+        keep = cia.grid_sampling(gm, sc.raw, 0.5)
+        assert np.array_equal(np.sort(keep), np.sort(orc.grid_sampling(sc.raw, 0.5)))
+        keep = np.sort(keep)
+        world = cia.transform_points(gm, sc.raw[keep], sc.t[keep], sc.pose_gt, sc.t_begin_end)
+        assert np.array_equal(gm.InsertPointCloud(world), om.insert(world))
+    prev_g = prev_o = case["scans"][4].pose_gt.copy()
+    for j in range(5, 10):
+        sc = case["scans"][j]
+        keep = np.sort(cia.grid_sampling(gm, sc.raw, 0.5))                               # InitializeFrame (odometry.cpp:349-352)
+        raw, t = sc.raw[keep], sc.t[keep]
+        kp = np.sort(cia.grid_sampling(gm, raw, 0.7))                                    # TryRegister (odometry.cpp:538)
+        assert np.array_equal(kp, np.sort(orc.grid_sampling(raw, 0.7)))
+        # constant-velocity prediction from the previous optimised frame, shared by both sides (odometry.cpp:276-330)
+        pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=j)
+        world0 = cia.transform_points(gm, raw[kp], t[kp], pose0, sc.t_begin_end)
+        mm.previous_frame = cia.TrajectoryFrame.from_pose14(prev_g, 0.0, 0.0)
+        kps = np.zeros(len(kp), dtype=cia.WPOINT3D_DTYPE)
+        kps["raw_point"], kps["t"], kps["world_point"] = raw[kp], t[kp], world0
+        frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+        summ = reg.Register(gm, kps, frame, mm)
+        op = orc.MotionPrior(previous_begin_tr=prev_o[4:7], previous_end_tr=prev_o[11:14])
+        pose_o, _, so = orc.register_gn(om, raw[kp], world0, t[kp], pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+        assert summ.success and so.success and summ.num_residuals_used == so.num_residuals_used and summ.num_iters == so.num_iters
+        pose_g = frame.pose14()
+        tr, rot = se3.pose_error(pose_g, pose_o)
+        assert tr < 1e-7 and rot < 1e-7, (j, tr, rot)
+        # undistort the whole frame with the optimised pose and update the map (odometry.cpp:461-486, :936-952)
+        world_g = cia.transform_points(gm, raw, t, pose_g, sc.t_begin_end)
+        world_o = orc.transform_points(pose_o, sc.t_begin_end, t[::50], raw[::50])
+        assert np.abs(world_g[::50] - world_o).max() < 1e-6
+        # feed BOTH maps the same points so that a 1e-8 pose difference cannot flip an insert decision
+        assert np.array_equal(gm.InsertPointCloud(world_g), om.insert(world_g))
+        gm.RemoveElementsFarFromLocation(pose_g[11:14], 60.0)
+        om.remove_far(pose_g[11:14], 60.0)
+        assert gm.NumPoints() == om.num_points() and gm.NumVoxels(0) == om.num_voxels(0)
+        prev_g, prev_o = pose_g, pose_o
+    assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(om.export(0)))
