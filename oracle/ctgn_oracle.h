@@ -128,6 +128,46 @@ int orc_register_gn(const orc_map *m, const double *raw_xyz, double *world_xyz, 
  * iteration order is unspecified). Returns the number of kept indices. */
 size_t orc_grid_sampling(const double *raw_xyz, size_t n, double voxel_size, uint32_t *out_indices);
 
+/* ---- robust-loss (CERES-profile) route: DoRegisterCeres, ct_icp.cpp:457-707 (ctgn_oracle_robust.c) ---- */
+enum { ORC_LOSS_STANDARD = 0, ORC_LOSS_CAUCHY = 1, ORC_LOSS_HUBER = 2, ORC_LOSS_TOLERANT = 3, ORC_LOSS_TRUNCATED = 4 };
+
+typedef struct {                           /* CTICPOptions fields read by DoRegisterCeres (ct_icp.h:58-132) */
+    int num_iters_icp, min_number_neighbors, max_number_neighbors, debug_print;
+    int max_num_residuals, loss_function, ls_max_num_iters, num_closest_neighbors;
+    double weight_alpha, weight_neighborhood, power_planarity, max_dist_to_plane_ct_icp;
+    double ls_sigma, ls_tolerant_min_threshold;
+    double threshold_orientation_norm, threshold_translation_norm;
+} orc_robust_options;
+
+typedef struct {                           /* PreviousFrameMotionModel (motion_model.h:42-58, motion_model.cpp:12-61) */
+    double beta_location_consistency, beta_constant_velocity, beta_small_velocity, beta_orientation_consistency;
+    double previous_begin_tr[3], previous_end_tr[3], previous_end_quat[4];
+} orc_robust_prior;
+
+typedef struct {
+    double initial_cost, final_cost, final_radius;
+    int iterations, num_successful_steps, num_unsuccessful_steps, termination;
+} orc_lm_report;
+
+void orc_loss_evaluate(int kind, double sigma, double tolerant_min, double s, double rho[3]);
+/* CTFunctor<FunctorPointToPlane> residual and its 12 tangent partials [begin_quat | end_quat | begin_t | end_t]
+ * (EigenQuaternionParameterization tangent), by forward-mode automatic differentiation. jac may be NULL. */
+void orc_ct_point_to_plane(const double pose[14], double alpha, const double raw[3], const double ref[3],
+                           const double normal[3], double weight, double *residual, double *jac);
+size_t orc_robust_build(const orc_map *m, const double *raw_xyz, const double *world_xyz, const double *t, size_t n,
+                        const double t_begin_end[2], const orc_robust_options *opts, int heap_mode, double *raw_out,
+                        double *ref_out, double *normal_out, double *weight_out, double *alpha_out,
+                        int32_t *keypoint_out);
+double orc_robust_evaluate_fixed(const double *raw, const double *ref, const double *normal, const double *weight,
+                                 const double *alpha, size_t n, const orc_robust_options *opts,
+                                 const orc_robust_prior *prior, const double pose[14], double *H, double *g);
+int orc_robust_solve_fixed(const double *raw, const double *ref, const double *normal, const double *weight,
+                           const double *alpha, size_t n, const orc_robust_options *opts, const orc_robust_prior *prior,
+                           double pose[14], int max_num_iterations, orc_lm_report *rep);
+int orc_register_robust(const orc_map *m, const double *raw_xyz, double *world_xyz, const double *t, size_t n,
+                        double pose[14], const double t_begin_end[2], const orc_robust_options *opts,
+                        const orc_robust_prior *prior, int heap_mode, orc_summary *summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,76 @@ def gn_solve_update(A, b, n_used, pose14, prior=None):
     pose14[4:7] += x[3:6]
     pose14[11:14] += x[9:12]
     return pose14, x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# robust-loss route: closed-form derivative of the continuous-time point-to-plane residual
+# (reference include/ct_icp/cost_functions.h:46-58,200-225; Ceres differentiates it automatically)
+# ---------------------------------------------------------------------------------------------------------------------
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def ct_point_to_plane_analytic(pose14, a, raw, ref, normal, weight):
+    """r = w n.(ref - (R(a) raw + (1-a) tb + a te)) and dr/d(tangent), tangent = [begin_quat, end_quat, begin_t, end_t]
+    of Ceres' EigenQuaternionParameterization (q <- [sin|d|/|d| d, cos|d|] (x) q, i.e. a LEFT rotation by 2 d).
+
+    With R_b^T R_e = Exp(theta u), R(a) = R_b Exp(a theta u):
+        d p / d w_b = -[R raw]x + R [raw]x W_b R_b^T,      W_b = a J_r(a phi) J_l^-1(phi)
+        d p / d w_e = -R [raw]x W_e R_e^T,                 W_e = a J_r(a phi) J_r^-1(phi)
+    and both W are  a u u^T + s (cos(psi) (I - u u^T) + sin(psi) [u]x),  s = sin(a theta/2) / sin(theta/2),
+    psi_e = (1 - a) theta / 2, psi_b = -(1 + a) theta / 2.
+    """
+    pose14 = np.asarray(pose14, float)
+    raw, ref, normal = (np.asarray(v, float) for v in (raw, ref, normal))
+    qb = pose14[0:4] / np.linalg.norm(pose14[0:4])
+    qe = pose14[7:11] / np.linalg.norm(pose14[7:11])
+    Rb, Re = Rotation.from_quat(qb), Rotation.from_quat(qe)
+    qrel = _qmul(np.array([-qb[0], -qb[1], -qb[2], qb[3]]), qe)
+    if qrel[3] < 0:
+        qrel = -qrel
+    half = np.arctan2(np.linalg.norm(qrel[:3]), qrel[3])          # theta / 2
+    if half < 1e-12:
+        u, s, psi_e, psi_b = np.array([1.0, 0, 0]), a, 0.0, 0.0
+    else:
+        u = qrel[:3] / np.linalg.norm(qrel[:3])
+        s = np.sin(a * half) / np.sin(half)
+        psi_e, psi_b = (1 - a) * half, -(1 + a) * half
+    R = Rb * Rotation.from_rotvec(2 * a * half * u)
+    p = R.apply(raw) + (1 - a) * pose14[4:7] + a * pose14[11:14]
+    m = weight * normal
+    r = m @ (ref - p)
+    arot = R.apply(raw)
+    c = np.cross(R.inv().apply(m), raw)
+
+    def wt(psi):                                                     # W^T c
+        uc = u @ c
+        return a * u * uc + s * (np.cos(psi) * (c - u * uc) - np.sin(psi) * np.cross(u, c))
+
+    J = np.zeros(12)
+    J[0:3] = -2.0 * (np.cross(arot, m) + Rb.apply(wt(psi_b)))
+    J[3:6] = 2.0 * Re.apply(wt(psi_e))
+    J[6:9] = -(1 - a) * m
+    J[9:12] = -a * m
+    return r, J
+
+
+def quat_plus(q, d):
+    """EigenQuaternionParameterization::Plus."""
+    n = np.linalg.norm(d)
+    if n == 0:
+        return np.array(q, float)
+    dq = np.concatenate([np.sin(n) / n * np.asarray(d, float), [np.cos(n)]])
+    return _qmul(dq, np.asarray(q, float))
+
+
+def pose_plus(pose14, delta12):
+    out = np.array(pose14, float)
+    out[0:4] = quat_plus(pose14[0:4], delta12[0:3])
+    out[7:11] = quat_plus(pose14[7:11], delta12[3:6])
+    out[4:7] += delta12[6:9]
+    out[11:14] += delta12[9:12]
+    return out

@@ -19,9 +19,8 @@ _SO = os.path.join(_HERE, "_build", "libctgn_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds). Returns the .so path."""
-    src = os.path.join(_HERE, "ctgn_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ctgn_oracle.h"))):
+    srcs = [os.path.join(_HERE, f) for f in ("ctgn_oracle.c", "ctgn_oracle_robust.c", "ctgn_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
     return _SO
 
@@ -47,6 +46,28 @@ class _Summary(C.Structure):
                 ("last_step_norm", C.c_double), ("error_log", C.c_char * 256),
                 ("t_neighbors", C.c_double), ("t_normals", C.c_double), ("t_jacobian", C.c_double),
                 ("t_solve", C.c_double), ("t_update", C.c_double)]
+
+
+class _RobustOpts(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("num_iters_icp", "min_number_neighbors", "max_number_neighbors", "debug_print",
+                                       "max_num_residuals", "loss_function", "ls_max_num_iters",
+                                       "num_closest_neighbors")] + \
+               [(k, C.c_double) for k in ("weight_alpha", "weight_neighborhood", "power_planarity",
+                                          "max_dist_to_plane_ct_icp", "ls_sigma", "ls_tolerant_min_threshold",
+                                          "threshold_orientation_norm", "threshold_translation_norm")]
+
+
+class _RobustPrior(C.Structure):
+    _fields_ = [("beta_location_consistency", C.c_double), ("beta_constant_velocity", C.c_double),
+                ("beta_small_velocity", C.c_double), ("beta_orientation_consistency", C.c_double),
+                ("previous_begin_tr", C.c_double * 3), ("previous_end_tr", C.c_double * 3),
+                ("previous_end_quat", C.c_double * 4)]
+
+
+class _LmReport(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("iterations", C.c_int), ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+                ("termination", C.c_int)]
 
 
 _lib = None
@@ -99,6 +120,21 @@ def lib():
                                       C.POINTER(_Prior), C.c_int, C.c_int, C.POINTER(_Summary)]
         L.orc_grid_sampling.restype = C.c_size_t
         L.orc_grid_sampling.argtypes = [dp, C.c_size_t, C.c_double, C.POINTER(C.c_uint32)]
+        # robust-loss route (ctgn_oracle_robust.c)
+        L.orc_loss_evaluate.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp]
+        L.orc_ct_point_to_plane.argtypes = [dp, C.c_double, dp, dp, dp, C.c_double, dp, dp]
+        L.orc_robust_build.restype = C.c_size_t
+        L.orc_robust_build.argtypes = [C.c_void_p, dp, dp, dp, C.c_size_t, dp, C.POINTER(_RobustOpts), C.c_int, dp, dp,
+                                       dp, dp, dp, C.POINTER(C.c_int32)]
+        L.orc_robust_evaluate_fixed.restype = C.c_double
+        L.orc_robust_evaluate_fixed.argtypes = [dp, dp, dp, dp, dp, C.c_size_t, C.POINTER(_RobustOpts),
+                                                C.POINTER(_RobustPrior), dp, dp, dp]
+        L.orc_robust_solve_fixed.restype = C.c_int
+        L.orc_robust_solve_fixed.argtypes = [dp, dp, dp, dp, dp, C.c_size_t, C.POINTER(_RobustOpts),
+                                             C.POINTER(_RobustPrior), dp, C.c_int, C.POINTER(_LmReport)]
+        L.orc_register_robust.restype = C.c_int
+        L.orc_register_robust.argtypes = [C.c_void_p, dp, dp, dp, C.c_size_t, dp, dp, C.POINTER(_RobustOpts),
+                                          C.POINTER(_RobustPrior), C.c_int, C.POINTER(_Summary)]
         _lib = L
     return _lib
 
@@ -330,3 +366,138 @@ def alpha_timestamp(t, tb, te):
 
 def voxel_coord(p, size):
     return lib().orc_voxel_coord(float(p), float(size))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# robust-loss (CERES-profile) route — DoRegisterCeres, reference src/ct_icp/ct_icp.cpp:457-707
+# ---------------------------------------------------------------------------------------------------------------------
+LOSS = {"STANDARD": 0, "CAUCHY": 1, "HUBER": 2, "TOLERANT": 3, "TRUNCATED": 4}
+
+
+@dataclass
+class RobustOptions:
+    """Fields of ct_icp::CTICPOptions read by DoRegisterCeres (reference include/ct_icp/ct_icp.h:58-132); defaults
+    are the reference's."""
+    num_iters_icp: int = 5
+    min_number_neighbors: int = 20
+    max_number_neighbors: int = 20
+    debug_print: bool = False
+    max_num_residuals: int = -1
+    loss_function: str = "CAUCHY"
+    ls_max_num_iters: int = 1
+    num_closest_neighbors: int = 1
+    weight_alpha: float = 0.9
+    weight_neighborhood: float = 0.1
+    power_planarity: float = 2.0
+    max_dist_to_plane_ct_icp: float = 0.3
+    ls_sigma: float = 0.1
+    ls_tolerant_min_threshold: float = 0.05
+    threshold_orientation_norm: float = 1e-4
+    threshold_translation_norm: float = 1e-3
+
+    def c(self) -> _RobustOpts:
+        return _RobustOpts(self.num_iters_icp, self.min_number_neighbors, self.max_number_neighbors,
+                           int(self.debug_print), self.max_num_residuals, LOSS[self.loss_function],
+                           self.ls_max_num_iters, self.num_closest_neighbors, self.weight_alpha,
+                           self.weight_neighborhood, self.power_planarity, self.max_dist_to_plane_ct_icp,
+                           self.ls_sigma, self.ls_tolerant_min_threshold, self.threshold_orientation_norm,
+                           self.threshold_translation_norm)
+
+
+@dataclass
+class RobustPrior:
+    """PreviousFrameMotionModel terms of the CERES route (reference src/ct_icp/motion_model.cpp:12-61)."""
+    beta_location_consistency: float = 0.001
+    beta_constant_velocity: float = 0.001
+    beta_small_velocity: float = 0.0
+    beta_orientation_consistency: float = 0.0
+    previous_begin_tr: tuple = (0.0, 0.0, 0.0)
+    previous_end_tr: tuple = (0.0, 0.0, 0.0)
+    previous_end_quat: tuple = (0.0, 0.0, 0.0, 1.0)
+
+    def c(self) -> _RobustPrior:
+        p = _RobustPrior(self.beta_location_consistency, self.beta_constant_velocity, self.beta_small_velocity,
+                         self.beta_orientation_consistency)
+        for i in range(3):
+            p.previous_begin_tr[i] = float(self.previous_begin_tr[i])
+            p.previous_end_tr[i] = float(self.previous_end_tr[i])
+        for i in range(4):
+            p.previous_end_quat[i] = float(self.previous_end_quat[i])
+        return p
+
+
+def loss_evaluate(kind: str, sigma, tolerant_min, s):
+    rho = np.zeros(3)
+    lib().orc_loss_evaluate(LOSS[kind], float(sigma), float(tolerant_min), float(s), _dp(rho))
+    return rho
+
+
+def ct_point_to_plane(pose, alpha, raw, ref, normal, weight, jacobian=True):
+    pose, raw, ref, normal = _f64(pose).ravel(), _f64(raw), _f64(ref), _f64(normal)
+    r = np.zeros(1)
+    J = np.zeros(12)
+    lib().orc_ct_point_to_plane(_dp(pose), float(alpha), _dp(raw), _dp(ref), _dp(normal), float(weight), _dp(r),
+                                _dp(J) if jacobian else None)
+    return (r[0], J) if jacobian else r[0]
+
+
+def robust_build(m: Map, raw, world, t, t_begin_end, opts: RobustOptions, heap_mode=0):
+    """Residual blocks of one ICP iteration: dict(raw, ref, normal, weight, alpha, keypoint)."""
+    raw, world, t = _f64(raw).reshape(-1, 3), _f64(world).reshape(-1, 3), _f64(t).ravel()
+    cap = max(1, len(t) * opts.num_closest_neighbors)
+    out = dict(raw=np.zeros((cap, 3)), ref=np.zeros((cap, 3)), normal=np.zeros((cap, 3)), weight=np.zeros(cap),
+               alpha=np.zeros(cap), keypoint=np.zeros(cap, dtype=np.int32))
+    o = opts.c()
+    k = lib().orc_robust_build(m._h, _dp(raw), _dp(world), _dp(t), len(t), _dp(_f64(t_begin_end)), C.byref(o),
+                               heap_mode, _dp(out["raw"]), _dp(out["ref"]), _dp(out["normal"]), _dp(out["weight"]),
+                               _dp(out["alpha"]), out["keypoint"].ctypes.data_as(C.POINTER(C.c_int32)))
+    return {key: v[:k].copy() for key, v in out.items()}
+
+
+def _blocks(blocks):
+    return [_f64(blocks[k]) for k in ("raw", "ref", "normal", "weight", "alpha")]
+
+
+def robust_evaluate(blocks, opts: RobustOptions, prior: RobustPrior | None, pose, jacobian=True):
+    """cost (= 1/2 sum rho) and, optionally, the loss-corrected J^T J and J^T r at `pose`."""
+    raw, ref, normal, weight, alpha = _blocks(blocks)
+    o = opts.c()
+    p = prior.c() if prior is not None else None
+    H, g = np.zeros(144), np.zeros(12)
+    cost = lib().orc_robust_evaluate_fixed(_dp(raw), _dp(ref), _dp(normal), _dp(weight), _dp(alpha), len(weight),
+                                           C.byref(o), C.byref(p) if p is not None else None,
+                                           _dp(_f64(pose).ravel()), _dp(H) if jacobian else None,
+                                           _dp(g) if jacobian else None)
+    return (cost, H.reshape(12, 12), g) if jacobian else cost
+
+
+def robust_solve_fixed(blocks, opts: RobustOptions, prior: RobustPrior | None, pose, max_num_iterations):
+    """The inner ceres::Solve on fixed correspondences. Returns (pose, report dict)."""
+    raw, ref, normal, weight, alpha = _blocks(blocks)
+    o = opts.c()
+    p = prior.c() if prior is not None else None
+    pose = _f64(pose).ravel().copy()
+    rep = _LmReport()
+    term = lib().orc_robust_solve_fixed(_dp(raw), _dp(ref), _dp(normal), _dp(weight), _dp(alpha), len(weight),
+                                        C.byref(o), C.byref(p) if p is not None else None, _dp(pose),
+                                        int(max_num_iterations), C.byref(rep))
+    return pose, dict(termination=term, initial_cost=rep.initial_cost, final_cost=rep.final_cost,
+                      final_radius=rep.final_radius, iterations=rep.iterations,
+                      successful=rep.num_successful_steps, unsuccessful=rep.num_unsuccessful_steps)
+
+
+def register_robust(m: Map, raw, t, pose, t_begin_end, opts: RobustOptions, prior: RobustPrior | None = None,
+                    heap_mode=0):
+    """DoRegisterCeres (CONTINUOUS_TIME, POINT_TO_PLANE). Returns (pose, world, Summary)."""
+    raw, t = _f64(raw).reshape(-1, 3), _f64(t).ravel()
+    world = np.zeros_like(raw)
+    pose, tbe = _f64(pose).ravel().copy(), _f64(t_begin_end)
+    o = opts.c()
+    p = prior.c() if prior is not None else None
+    s = _Summary()
+    rc = lib().orc_register_robust(m._h, _dp(raw), _dp(world), _dp(t), len(t), _dp(pose), _dp(tbe), C.byref(o),
+                                   C.byref(p) if p is not None else None, heap_mode, C.byref(s))
+    if rc != 0:
+        raise ValueError(f"oracle: register_robust failed (rc={rc})")
+    return pose, world, Summary(bool(s.success), s.num_residuals_used, s.num_iters, s.last_step_norm,
+                                s.error_log.decode(), 0.0, 0.0, 0.0)
