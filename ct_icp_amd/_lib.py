@@ -17,7 +17,8 @@ CTGN_F32, CTGN_F64 = 0, 1
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY = -1, -2, -3, -4
-ERR_TIMESTAMP_RANGE, ERR_VOXEL_RANGE, ERR_UNSUPPORTED = -5, -6, -7
+ERR_TIMESTAMP_RANGE, ERR_VOXEL_RANGE, ERR_UNSUPPORTED, ERR_SOLVER = -5, -6, -7, -8
+LOSS = {"STANDARD": 0, "CAUCHY": 1, "HUBER": 2, "TOLERANT": 3, "TRUNCATED": 4}    # ct_icp::LEAST_SQUARES
 
 
 class CtgnError(RuntimeError):
@@ -53,6 +54,28 @@ class Summary(C.Structure):
                 ("last_step_norm", C.c_double), ("error_log", C.c_char * 256)]
 
 
+class RobustOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("num_iters_icp", "min_number_neighbors", "max_number_neighbors", "debug_print",
+                                         "max_num_residuals", "loss_function", "ls_max_num_iters",
+                                         "num_closest_neighbors")] + \
+               [(k, C.c_double) for k in ("weight_alpha", "weight_neighborhood", "power_planarity",
+                                          "max_dist_to_plane_ct_icp", "ls_sigma", "ls_tolerant_min_threshold",
+                                          "threshold_orientation_norm", "threshold_translation_norm")]
+
+
+class RobustPrior(C.Structure):
+    _fields_ = [("beta_location_consistency", C.c_double), ("beta_constant_velocity", C.c_double),
+                ("beta_small_velocity", C.c_double), ("beta_orientation_consistency", C.c_double),
+                ("previous_begin_tr", C.c_double * 3), ("previous_end_tr", C.c_double * 3),
+                ("previous_end_quat", C.c_double * 4)]
+
+
+class RobustReport(C.Structure):
+    _fields_ = [("cost", C.c_double), ("radius", C.c_double), ("diff_rot_deg", C.c_double), ("diff_trans", C.c_double),
+                ("num_residuals", C.c_int32), ("ls_iterations", C.c_int32), ("ls_accepted", C.c_int32),
+                ("converged", C.c_int32), ("JtJ", C.c_double * 144), ("Jtr", C.c_double * 12)]
+
+
 class View(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_bytes", C.c_size_t), ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
@@ -85,6 +108,12 @@ SYMBOLS = {
     "ctgn_transform_points": (C.c_int, [_H, View, View, C.c_size_t, _dp, _dp, C.c_void_p, C.c_size_t, C.c_int]),
     "ctgn_register": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
                                 C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_robust_options_default": (None, [C.POINTER(RobustOptions)]),
+    "ctgn_solve_robust": (C.c_int, [_H, _dp, _dp, C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.POINTER(Summary)]),
+    "ctgn_register_robust": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
+                                       C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.POINTER(Summary)]),
+    "ctgn_robust_get_report": (C.c_int, [_H, C.POINTER(RobustReport)]),
+    "ctgn_robust_get_blocks": (C.c_int, [_H, _dp, _dp, _dp, _dp, C.POINTER(C.c_int32), C.c_size_t]),
     "ctgn_gn_begin": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior)]),
     "ctgn_gn_accumulate": (C.c_int, [_H]),
     "ctgn_gn_system_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p)]),

@@ -15,6 +15,7 @@
 
 #include "ctgn_devmap.hpp"
 #include "ctgn_kernels.hpp"
+#include "ctgn_robust.hpp"
 
 using namespace ctgn;
 
@@ -93,6 +94,15 @@ struct ctgn_context {
     double acc_ms = 0.0;
     int acc_launches = 0;
 
+    // robust-loss route (ctgn_robust.hpp)
+    RobustState *d_rstate = nullptr;
+    RobustState *h_rstate = nullptr;    // pinned
+    double *d_rbuf = nullptr;           // (5 + 3 K) x rb_cap doubles
+    int *d_rrank = nullptr;
+    int rb_cap = 0, rb_k = 0;
+    RobustParams rprm{};
+    ctgn_robust_options r_opts{};
+
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
@@ -112,6 +122,7 @@ const char *status_str(ctgn_status s) {
         case CTGN_ERR_TIMESTAMP_RANGE: return "The timestamp cannot be interpolated between the two poses";
         case CTGN_ERR_VOXEL_RANGE: return "voxel coordinate out of range";
         case CTGN_ERR_UNSUPPORTED: return "unsupported configuration";
+        case CTGN_ERR_SOLVER: return "Error During Optimization";
     }
     return "unknown";
 }
@@ -313,7 +324,7 @@ int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
     return per_cu * h->num_cus;
 }
 
-ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter) {
+ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter, bool search_only = false) {
     KpView kv = kp_view(h);
     DebugView dv = dbg_view(h);
     EventPair *ev = nullptr;
@@ -329,6 +340,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
     }
     int grid;
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
+    if (search_only && (h->variant == 1 || !rows_ok))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the robust route needs the row kernel: voxel_neighborhood 1 or 2, <= 64 points per voxel");
     if (h->variant == 1 || !rows_ok) {
         const int ntiles = (h->n_kp + LANE_BLOCK - 1) / LANE_BLOCK;
         grid = std::max(1, std::min(ntiles, MAX_PARTIAL_BLOCKS));
@@ -345,6 +358,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter)
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
             ev = nullptr;
+            if (search_only) { grid = g1; return; }
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
             grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
             hipLaunchKernelGGL(k_residual_reduce, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm,
@@ -516,6 +530,10 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->h_pose_in) hipHostFree(h->h_pose_in);
         if (h->d_counters) hipFree(h->d_counters);
         if (h->d_prof) hipFree(h->d_prof);
+        if (h->d_rstate) hipFree(h->d_rstate);
+        if (h->h_rstate) hipHostFree(h->h_rstate);
+        if (h->d_rbuf) hipFree(h->d_rbuf);
+        if (h->d_rrank) hipFree(h->d_rrank);
         if (h->d_nnb) { hipFree(h->d_nnb); hipFree(h->d_normal); hipFree(h->d_a2d); hipFree(h->d_far); hipFree(h->d_used); }
         if (h->d_edit) hipFree(h->d_edit);
         if (h->h_edit) hipHostFree(h->h_edit);
@@ -953,6 +971,217 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t
     st = ctgn_solve(h, pose_io, tbe, opts, prior, summary);
     if (st != CTGN_OK) return st;
     return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
+}
+
+
+// ---------------------------------------------------------------------------------------- robust-loss route
+void ctgn_robust_options_default(ctgn_robust_options *o) {
+    if (!o) return;
+    o->num_iters_icp = 5;                 // reference include/ct_icp/ct_icp.h:58-132
+    o->min_number_neighbors = 20;
+    o->max_number_neighbors = 20;
+    o->debug_print = 0;
+    o->max_num_residuals = -1;
+    o->loss_function = CTGN_LOSS_CAUCHY;
+    o->ls_max_num_iters = 1;
+    o->num_closest_neighbors = 1;
+    o->weight_alpha = 0.9;
+    o->weight_neighborhood = 0.1;
+    o->power_planarity = 2.0;
+    o->max_dist_to_plane_ct_icp = 0.3;
+    o->ls_sigma = 0.1;
+    o->ls_tolerant_min_threshold = 0.05;
+    o->threshold_orientation_norm = 0.0001;
+    o->threshold_translation_norm = 0.001;
+}
+
+static ctgn_status ensure_robust(ctgn_handle h, int k) {
+    if (!h->d_rstate) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RobustState)));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_rstate), sizeof(RobustState), hipHostMallocDefault));
+        HIPCHK(h, hipMemsetAsync(h->d_rstate, 0, sizeof(RobustState), h->stream));
+    }
+    if (h->rb_cap < h->cap_kp || h->rb_k < k) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_rbuf) HIPCHK(h, hipFree(h->d_rbuf));
+        if (h->d_rrank) HIPCHK(h, hipFree(h->d_rrank));
+        h->d_rbuf = nullptr; h->d_rrank = nullptr; h->rb_cap = 0; h->rb_k = 0;
+        const size_t c = (size_t) std::max(h->cap_kp, 1);
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_rbuf), c * (5 + 3 * (size_t) k) * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_rrank), c * sizeof(int)));
+        h->rb_cap = (int) c;
+        h->rb_k = k;
+    }
+    return CTGN_OK;
+}
+
+static RobustBuf robust_buf(ctgn_handle h) {
+    RobustBuf b;
+    const size_t c = (size_t) h->rb_cap;
+    b.nx = h->d_rbuf; b.ny = h->d_rbuf + c; b.nz = h->d_rbuf + 2 * c; b.w = h->d_rbuf + 3 * c; b.alpha = h->d_rbuf + 4 * c;
+    b.ref = h->d_rbuf + 5 * c;
+    b.rank = h->d_rrank;
+    b.cap = c;
+    return b;
+}
+
+ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tbe[2], const ctgn_robust_options *o,
+                              const ctgn_robust_prior *prior, ctgn_summary *summary) {
+    NEED_DEVICE(h);
+    if (summary) std::memset(summary, 0, sizeof(*summary));
+    if (!pose_io || !tbe || !o) return CTGN_ERR_INVALID_ARGUMENT;
+    if (o->max_number_neighbors < 1 || o->max_number_neighbors > CTGN_MAX_NEIGHBORS)
+        return fail(h, CTGN_ERR_UNSUPPORTED, "max_number_neighbors must be in [1, 32]");
+    if (o->num_closest_neighbors < 1 || o->num_closest_neighbors > o->min_number_neighbors ||
+        o->num_closest_neighbors > o->max_number_neighbors)
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "num_closest_neighbors must be in [1, min(min_, max_number_neighbors)]");
+    if (o->loss_function < CTGN_LOSS_STANDARD || o->loss_function > CTGN_LOSS_TRUNCATED)
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "unknown loss_function");
+    const double wsum = std::fabs(o->weight_alpha) + std::fabs(o->weight_neighborhood);
+    if (!(wsum > 0.0))                                                    // CHECK at ct_icp.cpp:529
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "weight_alpha + weight_neighborhood must be > 0");
+    if (h->n_kp > 0 && !(tbe[0] <= h->t_min && h->t_max <= tbe[1]))
+        return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "keypoint timestamps must lie in [t_begin, t_end]");
+    const auto t0 = std::chrono::steady_clock::now();
+    ctgn_status st = ensure_robust(h, o->num_closest_neighbors);
+    if (st != CTGN_OK) return st;
+    h->r_opts = *o;
+    RobustParams &r = h->rprm;
+    r.min_nb = o->min_number_neighbors; r.max_nb = o->max_number_neighbors; r.num_closest = o->num_closest_neighbors;
+    r.max_res = o->max_num_residuals; r.loss = o->loss_function; r.ls_max_iters = std::max(0, o->ls_max_num_iters);
+    r.lambda_w = std::fabs(o->weight_alpha) / wsum; r.lambda_n = std::fabs(o->weight_neighborhood) / wsum;   // :525-532
+    r.power = o->power_planarity;
+    r.nbr_scale = o->max_dist_to_plane_ct_icp * o->min_number_neighbors;
+    r.sigma = o->ls_sigma; r.tol_min = o->ls_tolerant_min_threshold;
+    r.thr_rot_deg = o->threshold_orientation_norm; r.thr_trans = o->threshold_translation_norm;
+    r.has_prior = prior ? 1 : 0;
+    r.beta_loc = prior ? prior->beta_location_consistency : 0.0;
+    r.beta_vel = prior ? prior->beta_constant_velocity : 0.0;
+    r.beta_small = prior ? prior->beta_small_velocity : 0.0;
+    r.beta_orient = prior ? prior->beta_orientation_consistency : 0.0;
+    for (int c = 0; c < 3; ++c) { r.prev_b[c] = prior ? prior->previous_begin_tr[c] : 0.0; r.prev_e[c] = prior ? prior->previous_end_tr[c] : 0.0; }
+    for (int c = 0; c < 4; ++c) r.prev_q[c] = prior ? prior->previous_end_quat[c] : (c == 3 ? 1.0 : 0.0);
+    // the row kernel reads max_nb only
+    h->prm = GnParams{};
+    h->prm.min_nb = o->min_number_neighbors;
+    h->prm.max_nb = o->max_number_neighbors;
+
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
+    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);    // :476-477
+    hipLaunchKernelGGL(k_robust_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_loop_start, h->stream));
+    MapView mv;
+    st = make_map_view(h, -1.0, &mv);
+    if (st != CTGN_OK) return st;
+    const RobustBuf rb = robust_buf(h);
+    const KpView kv = kp_view(h);
+    const int n = h->n_kp;
+    const int grid_lane = std::max(1, std::min((n + 255) / 256, 2048));
+    const int grid_eval = std::max(1, std::min((n + EVAL_BLOCK - 1) / EVAL_BLOCK, h->res_grid_cap));
+    const bool saved_prof = h->profiling;
+    h->profiling = false;
+    for (int it = 0; st == CTGN_OK && it < o->num_iters_icp; ++it) {                     // :535
+        st = launch_accumulate(h, mv, false, true);                                      // transform_keypoints + neighbourhoods
+        if (st != CTGN_OK) break;
+        hipLaunchKernelGGL(k_robust_prepare, dim3(grid_lane), dim3(256), 0, h->stream, mv, kv, h->d_state, r, rb);
+        hipLaunchKernelGGL(k_robust_cap, dim3(1), dim3(CAP_BLOCK), 0, h->stream, h->d_state, h->d_rstate, r, rb, n);
+        for (int j = 0; j < std::max(1, r.ls_max_iters); ++j) {                          // ceres::Solve, :627
+            hipLaunchKernelGGL(k_robust_eval<true>, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
+                               h->d_partials);
+            hipLaunchKernelGGL(k_robust_step<0>, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
+                               h->d_rstate, r);
+            if (r.ls_max_iters == 0) break;
+            hipLaunchKernelGGL(k_robust_eval<false>, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
+                               h->d_partials);
+            hipLaunchKernelGGL(k_robust_step<1>, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
+                               h->d_rstate, r);
+        }
+        hipLaunchKernelGGL(k_robust_outer, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate, r);
+        if (hipGetLastError() != hipSuccess) st = fail(h, CTGN_ERR_HIP, "[HIP] robust kernel launch failed");
+    }
+    h->profiling = saved_prof;
+    if (st != CTGN_OK) { hipStreamSynchronize(h->stream); return st; }
+    if (n > 0) {                                                                          // :685 (not after a failure)
+        hipLaunchKernelGGL(k_transform, dim3(grid_lane), dim3(256), 0, h->stream, kv, h->d_state);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_rstate, h->d_rstate, sizeof(RobustState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const GnState &s = *h->h_state;
+    const RobustState &rs = *h->h_rstate;
+    if (rs.error) return fail(h, CTGN_ERR_SOLVER, "the inner solver reported an unusable solution");
+    for (int i = 0; i < 14; ++i) pose_io[i] = s.pose[i];
+    if (summary) {
+        summary->success = s.failed ? 0 : 1;
+        summary->num_residuals_used = rs.n_res;
+        summary->num_iters = rs.icp_iter;
+        summary->last_step_norm = rs.diff_trans;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, h->ev_loop_start, h->ev_loop_stop);
+        summary->duration_device_ms = ms;
+        summary->duration_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (s.failed) {
+            std::snprintf(summary->error_log, sizeof(summary->error_log),
+                          "[CT_ICP] Error : not enough keypoints selected in ct-icp !\n[CT_ICP] number_of_residuals : %d\n",
+                          rs.n_res);                                 // same text as ct_icp.cpp:614-615
+            if (o->debug_print) std::fputs(summary->error_log, stdout);
+        }
+    }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_register_robust(ctgn_handle h, ctgn_view raw, void *world_base, size_t world_stride, ctgn_dtype world_dtype,
+                                 ctgn_view ts, size_t n, double pose_io[14], const double tbe[2], const ctgn_robust_options *opts,
+                                 const ctgn_robust_prior *prior, ctgn_summary *summary) {
+    ctgn_view world{world_base, world_stride, world_dtype, 0};
+    ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
+    if (st != CTGN_OK) return st;
+    st = ctgn_solve_robust(h, pose_io, tbe, opts, prior, summary);
+    if (st != CTGN_OK) return st;
+    return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
+}
+
+ctgn_status ctgn_robust_get_report(ctgn_handle h, ctgn_robust_report *out) {
+    NEED_DEVICE(h);
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h->d_rstate) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_solve_robust was not called");
+    HIPCHK(h, hipMemcpyAsync(h->h_rstate, h->d_rstate, sizeof(RobustState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const RobustState &rs = *h->h_rstate;
+    out->cost = rs.x_cost; out->radius = rs.radius; out->diff_rot_deg = rs.diff_rot; out->diff_trans = rs.diff_trans;
+    out->num_residuals = rs.n_res; out->ls_iterations = rs.ls_iters_total; out->ls_accepted = rs.ls_accepted_total;
+    out->converged = rs.converged;
+    for (int i = 0; i < 144; ++i) out->JtJ[i] = rs.H[i];
+    for (int i = 0; i < 12; ++i) out->Jtr[i] = rs.g[i];
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_robust_get_blocks(ctgn_handle h, double *normal, double *weight, double *alpha, double *reference, int32_t *rank,
+                                   size_t n) {
+    NEED_DEVICE(h);
+    if (!h->d_rbuf || n > (size_t) h->n_kp) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no robust solve on this many keypoints");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const RobustBuf rb = robust_buf(h);
+    std::vector<double> tmp(n);
+    auto pull = [&](const double *src, double *dst, int comp, int ncomp) -> hipError_t {
+        hipError_t e = hipMemcpy(tmp.data(), src, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) for (size_t i = 0; i < n; ++i) dst[ncomp * i + comp] = tmp[i];
+        return e;
+    };
+    if (normal) { HIPCHK(h, pull(rb.nx, normal, 0, 3)); HIPCHK(h, pull(rb.ny, normal, 1, 3)); HIPCHK(h, pull(rb.nz, normal, 2, 3)); }
+    if (weight) HIPCHK(h, pull(rb.w, weight, 0, 1));
+    if (alpha) HIPCHK(h, pull(rb.alpha, alpha, 0, 1));
+    if (reference) {
+        const size_t ncap = (size_t) h->rprm.num_closest * rb.cap;
+        for (int c = 0; c < 3; ++c) HIPCHK(h, pull(rb.ref + c * ncap, reference, c, 3));
+    }
+    if (rank) HIPCHK(h, hipMemcpy(rank, rb.rank, n * sizeof(int), hipMemcpyDeviceToHost));
+    return CTGN_OK;
 }
 
 // ---------------------------------------------------------------------------------------- misc

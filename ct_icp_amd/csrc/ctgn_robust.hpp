@@ -1,0 +1,631 @@
+// ctgn_robust.hpp — robust-loss (CERES-profile) registration on the GPU: SURVEY.md section 8f row 4.
+//
+// Replaces CT_ICP_Registration::DoRegisterCeres (reference src/ct_icp/ct_icp.cpp:457-707) for
+// parametrization = CONTINUOUS_TIME, distance = POINT_TO_PLANE. Per ICP iteration:
+//   k_accumulate_rows   the same neighbour search as the GN route (ctgn_kernels.hpp)
+//   k_robust_prepare    lane per keypoint: normal + a2D + weight (:569-579), the num_closest_neighbors reference points
+//   k_robust_cap        max_num_residuals cap in keypoint order (:415-426), soft failure (:612-624), solver reset
+//   ls_max_num_iters x [ k_robust_eval<true>   residual + closed-form Jacobian + loss -> packed J^T J | J^T r | cost
+//                        k_robust_step<0>      regularisers (motion_model.cpp:12-61), Levenberg-Marquardt step, candidate
+//                        k_robust_eval<false>  cost at the candidate
+//                        k_robust_step<1> ]    accept / reject, trust-region radius
+//   k_robust_outer      normalise, ICP stop test (:640-667)
+// Everything stays on the device; the host enqueues the fixed worst-case sequence and the kernels turn into no-ops once
+// the device-side flags say the inner solve or the ICP loop is finished.
+//
+// The inner solver is Ceres' trust-region Levenberg-Marquardt minimiser restated (DESIGN.md section 9 lists what is
+// taken from Ceres' published algorithm and at which defaults); the derivative Ceres obtains by automatic differentiation is evaluated in closed form:
+// with R_b^T R_e = Exp(theta u) and R(a) = R_b Exp(a theta u),
+//     d p / d w_b = -[R raw]x + R [raw]x W_b R_b^T,    d p / d w_e = -R [raw]x W_e R_e^T,
+//     W = a u u^T + s (cos(psi) (I - u u^T) + sin(psi) [u]x),   s = sin(a theta/2) / sin(theta/2),
+//     psi_e = (1 - a) theta/2,  psi_b = -(1 + a) theta/2,
+// in the tangent of Ceres' EigenQuaternionParameterization (a left rotation by twice the tangent vector).
+#pragma once
+
+#include "ctgn_kernels.hpp"
+
+namespace ctgn {
+
+enum { LOSS_STANDARD = 0, LOSS_CAUCHY = 1, LOSS_HUBER = 2, LOSS_TOLERANT = 3, LOSS_TRUNCATED = 4 };
+
+struct RobustParams {
+    int min_nb, max_nb, num_closest, max_res, loss, ls_max_iters;
+    double lambda_w, lambda_n, power, nbr_scale;       // nbr_scale = max_dist_to_plane * min_number_neighbors
+    double sigma, tol_min;
+    double thr_rot_deg, thr_trans;
+    int has_prior;
+    double beta_loc, beta_vel, beta_small, beta_orient;
+    double prev_b[3], prev_e[3], prev_q[4];
+};
+
+struct PoseCtx {             // a begin|end pose with everything that depends on the pair only
+    double pose[14];
+    double theta, sin_theta;  // slerp constants (quaternion half-angle of the relative rotation)
+    int linear, negate;
+    double ux, uy, uz;        // axis of R_b^T R_e in the begin/end body frame
+};
+
+struct RobustState {
+    PoseCtx x, cand;
+    double prev[14];          // pose at the end of the previous ICP iteration (:500-501, :648-649)
+    double H[144], g[12], scale[12];
+    double x_cost, cand_cost, model_cost_change, radius, decrease_factor;
+    double diff_trans, diff_rot;
+    int have_scale, ls_iter, ls_done, ls_term, invalid, step_valid;
+    int ls_iters_total, ls_accepted_total;
+    int n_res;                // residual blocks of the current ICP iteration
+    int icp_iter;             // the reference's loop counter `iter` (:535) as ICPSummary::num_iters reports it
+    int error;                // the inner solver gave up (reference throws, :628-631)
+    int converged;
+};
+
+struct RobustBuf {            // per-keypoint output of k_robust_prepare, SoA with stride cap
+    double *nx, *ny, *nz, *w, *alpha;
+    double *ref;              // [3][num_closest][cap]
+    int *rank;                // k_robust_prepare: 1 valid / 0 not;  k_robust_cap: rank of the keypoint's first block, -1
+    size_t cap;
+};
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ Quat quat_mul(Quat a, Quat b) {       // Eigen a * b
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+            a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+
+__device__ inline void pose_ctx_prepare(PoseCtx &c) {
+    const Quat qb{c.pose[0], c.pose[1], c.pose[2], c.pose[3]}, qe{c.pose[7], c.pose[8], c.pose[9], c.pose[10]};
+    const SlerpPair sp = slerp_prepare(qb, qe);
+    c.theta = sp.theta; c.sin_theta = sp.sin_theta; c.linear = sp.linear; c.negate = sp.negate;
+    Quat qr = quat_mul(Quat{-qb.x, -qb.y, -qb.z, qb.w}, qe);
+    if (qr.w < 0) qr = Quat{-qr.x, -qr.y, -qr.z, -qr.w};
+    const double n = sqrt(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z);
+    if (sp.linear || !(n > 0)) { c.ux = 1.0; c.uy = 0.0; c.uz = 0.0; }
+    else { c.ux = qr.x / n; c.uy = qr.y / n; c.uz = qr.z / n; }
+}
+
+// EigenQuaternionParameterization::Plus on both quaternions + plain addition on the translations; tangent layout
+// [begin_quat | end_quat | begin_t | end_t] (the order of AddParameterBlocks, ct_icp.cpp:227-230)
+__device__ inline void quat_plus(const double *q, const double *d, double *out) {
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n == 0.0) { out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3]; return; }
+    const double k = sin(n) / n;
+    const Quat r = quat_mul(Quat{k * d[0], k * d[1], k * d[2], cos(n)}, Quat{q[0], q[1], q[2], q[3]});
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+__device__ inline void pose_plus(const double *pose, const double *delta, double *out) {
+    quat_plus(pose, delta, out);
+    quat_plus(pose + 7, delta + 3, out + 7);
+    for (int i = 0; i < 3; ++i) { out[4 + i] = pose[4 + i] + delta[6 + i]; out[11 + i] = pose[11 + i] + delta[9 + i]; }
+}
+
+// ceres::LossFunction::Evaluate for the five choices of ct_icp.cpp:170-187
+__device__ __forceinline__ void loss_evaluate(int kind, double sigma, double tol_min, double s, double rho[3]) {
+    switch (kind) {
+        case LOSS_CAUCHY: {
+            const double b = sigma * sigma, c = 1.0 / b, sum = 1.0 + s * c, inv = 1.0 / sum;
+            rho[0] = b * log(sum); rho[1] = fmax(DBL_MIN, inv); rho[2] = -c * (inv * inv);
+            return;
+        }
+        case LOSS_HUBER: {
+            const double b = sigma * sigma;
+            if (s > b) {
+                const double r = sqrt(s);
+                rho[0] = 2.0 * sigma * r - b; rho[1] = fmax(DBL_MIN, sigma / r); rho[2] = -rho[1] / (2.0 * s);
+            } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+            return;
+        }
+        case LOSS_TOLERANT: {
+            const double a = tol_min, b = sigma, c = b * log(1.0 + exp(-a / b)), x = (s - a) / b;
+            if (x > 36.7) { rho[0] = s - a - c; rho[1] = 1.0; rho[2] = 0.0; }
+            else {
+                const double ex = exp(x);
+                rho[0] = b * log(1.0 + ex) - c; rho[1] = fmax(DBL_MIN, ex / (1.0 + ex)); rho[2] = 0.5 / (b * (1.0 + cosh(x)));
+            }
+            return;
+        }
+        case LOSS_TRUNCATED: {
+            const double s2 = sigma * sigma;
+            if (s < s2) { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+            else { rho[0] = s2; rho[1] = 0.0; rho[2] = 0.0; }
+            return;
+        }
+        default: rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+}
+
+// CTFunctor<FunctorPointToPlane> (include/ct_icp/cost_functions.h:46-58,200-225): r = m . (ref - p(alpha)), m = weight * normal,
+// and (JAC) its 12 tangent partials in closed form.
+template <bool JAC>
+__device__ __forceinline__ double ct_residual(const PoseCtx &c, double alpha, Vec3 raw, Vec3 ref, Vec3 m, double *J) {
+    const Quat qb{c.pose[0], c.pose[1], c.pose[2], c.pose[3]}, qe{c.pose[7], c.pose[8], c.pose[9], c.pose[10]};
+    const SlerpPair sp{c.theta, c.sin_theta, c.linear, c.negate};
+    const Quat qi = quat_normalized(slerp_eval(qb, qe, sp, alpha));
+    const Vec3 a = quat_rotate(qi, raw);
+    const double oma = 1.0 - alpha;
+    const Vec3 p{a.x + (oma * c.pose[4] + alpha * c.pose[11]), a.y + (oma * c.pose[5] + alpha * c.pose[12]),
+                 a.z + (oma * c.pose[6] + alpha * c.pose[13])};
+    const double r = dot(m, ref - p);
+    if (JAC) {
+        const Vec3 mb = quat_rotate(Quat{-qi.x, -qi.y, -qi.z, qi.w}, m);      // normal in the interpolated body frame
+        const Vec3 cc = cross(mb, raw);
+        Vec3 wb, we;
+        if (c.linear) {
+            wb = alpha * cc; we = wb;
+        } else {
+            const Vec3 u{c.ux, c.uy, c.uz};
+            const double s = sin(alpha * c.theta) / c.sin_theta;
+            const double uc = dot(u, cc);
+            const Vec3 perp = cc - uc * u, uxc = cross(u, cc), ax = (alpha * uc) * u;
+            double sb, cb, se, ce;
+            sincos(-(1.0 + alpha) * c.theta, &sb, &cb);
+            sincos(oma * c.theta, &se, &ce);
+            wb = ax + s * (cb * perp - sb * uxc);        // W_b^T c
+            we = ax + s * (ce * perp - se * uxc);        // W_e^T c
+        }
+        const Vec3 jb = cross(a, m) + quat_rotate(qb, wb), je = quat_rotate(qe, we);
+        J[0] = -2.0 * jb.x; J[1] = -2.0 * jb.y; J[2] = -2.0 * jb.z;
+        J[3] = 2.0 * je.x; J[4] = 2.0 * je.y; J[5] = 2.0 * je.z;
+        J[6] = -oma * m.x; J[7] = -oma * m.y; J[8] = -oma * m.z;
+        J[9] = -alpha * m.x; J[10] = -alpha * m.y; J[11] = -alpha * m.z;
+    }
+    return r;
+}
+
+// ================================================================================================
+// k_robust_prepare — lane per keypoint (ct_icp.cpp:548-596 without the solver bookkeeping)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, const GnState *st, RobustParams prm, RobustBuf rb) {
+    if (st->done) return;
+    const char *pbase = reinterpret_cast<const char *>(map.blocks);
+    const uint32_t blk8 = (uint32_t) map.blk * 8u;
+    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < kp.n; k += gridDim.x * blockDim.x) {
+        const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) k * SEL_STRIDE);
+        uint32_t rec32[SEL_STRIDE];
+#pragma unroll
+        for (int q = 0; q < SEL_STRIDE / 4; ++q) {
+            const uint4 v4 = in4[q];
+            rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
+        }
+        const int n = min((int) rec32[0], KMAX);
+        Vec3 S{0, 0, 0}, q0{0, 0, 0};
+        Sym3 SS{0, 0, 0, 0, 0, 0};
+        // farthest-first, summed front to back like the GN route (neighborhood.h:236-240)
+#pragma unroll
+        for (int g = 0; g < KMAX / 8; ++g) {
+            if (8 * g < n) {
+                double gx[8], gy[8], gz[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t off = (8 * g + q < n) ? rec32[1 + 8 * g + q] : 0u;
+                    gx[q] = *reinterpret_cast<const double *>(pbase + off);
+                    gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
+                    gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
+                }
+                if (g == 0) q0 = Vec3{gx[0], gy[0], gz[0]};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (8 * g + q < n) {
+                        const double x = gx[q], y = gy[q], z = gz[q];
+                        S.x += x; S.y += y; S.z += z;
+                        SS.xx += x * x; SS.xy += x * y; SS.xz += x * z; SS.yy += y * y; SS.yz += y * z; SS.zz += z * z;
+                        if (8 * g + q < prm.num_closest) {                    // neighborhood.points[i], :585-595
+                            const size_t at = (size_t) (8 * g + q) * rb.cap + k;
+                            rb.ref[at] = x;
+                            rb.ref[(size_t) prm.num_closest * rb.cap + at] = y;
+                            rb.ref[(size_t) 2 * prm.num_closest * rb.cap + at] = z;
+                        }
+                    }
+                }
+            }
+        }
+        const bool valid = n >= prm.min_nb && n >= 5;                          // :566-567 ; neighborhood.h:227-230
+        Vec3 nrm{0, 0, 0};
+        double weight = 0.0;
+        if (valid) {
+            const double dn = (double) n;
+            const Vec3 mu{S.x / dn, S.y / dn, S.z / dn};
+            Sym3 C;
+            C.xx = SS.xx / dn - mu.x * mu.x; C.xy = SS.xy / dn - mu.x * mu.y; C.xz = SS.xz / dn - mu.x * mu.z;
+            C.yy = SS.yy / dn - mu.y * mu.y; C.yz = SS.yz / dn - mu.y * mu.z; C.zz = SS.zz / dn - mu.z * mu.z;
+            double a2d;
+            sym3_normal_a2d(C, nrm, a2d);       // :570-573 never flips: normal . (BeginTr - BeginTr) = 0
+            const Vec3 p{kp.wx[k], kp.wy[k], kp.wz[k]};
+            const Vec3 d = q0 - p;
+            weight = prm.lambda_w * pow(a2d, prm.power) + prm.lambda_n * exp(-sqrt(dot(d, d)) / prm.nbr_scale);   // :574-579
+        }
+        rb.nx[k] = nrm.x; rb.ny[k] = nrm.y; rb.nz[k] = nrm.z;
+        rb.w[k] = weight;
+        rb.alpha[k] = alpha_timestamp(kp.t[k], st->tbe[0], st->tbe[1]);         // :592
+        rb.rank[k] = valid ? 1 : 0;
+    }
+}
+
+// ================================================================================================
+// k_robust_cap — one block: rank of every valid keypoint's first residual block in index order, the
+// max_num_residuals cap (GetProblem, :415-426), the soft failure (:612-624) and the reset of the inner solver.
+// ================================================================================================
+constexpr int CAP_BLOCK = 1024;
+__global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustState *rs, RobustParams prm, RobustBuf rb, int n) {
+    __shared__ int s_cnt[CAP_BLOCK];
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const int chunk = (n + CAP_BLOCK - 1) / CAP_BLOCK;
+    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    int cnt = 0;
+    for (int k = lo; k < hi; ++k) cnt += rb.rank[k];
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < CAP_BLOCK; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
+        long long total = (long long) run * prm.num_closest;
+        if (prm.max_res > 0 && total > prm.max_res) total = prm.max_res;
+        rs->n_res = (int) total;
+        st->n_used = (int) total;
+        if (total < prm.min_nb) {                              // :612-624
+            st->failed = 1;
+            st->done = 1;
+        } else {                                               // a fresh ceres::Solve: new strategy, new scaling
+            for (int i = 0; i < 14; ++i) rs->x.pose[i] = st->pose[i];
+            pose_ctx_prepare(rs->x);
+            rs->radius = 1e4; rs->decrease_factor = 2.0;
+            rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
+        }
+    }
+    __syncthreads();
+    int run = s_cnt[tid];
+    for (int k = lo; k < hi; ++k) {
+        const int v = rb.rank[k];
+        rb.rank[k] = v ? run * prm.num_closest : -1;
+        run += v;
+    }
+}
+
+// ================================================================================================
+// k_robust_eval — lane per keypoint, its num_closest residual blocks in turn.
+//   FULL : residual + Jacobian at rs->x, loss + Triggs corrector (Ceres corrector.cc), packed J^T J | -J^T r | cost
+//   !FULL: cost at rs->cand
+// ================================================================================================
+constexpr int EVAL_BLOCK = 256;
+constexpr int EVAL_REC = 15;                 // 12 J | r | cost | pad (odd stride: conflict-free LDS writes)
+
+template <bool FULL>
+__global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnState *st, const RobustState *rs, RobustParams prm,
+                                                             RobustBuf rb, double *partials) {
+    __shared__ double s_rec[EVAL_BLOCK / 64][64 * EVAL_REC];
+    __shared__ double s_comb[EVAL_BLOCK / 64][SYS_N];
+    __shared__ PoseCtx s_ctx;
+    if (st->done || rs->ls_done) return;
+    if (!FULL && !rs->step_valid) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ctx = FULL ? rs->x : rs->cand;
+    __syncthreads();
+    double acc0 = 0.0, acc1 = 0.0;
+    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
+    int e1i = 0, e1j = 0, e1kind = 3;          // 0: product, 1: -J_i * r, 2: cost, 3: none
+    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
+    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; }
+    else if (lane + 64 == 90) { e1kind = 2; }
+    const int ntiles = (kp.n + EVAL_BLOCK - 1) / EVAL_BLOCK;
+    const size_t ncap = (size_t) prm.num_closest * rb.cap;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int k = tile * EVAL_BLOCK + tid;
+        int rank = -1;
+        Vec3 raw{0, 0, 0}, m{0, 0, 0};
+        double alpha = 0.0;
+        if (k < kp.n) {
+            rank = rb.rank[k];
+            if (rank >= 0) {
+                raw = Vec3{kp.rx[k], kp.ry[k], kp.rz[k]};
+                const double w = rb.w[k];
+                m = Vec3{w * rb.nx[k], w * rb.ny[k], w * rb.nz[k]};
+                alpha = rb.alpha[k];
+            }
+        }
+        for (int i = 0; i < prm.num_closest; ++i) {
+            const bool used = rank >= 0 && (prm.max_res <= 0 || rank + i < prm.max_res);
+            double J[12], r = 0.0, cost = 0.0;
+            if (used) {
+                const size_t at = (size_t) i * rb.cap + k;
+                const Vec3 ref{rb.ref[at], rb.ref[ncap + at], rb.ref[2 * ncap + at]};
+                r = ct_residual<FULL>(s_ctx, alpha, raw, ref, m, J);
+                const double s = r * r;
+                if (prm.loss == LOSS_STANDARD) {
+                    cost = 0.5 * s;
+                } else {
+                    double rho[3];
+                    loss_evaluate(prm.loss, prm.sigma, prm.tol_min, s, rho);
+                    cost = 0.5 * rho[0];
+                    if (FULL) {
+                        const double sqrt_rho1 = sqrt(rho[1]);
+                        double residual_scaling, alpha_sq_norm;
+                        if (s == 0.0 || rho[2] <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
+                        else {
+                            const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+                            const double al = 1.0 - sqrt(D);
+                            residual_scaling = sqrt_rho1 / (1.0 - al);
+                            alpha_sq_norm = al / s;
+                        }
+                        const double js = sqrt_rho1 * (1.0 - alpha_sq_norm * s);
+#pragma unroll
+                        for (int c = 0; c < 12; ++c) J[c] *= js;
+                        r *= residual_scaling;
+                    }
+                }
+            }
+            if (FULL) {
+                double *rec = s_rec[wave];
+                double *my = rec + lane * EVAL_REC;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) my[c] = used ? J[c] : 0.0;
+                my[12] = used ? r : 0.0;
+                my[13] = cost;
+                for (int j = 0; j < 64; ++j) {
+                    const double *rj = rec + j * EVAL_REC;
+                    acc0 += rj[e0i] * rj[e0j];
+                    if (e1kind == 0) acc1 += rj[e1i] * rj[e1j];
+                    else if (e1kind == 1) acc1 -= rj[e1i] * rj[12];
+                    else if (e1kind == 2) acc1 += rj[13];
+                }
+            } else {
+                acc1 += cost;                   // every lane: its own blocks
+            }
+        }
+    }
+    if (FULL) {
+        s_comb[wave][lane] = acc0;
+        if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+        __syncthreads();
+        if (tid < SYS_N) {
+            double s = 0.0;
+            for (int w = 0; w < EVAL_BLOCK / 64; ++w) s += s_comb[w][tid];
+            partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
+        }
+    } else {
+        const double s = wave_sum_fixed(acc1);
+        if (lane == 0) s_comb[wave][0] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < EVAL_BLOCK / 64; ++w) t += s_comb[w][0];
+            partials[(size_t) 90 * MAX_PARTIAL_BLOCKS + blockIdx.x] = t;
+        }
+    }
+}
+
+// regularisers of PreviousFrameMotionModel::AddConstraintsToCeresProblem (src/ct_icp/motion_model.cpp:12-61), no loss.
+// H (full 12x12) and g may be null (cost only).
+__device__ inline double robust_regularisers(const RobustParams &prm, int n_res, const double *pose, double *H, double *g) {
+    if (!prm.has_prior) return 0.0;
+    double cost = 0.0;
+    const double nres = (double) n_res;
+    const double *tb = pose + 4, *te = pose + 11;
+    if (prm.beta_loc > 0.) {                                          // :18-27
+        const double beta = sqrt(nres * prm.beta_loc);
+        for (int c = 0; c < 3; ++c) {
+            const double r = beta * (tb[c] - prm.prev_e[c]);
+            cost += 0.5 * r * r;
+            if (H) { H[13 * (6 + c)] += beta * beta; g[6 + c] += beta * r; }
+        }
+    }
+    if (prm.beta_orient > 0.) {                                       // :31-39
+        const double beta = sqrt(nres * prm.beta_orient);
+        const double sc = pose[0] * prm.prev_q[0] + pose[1] * prm.prev_q[1] + pose[2] * prm.prev_q[2] + pose[3] * prm.prev_q[3];
+        const double r = beta * (1.0 - sc * sc);
+        cost += 0.5 * r * r;
+        if (H) {
+            const double k = -2.0 * beta * sc;
+            const double ax = k * prm.prev_q[0], ay = k * prm.prev_q[1], az = k * prm.prev_q[2], aw = k * prm.prev_q[3];
+            const double x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+            // ambient gradient times the 4x3 Jacobian of Plus at zero
+            const double J[3] = {ax * w - ay * z + az * y - aw * x, ax * z + ay * w - az * x - aw * y,
+                                 -ax * y + ay * x + az * w - aw * z};
+            for (int i = 0; i < 3; ++i) {
+                g[i] += J[i] * r;
+                for (int j = 0; j < 3; ++j) H[12 * i + j] += J[i] * J[j];
+            }
+        }
+    }
+    if (prm.beta_vel > 0.) {                                          // :42-50
+        const double beta = sqrt(nres * prm.beta_vel);
+        for (int c = 0; c < 3; ++c) {
+            const double r = beta * (te[c] - tb[c] - (prm.prev_e[c] - prm.prev_b[c]));
+            cost += 0.5 * r * r;
+            if (H) {
+                const double b2 = beta * beta;
+                H[13 * (6 + c)] += b2; H[13 * (9 + c)] += b2;
+                H[12 * (6 + c) + 9 + c] -= b2; H[12 * (9 + c) + 6 + c] -= b2;
+                g[6 + c] -= beta * r; g[9 + c] += beta * r;
+            }
+        }
+    }
+    if (prm.beta_small > 0.) {                                        // :53-60
+        const double beta = sqrt(nres * prm.beta_small);
+        for (int c = 0; c < 3; ++c) {
+            const double r = beta * (tb[c] - te[c]);
+            cost += 0.5 * r * r;
+            if (H) {
+                const double b2 = beta * beta;
+                H[13 * (6 + c)] += b2; H[13 * (9 + c)] += b2;
+                H[12 * (6 + c) + 9 + c] -= b2; H[12 * (9 + c) + 6 + c] -= b2;
+                g[6 + c] += beta * r; g[9 + c] -= beta * r;
+            }
+        }
+    }
+    return cost;
+}
+
+// ================================================================================================
+// k_robust_step — one block.
+//   PHASE 0 (after k_robust_eval<true>):  reduce the partials, add the regularisers, run the checks of
+//            FinalizeIterationAndCheckIfMinimizerCanContinue, compute the Levenberg-Marquardt step and the candidate
+//   PHASE 1 (after k_robust_eval<false>): candidate cost, function tolerance, accept / reject, radius update
+// ================================================================================================
+constexpr int STEP_BLOCK = 1024;
+
+template <int PHASE>
+__global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partials, int nblocks, GnState *st, RobustState *rs,
+                                                             RobustParams prm) {
+    __shared__ double s_sys[SYS_N];
+    if (st->done || rs->ls_done) return;
+    if (PHASE == 1 && !rs->step_valid) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave w sums entries w, w + 16, ... over the blocks: lane-strided, then a fixed shuffle tree (deterministic)
+    for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
+        if (PHASE == 1 && e != 90) continue;
+        double acc = 0.0;
+        for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
+        acc = wave_sum_fixed(acc);
+        if (lane == 0) s_sys[e] = acc;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+
+    const double min_relative_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double max_radius = 1e16, min_radius = 1e-32;
+    if (PHASE == 0) {
+        double *H = rs->H, *g = rs->g;
+        for (int e = 0; e < 78; ++e) {
+            const int i = c_tri_i[e], j = c_tri_j[e];
+            H[12 * i + j] = s_sys[e];
+            H[12 * j + i] = s_sys[e];
+        }
+        for (int i = 0; i < 12; ++i) g[i] = -s_sys[78 + i];
+        double cost = s_sys[90];
+        cost += robust_regularisers(prm, rs->n_res, rs->x.pose, H, g);
+        rs->x_cost = cost;
+        if (!isfinite(cost)) { rs->error = 1; rs->ls_done = 1; st->done = 1; return; }
+        if (!rs->have_scale) {                          // jacobi_scaling: from the first Jacobian of the solve only
+            for (int i = 0; i < 12; ++i) rs->scale[i] = 1.0 / (1.0 + sqrt(H[13 * i]));
+            rs->have_scale = 1;
+        }
+        if (rs->ls_iter >= prm.ls_max_iters) { rs->ls_done = 1; rs->ls_term = 0; return; }
+        {   // gradient tolerance: max norm of x - Plus(x, -g)
+            double neg[12], moved[14], mx = 0.0;
+            for (int i = 0; i < 12; ++i) neg[i] = -g[i];
+            pose_plus(rs->x.pose, neg, moved);
+            for (int i = 0; i < 14; ++i) mx = fmax(mx, fabs(rs->x.pose[i] - moved[i]));
+            if (mx <= gradient_tolerance) { rs->ls_done = 1; rs->ls_term = 1; return; }
+        }
+        if (rs->radius < min_radius) { rs->ls_done = 1; rs->ls_term = 1; return; }
+        rs->ls_iter += 1;
+        rs->ls_iters_total += 1;
+        // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian
+        double A[144], Hs[144], gs[12], rhs[12], y[12];
+        const double *sc = rs->scale;
+        for (int i = 0; i < 12; ++i) {
+            gs[i] = sc[i] * g[i];
+            rhs[i] = -gs[i];
+            for (int j = 0; j < 12; ++j) { Hs[12 * i + j] = sc[i] * H[12 * i + j] * sc[j]; A[12 * i + j] = Hs[12 * i + j]; }
+        }
+        for (int i = 0; i < 12; ++i) A[13 * i] += fmin(fmax(Hs[13 * i], min_diag), max_diag) / rs->radius;
+        ldlt_solve12(A, rhs, y);
+        bool ok = true;
+        double yg = 0.0, yHy = 0.0;
+        for (int i = 0; i < 12; ++i) {
+            ok = ok && isfinite(y[i]);
+            yg += y[i] * gs[i];
+            double row = 0.0;
+            for (int j = 0; j < 12; ++j) row += Hs[12 * i + j] * y[j];
+            yHy += y[i] * row;
+        }
+        const double model_cost_change = -(yg + 0.5 * yHy);
+        ok = ok && model_cost_change > 0.0;
+        if (!ok) {                                      // HandleInvalidStep
+            rs->step_valid = 0;
+            if (++rs->invalid >= 5) { rs->error = 1; rs->ls_done = 1; st->done = 1; return; }
+            rs->radius *= 0.5;
+            return;
+        }
+        rs->invalid = 0;
+        rs->model_cost_change = model_cost_change;
+        double delta[12];
+        for (int i = 0; i < 12; ++i) delta[i] = y[i] * sc[i];
+        pose_plus(rs->x.pose, delta, rs->cand.pose);
+        pose_ctx_prepare(rs->cand);
+        rs->step_valid = 1;
+        double step2 = 0.0, x2 = 0.0;
+        for (int i = 0; i < 14; ++i) {
+            const double d = rs->x.pose[i] - rs->cand.pose[i];
+            step2 += d * d;
+            x2 += rs->x.pose[i] * rs->x.pose[i];
+        }
+        if (sqrt(step2) <= parameter_tolerance * (sqrt(x2) + parameter_tolerance)) { rs->ls_done = 1; rs->ls_term = 1; }
+    } else {
+        double cand_cost = s_sys[90];
+        cand_cost += robust_regularisers(prm, rs->n_res, rs->cand.pose, nullptr, nullptr);
+        rs->cand_cost = cand_cost;
+        const double cost_change = rs->x_cost - cand_cost;
+        if (fabs(cost_change) <= function_tolerance * rs->x_cost) { rs->ls_done = 1; rs->ls_term = 1; return; }
+        const double rd = cost_change / rs->model_cost_change;
+        if (isfinite(cand_cost) && rd > min_relative_decrease) {             // HandleSuccessfulStep
+            rs->x = rs->cand;
+            for (int i = 0; i < 14; ++i) st->pose[i] = rs->cand.pose[i];
+            st->slerp_theta = rs->cand.theta; st->slerp_sin = rs->cand.sin_theta;
+            st->slerp_linear = rs->cand.linear; st->slerp_negate = rs->cand.negate;
+            const double f = 1.0 - pow(2.0 * rd - 1.0, 3.0);
+            rs->radius = fmin(max_radius, rs->radius / fmax(1.0 / 3.0, f));
+            rs->decrease_factor = 2.0;
+            rs->ls_accepted_total += 1;
+            rs->x_cost = cand_cost;
+        } else {                                                             // StepRejected
+            rs->radius = rs->radius / rs->decrease_factor;
+            rs->decrease_factor *= 2.0;
+        }
+        rs->step_valid = 0;
+    }
+}
+
+// slam::AngularDistance (include/SlamCore/types.h:142-150), degrees
+__device__ inline double angular_distance_deg(const double *qa, const double *qb) {
+    double Ra[9], Rb[9];
+    quat_to_matrix(quat_normalized(Quat{qa[0], qa[1], qa[2], qa[3]}), Ra);
+    quat_to_matrix(quat_normalized(Quat{qb[0], qb[1], qb[2], qb[3]}), Rb);
+    double tr = 0.0;
+    for (int i = 0; i < 9; ++i) tr += Ra[i] * Rb[i];
+    double c = (tr - 1.0) / 2.0;
+    c = fmin(1.0, fmax(-1.0, c));
+    return acos(c) * (180.0 / M_PI);
+}
+
+// End of one ICP iteration (ct_icp.cpp:633-667): normalise, pose change since the previous iteration, stop test.
+__global__ void k_robust_outer(GnState *st, RobustState *rs, RobustParams prm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || st->done) return;
+    const Quat qb = quat_normalized(Quat{st->pose[0], st->pose[1], st->pose[2], st->pose[3]});
+    const Quat qe = quat_normalized(Quat{st->pose[7], st->pose[8], st->pose[9], st->pose[10]});
+    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
+    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
+    const SlerpPair sp = slerp_prepare(qb, qe);
+    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
+    double db = 0.0, de = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        db += (rs->prev[4 + c] - st->pose[4 + c]) * (rs->prev[4 + c] - st->pose[4 + c]);
+        de += (rs->prev[11 + c] - st->pose[11 + c]) * (rs->prev[11 + c] - st->pose[11 + c]);
+    }
+    const double diff_trans = sqrt(db) + sqrt(de);
+    const double diff_rot = angular_distance_deg(st->pose, rs->prev) + angular_distance_deg(st->pose + 7, rs->prev + 7);
+    for (int i = 0; i < 14; ++i) rs->prev[i] = st->pose[i];
+    rs->diff_trans = diff_trans; rs->diff_rot = diff_rot;
+    st->step_norm = diff_trans;
+    st->iter += 1;
+    if (diff_rot < prm.thr_rot_deg && diff_trans < prm.thr_trans) { rs->converged = 1; st->done = 1; }   // :662-667: break
+    else rs->icp_iter += 1;
+}
+
+__global__ void k_robust_init(const GnState *st, RobustState *rs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 14; ++i) { rs->prev[i] = st->pose[i]; rs->x.pose[i] = st->pose[i]; rs->cand.pose[i] = st->pose[i]; }
+    pose_ctx_prepare(rs->x);
+    rs->cand = rs->x;
+    rs->x_cost = 0.0; rs->cand_cost = 0.0; rs->model_cost_change = 0.0; rs->radius = 1e4; rs->decrease_factor = 2.0;
+    rs->diff_trans = 0.0; rs->diff_rot = 0.0;
+    rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
+    rs->ls_iters_total = 0; rs->ls_accepted_total = 0;
+    rs->n_res = 0; rs->icp_iter = 0; rs->error = 0; rs->converged = 0;
+    for (int i = 0; i < 144; ++i) rs->H[i] = 0.0;
+    for (int i = 0; i < 12; ++i) { rs->g[i] = 0.0; rs->scale[i] = 1.0; }
+}
+
+}  // namespace ctgn

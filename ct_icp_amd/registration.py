@@ -1,4 +1,4 @@
-"""CT_ICP_Registration — host-side mirror of ct_icp::CT_ICP_Registration for `solver: GN`
+"""CT_ICP_Registration — host-side mirror of ct_icp::CT_ICP_Registration for `solver: GN` and `solver: CERES`
 (reference include/ct_icp/ct_icp.h:171-215, src/ct_icp/ct_icp.cpp:998-1053). `Register` keeps the reference's
 argument order and in-place semantics: the TrajectoryFrame poses and the keypoints' world points are updated,
 an ICPSummary is returned. The work is done by libctgn (HIP, gfx950); nothing here computes on the CPU."""
@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 from .map import GpuVoxelMap
-from .types import GN, CTICPOptions, ICPSummary, PreviousFrameMotionModel, TrajectoryFrame, WPOINT3D_DTYPE
+from .types import CERES, GN, CTICPOptions, ICPSummary, PreviousFrameMotionModel, TrajectoryFrame, WPOINT3D_DTYPE
 
 
 def _view(arr: np.ndarray, offset: int = 0) -> L.View:
@@ -37,6 +37,33 @@ def _c_prior(motion_model) -> L.MotionPrior | None:
     return p
 
 
+def _c_robust_options(o: CTICPOptions) -> L.RobustOptions:
+    if o.parametrization != "CONTINUOUS_TIME" or o.distance != "POINT_TO_PLANE":
+        raise RuntimeError("the CERES route serves parametrization CONTINUOUS_TIME with distance POINT_TO_PLANE only")
+    return L.RobustOptions(o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors, int(o.debug_print),
+                           o.max_num_residuals, L.LOSS[o.loss_function], o.ls_max_num_iters, o.num_closest_neighbors,
+                           o.weight_alpha, o.weight_neighborhood, o.power_planarity, o.max_dist_to_plane_ct_icp, o.ls_sigma,
+                           o.ls_tolerant_min_threshold, o.threshold_orientation_norm, o.threshold_translation_norm)
+
+
+def _c_robust_prior(motion_model, continuous_time=True) -> L.RobustPrior | None:
+    # ct_icp.cpp:608-610: `_previous_frame && parametrization == CONTINUOUS_TIME`
+    if motion_model is None or not continuous_time or not isinstance(motion_model, PreviousFrameMotionModel):
+        return None
+    p = L.RobustPrior()
+    p.beta_location_consistency = motion_model.beta_location_consistency
+    p.beta_constant_velocity = motion_model.beta_constant_velocity
+    p.beta_small_velocity = motion_model.beta_small_velocity
+    p.beta_orientation_consistency = motion_model.beta_orientation_consistency
+    pf = motion_model.PreviousFrame()
+    for i in range(3):
+        p.previous_begin_tr[i] = float(pf.BeginTr()[i])
+        p.previous_end_tr[i] = float(pf.EndTr()[i])
+    for i in range(4):
+        p.previous_end_quat[i] = float(pf.EndQuat()[i])
+    return p
+
+
 def _summary(s: L.Summary) -> ICPSummary:
     return ICPSummary(success=bool(s.success), num_residuals_used=s.num_residuals_used, num_iters=s.num_iters,
                       error_log=s.error_log.decode(), duration_total=s.duration_total_ms * 1e-3,
@@ -55,8 +82,8 @@ class CT_ICP_Registration:
                  motion_model=None, strategy=None) -> ICPSummary:
         """keypoints: structured array of WPOINT3D_DTYPE (the vector<slam::WPoint3D> overload, ct_icp.cpp:1026-1037).
         `strategy` is accepted and ignored, as DoRegisterGaussNewton ignores it."""
-        if self._options.solver != GN:
-            raise RuntimeError("Unsupported Solver Type")        # ct_icp.cpp:1022 — only the GN arm lives here
+        if self._options.solver not in (GN, CERES):
+            raise RuntimeError("Unsupported Solver Type")        # ct_icp.cpp:1022 — the ROBUST arm does not live here
         if not isinstance(voxel_map, GpuVoxelMap):
             raise TypeError("Register needs a GpuVoxelMap (the GPU path has no other map backend)")
         if keypoints.dtype != WPOINT3D_DTYPE:
@@ -67,13 +94,15 @@ class CT_ICP_Registration:
         ts = L.View(keypoints.ctypes.data + 24, keypoints.strides[0] if n else 64, L.CTGN_F64, 0)
         pose = np.ascontiguousarray(trajectory_frame.pose14(), dtype=np.float64)
         tbe = np.array([trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp])
-        opts = _c_options(self._options)
-        prior = _c_prior(motion_model)
         s = L.Summary()
         dp = C.POINTER(C.c_double)
-        st = L.lib().ctgn_register(h, raw, keypoints.ctypes.data + 32, keypoints.strides[0] if n else 64, L.CTGN_F64, ts, n,
-                                   pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
-                                   C.byref(prior) if prior is not None else None, C.byref(s))
+        if self._options.solver == GN:
+            opts, prior, fn = _c_options(self._options), _c_prior(motion_model), L.lib().ctgn_register
+        else:
+            opts, prior, fn = _c_robust_options(self._options), _c_robust_prior(motion_model), L.lib().ctgn_register_robust
+        st = fn(h, raw, keypoints.ctypes.data + 32, keypoints.strides[0] if n else 64, L.CTGN_F64, ts, n,
+                pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                C.byref(prior) if prior is not None else None, C.byref(s))
         L.check(h, st)
         trajectory_frame.set_pose14(pose)
         return _summary(s)
@@ -135,6 +164,34 @@ class GnSolver:
                                 C.byref(prior) if prior is not None else None, C.byref(s))
         L.check(self._h, st)
         return pose, _summary(s), s
+
+    def solve_robust(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
+        """DoRegisterCeres on the resident keypoints (their world coordinates are ignored and rewritten)."""
+        pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        opts, prior, s = _c_robust_options(options), _c_robust_prior(motion_model), L.Summary()
+        dp = C.POINTER(C.c_double)
+        st = L.lib().ctgn_solve_robust(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                                       C.byref(prior) if prior is not None else None, C.byref(s))
+        L.check(self._h, st)
+        return pose, _summary(s), s
+
+    def robust_report(self) -> dict:
+        r = L.RobustReport()
+        L.check(self._h, L.lib().ctgn_robust_get_report(self._h, C.byref(r)))
+        return dict(cost=r.cost, radius=r.radius, diff_rot_deg=r.diff_rot_deg, diff_trans=r.diff_trans,
+                    num_residuals=r.num_residuals, ls_iterations=r.ls_iterations, ls_accepted=r.ls_accepted,
+                    converged=bool(r.converged), JtJ=np.array(r.JtJ).reshape(12, 12), Jtr=np.array(r.Jtr))
+
+    def robust_blocks(self) -> dict:
+        n = self._n
+        normal, weight, alpha, ref = np.zeros((n, 3)), np.zeros(n), np.zeros(n), np.zeros((n, 3))
+        rank = np.zeros(n, dtype=np.int32)
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_robust_get_blocks(self._h, normal.ctypes.data_as(dp), weight.ctypes.data_as(dp),
+                                                       alpha.ctypes.data_as(dp), ref.ctypes.data_as(dp),
+                                                       rank.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return dict(normal=normal, weight=weight, alpha=alpha, ref=ref, rank=rank)
 
     def world_points(self) -> np.ndarray:
         out = np.zeros((self._n, 3))

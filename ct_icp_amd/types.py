@@ -1,8 +1,8 @@
-"""Host-side mirror of the reference's API types on the GN path (same names, same meaning):
+"""Host-side mirror of the reference's API types on the registration path (same names, same meaning):
 
   slam::Pose / TPose<double>   include/SlamCore/types.h:161-274
   ct_icp::TrajectoryFrame      include/ct_icp/types.h:31-61
-  ct_icp::CTICPOptions         include/ct_icp/ct_icp.h:56-153   (every field kept; GN reads six of them)
+  ct_icp::CTICPOptions         include/ct_icp/ct_icp.h:56-153   (every field kept; GN reads six of them, CERES sixteen)
   ct_icp::ICPSummary           include/ct_icp/ct_icp.h:155-169
   slam::WPoint3D               include/SlamCore/types.h:35-60    (64-byte record, numpy structured dtype)
   PreviousFrameMotionModel     include/ct_icp/motion_model.h:35-80 (the part GN reads)
@@ -82,7 +82,7 @@ class CTICPOptions:
     num_iters_icp: int = 5
     parametrization: str = "CONTINUOUS_TIME"
     distance: str = "POINT_TO_PLANE"
-    solver: int = CERES                      # the reference's default; only GN is served by this package
+    solver: int = CERES                      # the reference's default; GN and CERES are served by this package
     max_num_residuals: int = -1
     min_num_residuals: int = 100
     weighting_scheme: str = "ALL"
@@ -122,9 +122,12 @@ class ICPSummary:
 
 @dataclass
 class PreviousFrameMotionModel:
-    """The part of ct_icp::PreviousFrameMotionModel GN reads (ct_icp.cpp:888-908)."""
+    """The part of ct_icp::PreviousFrameMotionModel the solvers read: GN the first two betas and the previous
+    translations (ct_icp.cpp:888-908), CERES all four and the previous end orientation (motion_model.cpp:12-61)."""
     beta_location_consistency: float = 0.001
     beta_constant_velocity: float = 0.001
+    beta_small_velocity: float = 0.0
+    beta_orientation_consistency: float = 0.0
     previous_frame: TrajectoryFrame = field(default_factory=TrajectoryFrame)
 
     def UpdateState(self, optimized_frame: TrajectoryFrame, frame_index: int = 0):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CTGN_ABI_VERSION 1
+#define CTGN_ABI_VERSION 2
 #define CTGN_MAX_RESOLUTIONS 8
 /* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
 #define CTGN_MIN_KEYPOINTS_USED 100
@@ -55,7 +55,9 @@ typedef enum {
                                       glog-CHECK-aborts here (include/SlamCore/types.h:456)           */
     CTGN_ERR_VOXEL_RANGE = -6,     /* voxel coordinate outside the int16 sweep range of the reference
                                       (`short kxx`, include/ct_icp/map.h:470-472)                     */
-    CTGN_ERR_UNSUPPORTED = -7
+    CTGN_ERR_UNSUPPORTED = -7,
+    CTGN_ERR_SOLVER = -8           /* robust route: the inner solver reports an unusable solution; the reference
+                                      throws std::runtime_error("Error During Optimization"), ct_icp.cpp:628-631 */
 } ctgn_status;
 
 typedef enum { CTGN_F32 = 0, CTGN_F64 = 1 } ctgn_dtype;
@@ -199,6 +201,82 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw_xyz, void *world_base, si
                           ctgn_dtype world_dtype, ctgn_view timestamps, size_t n, double pose_io[14],
                           const double t_begin_end[2], const ctgn_options *opts,
                           const ctgn_motion_prior *prior, ctgn_summary *summary);
+
+/* -------------------------------------------------------------------------------------------------
+ * Robust-loss (CERES-profile) route — SURVEY.md section 8f row 4.
+ * Replaces CT_ICP_Registration::DoRegisterCeres (reference src/ct_icp/ct_icp.cpp:457-707) for
+ * parametrization = CONTINUOUS_TIME and distance = POINT_TO_PLANE, the configuration of every shipped config
+ * (`solver: CERES`, config/odometry/driving_config.yaml:52-89): same neighbour search kernel as the GN route, then
+ * planarity / neighbourhood weights (:525-532,574-579), the robust loss (:170-187), the max_num_residuals cap
+ * (:415-426), the PreviousFrameMotionModel regularisers (src/ct_icp/motion_model.cpp:12-61) and an on-device
+ * restatement of Ceres' Levenberg-Marquardt trust-region minimiser (ls_max_num_iters iterations per ICP iteration).
+ * Equivalence with a Ceres build is algorithmic, not bit-exact: Ceres is a third-party dependency absent from the
+ * reference tree.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {                           /* ct_icp::LEAST_SQUARES, include/ct_icp/ct_icp.h:41-47 */
+    CTGN_LOSS_STANDARD = 0, CTGN_LOSS_CAUCHY = 1, CTGN_LOSS_HUBER = 2, CTGN_LOSS_TOLERANT = 3, CTGN_LOSS_TRUNCATED = 4
+} ctgn_loss;
+
+typedef struct {                         /* CTICPOptions fields read by DoRegisterCeres (ct_icp.h:58-132) */
+    int32_t num_iters_icp;               /* default 5                                                     */
+    int32_t min_number_neighbors;        /* default 20; also the soft-failure bound on the residual count  */
+    int32_t max_number_neighbors;        /* default 20 (INeighborStrategyOptions::max_num_neighbors)       */
+    int32_t debug_print;
+    int32_t max_num_residuals;           /* default -1 = no cap                                            */
+    int32_t loss_function;               /* ctgn_loss, default CAUCHY                                      */
+    int32_t ls_max_num_iters;            /* default 1                                                      */
+    int32_t num_closest_neighbors;       /* default 1, <= min_number_neighbors                             */
+    double weight_alpha;                 /* default 0.9                                                    */
+    double weight_neighborhood;          /* default 0.1                                                    */
+    double power_planarity;              /* default 2.0                                                    */
+    double max_dist_to_plane_ct_icp;     /* default 0.3 (scale of the neighbourhood weight only)           */
+    double ls_sigma;                     /* default 0.1                                                    */
+    double ls_tolerant_min_threshold;    /* default 0.05                                                   */
+    double threshold_orientation_norm;   /* default 1e-4, DEGREES on this route (ct_icp.cpp:645-646,662)   */
+    double threshold_translation_norm;   /* default 1e-3                                                   */
+} ctgn_robust_options;
+
+void ctgn_robust_options_default(ctgn_robust_options *opts);
+
+typedef struct {                         /* PreviousFrameMotionModel::Options + previous frame (motion_model.h:42-58) */
+    double beta_location_consistency;    /* default 0.001 */
+    double beta_constant_velocity;       /* default 0.001 */
+    double beta_small_velocity;          /* default 0     */
+    double beta_orientation_consistency; /* default 0     */
+    double previous_begin_tr[3];         /* PreviousFrame().BeginTr()  */
+    double previous_end_tr[3];           /* PreviousFrame().EndTr()    */
+    double previous_end_quat[4];         /* PreviousFrame().EndQuat()  */
+} ctgn_robust_prior;
+
+/* Run the robust ICP loop on the resident keypoints (ctgn_set_keypoints; their world coordinates are ignored and
+ * overwritten: the reference re-derives them from the poses at the top of every iteration, ct_icp.cpp:499-515,537).
+ * summary->num_residuals_used = residual blocks of the last iteration; a residual count below
+ * min_number_neighbors is the reference's soft failure (success = 0, same error_log text as :612-618). */
+ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double t_begin_end[2],
+                              const ctgn_robust_options *opts, const ctgn_robust_prior *prior, ctgn_summary *summary);
+/* One-shot drop-in for `case CERES:` of SELECT_SOLVER (ct_icp.cpp:1003-1007). */
+ctgn_status ctgn_register_robust(ctgn_handle h, ctgn_view raw_xyz, void *world_base, size_t world_stride_bytes,
+                                 ctgn_dtype world_dtype, ctgn_view timestamps, size_t n, double pose_io[14],
+                                 const double t_begin_end[2], const ctgn_robust_options *opts,
+                                 const ctgn_robust_prior *prior, ctgn_summary *summary);
+
+typedef struct {                         /* state of the last ctgn_solve_robust (tests / diagnostics) */
+    double cost;                         /* 1/2 sum rho(r^2) + regularisers at the last evaluated pose          */
+    double radius;                       /* trust-region radius of the last inner solve                        */
+    double diff_rot_deg, diff_trans;     /* pose change of the last ICP iteration (the stop test's inputs)     */
+    int32_t num_residuals;               /* residual blocks of the last ICP iteration                          */
+    int32_t ls_iterations;               /* Levenberg-Marquardt iterations over all ICP iterations             */
+    int32_t ls_accepted;                 /* of which accepted                                                  */
+    int32_t converged;                   /* the ICP stop test fired                                            */
+    double JtJ[144];                     /* loss-corrected normal equations of the last evaluation, row-major, */
+    double Jtr[12];                      /* tangent order: begin_quat | end_quat | begin_t | end_t             */
+} ctgn_robust_report;
+ctgn_status ctgn_robust_get_report(ctgn_handle h, ctgn_robust_report *out);
+/* Residual blocks of the last ICP iteration, per keypoint (any pointer may be NULL): normal[3n], weight[n], alpha[n],
+ * reference[3n] (the first of the num_closest_neighbors points), rank[n] (index of the keypoint's first block in the
+ * problem, -1 = no block). */
+ctgn_status ctgn_robust_get_blocks(ctgn_handle h, double *normal, double *weight, double *alpha, double *reference,
+                                   int32_t *rank, size_t n);
 
 /* -------------------------------------------------------------------------------------------------
  * Stepwise GN (for the keypoint-sharded multi-GPU mode: one all-reduce of the packed system between

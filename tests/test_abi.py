@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ctgn.h but not exported by libctgn.so"
     assert set(declared) == set(L.SYMBOLS), set(declared) ^ set(L.SYMBOLS)
-    assert lib.ctgn_abi_version() == 1
+    assert lib.ctgn_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(tmp_path):
@@ -92,5 +92,16 @@ def test_invalid_options_are_rejected():
         cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(-1.0, 0.1, 20)], device=-1))
     with pytest.raises(RuntimeError, match="Unsupported Solver Type"):
         m = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(device=-1))
+        cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.ROBUST)).Register(
+            m, np.zeros(0, dtype=cia.WPOINT3D_DTYPE), cia.TrajectoryFrame())
+
+
+def test_robust_route_fails_loudly_without_a_device():
+    m = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(device=-1))
+    with pytest.raises(cia.CtgnError) as e:
         cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.CERES)).Register(
+            m, np.zeros(0, dtype=cia.WPOINT3D_DTYPE), cia.TrajectoryFrame())
+    assert e.value.status == L.ERR_NO_DEVICE
+    with pytest.raises(RuntimeError, match="CONTINUOUS_TIME"):
+        cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.CERES, distance="POINT_TO_POINT")).Register(
             m, np.zeros(0, dtype=cia.WPOINT3D_DTYPE), cia.TrajectoryFrame())

@@ -1,0 +1,181 @@
+"""GPU parity tests of the robust-loss (CERES-profile) route: ctgn_solve_robust / ctgn_register_robust
+through the C ABI against oracle/ctgn_oracle_robust.c on the same seeded inputs.
+
+The two sides share no arithmetic for the derivative (closed form on the GPU, forward-mode jets in the oracle), the
+12x12 solve (pivoted LDL^T vs Cholesky) or the reductions (fixed block tree vs serial), so agreement is FP64 round-off
+amplified by the conditioning of the normal equations: asserted at 1e-8 .. 1e-6, far inside the contractual
+1e-4 m / 1e-4 rad."""
+import numpy as np
+import pytest
+
+import ct_icp_amd as cia
+from ct_icp_amd import _lib as L
+from ct_icp_amd import se3, synthetic as syn
+from oracle import oracle as orc
+from conftest import build_maps
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(case, frame, voxel, n_map=None, perturb=(0.004, 0.04), seed=3):
+    om, gm = build_maps(case, n_map if n_map is not None else frame, with_gpu=True)
+    sc = case["scans"][frame]
+    sel = syn.grid_sample_indices(sc.raw, voxel)
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, perturb[0], perturb[1], seed=seed)
+    return om, gm, sc, raw, t, pose0
+
+
+def _opts(**kw):
+    d = dict(solver=cia.CERES, debug_print=False, min_number_neighbors=10)
+    d.update(kw)
+    return cia.CTICPOptions(**d)
+
+
+def _oopts(o: cia.CTICPOptions):
+    return orc.RobustOptions(o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors, False, o.max_num_residuals,
+                             o.loss_function, o.ls_max_num_iters, o.num_closest_neighbors, o.weight_alpha, o.weight_neighborhood,
+                             o.power_planarity, o.max_dist_to_plane_ct_icp, o.ls_sigma, o.ls_tolerant_min_threshold,
+                             o.threshold_orientation_norm, o.threshold_translation_norm)
+
+
+def _priors(case, frame, **betas):
+    k = case["knots"]
+    mm = cia.PreviousFrameMotionModel(**betas)
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([k[frame - 1], k[frame]]), 0.0, 0.0)
+    op = orc.RobustPrior(previous_begin_tr=tuple(k[frame - 1, 4:7]), previous_end_tr=tuple(k[frame, 4:7]),
+                         previous_end_quat=tuple(k[frame, 0:4]),
+                         beta_location_consistency=mm.beta_location_consistency,
+                         beta_constant_velocity=mm.beta_constant_velocity, beta_small_velocity=mm.beta_small_velocity,
+                         beta_orientation_consistency=mm.beta_orientation_consistency)
+    return mm, op
+
+
+@pytest.mark.parametrize("case_name,voxel,loss", [("box_case", 0.4, "CAUCHY"), ("street_case", 0.6, "HUBER"),
+                                                  ("box_case", 0.5, "TOLERANT"), ("street_case", 0.8, "TRUNCATED"),
+                                                  ("box_case", 0.5, "STANDARD")])
+def test_blocks_and_normal_equations_match_oracle(case_name, voxel, loss, request):
+    """One ICP iteration with a zero-iteration inner solve = Ceres' "iteration 0": blocks, weights, cost, J^T J, J^T r."""
+    case = request.getfixturevalue(case_name)
+    om, gm, sc, raw, t, pose0 = _setup(case, 5, voxel)
+    mm, op = _priors(case, 5, beta_small_velocity=0.002, beta_orientation_consistency=0.003)
+    o = _opts(num_iters_icp=1, ls_max_num_iters=0, loss_function=loss, ls_sigma=0.08, ls_tolerant_min_threshold=0.02)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, np.zeros_like(raw), t)
+    pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o, mm)
+    q0 = pose0.copy()
+    q0[0:4] /= np.linalg.norm(q0[0:4]); q0[7:11] /= np.linalg.norm(q0[7:11])
+    assert np.allclose(pose1, q0, atol=1e-15)                              # no inner iteration: pose untouched
+    world = orc.transform_points(q0, sc.t_begin_end, t, raw)
+    assert np.abs(s.world_points() - world).max() < 1e-12
+    want = orc.robust_build(om, raw, world, t, sc.t_begin_end, _oopts(o), heap_mode=1)
+    got = s.robust_blocks()
+    kp = want["keypoint"]
+    assert len(kp) > 400 and summ.num_residuals_used == len(kp)
+    valid = got["rank"] >= 0
+    assert np.array_equal(np.nonzero(valid)[0], kp)
+    assert np.array_equal(got["rank"][kp], np.arange(len(kp)))
+    assert np.array_equal(got["ref"][kp], want["ref"])                      # bit-exact neighbour sets
+    assert np.array_equal(got["alpha"][kp], want["alpha"])
+    assert np.abs(got["weight"][kp] - want["weight"]).max() < 1e-9
+    sign = np.sign(np.sum(got["normal"][kp] * want["normal"], axis=1))
+    planar = want["weight"] > 0.1
+    assert np.abs(got["normal"][kp][planar] * sign[planar, None] - want["normal"][planar]).max() < 1e-7
+    cost, H, g = orc.robust_evaluate(want, _oopts(o), op, q0)
+    rep = s.robust_report()
+    assert abs(rep["cost"] - cost) < 1e-9 * cost
+    assert np.abs(rep["JtJ"] - H).max() < 1e-8 * np.abs(H).max()
+    assert np.abs(rep["Jtr"] - g).max() < 1e-8 * np.abs(g).max()
+
+
+@pytest.mark.parametrize("ls_iters", [1, 3, 6])
+def test_inner_solve_matches_oracle(box_case, ls_iters):
+    """One ICP iteration, ls_max_num_iters Levenberg-Marquardt iterations on fixed correspondences."""
+    case = box_case
+    om, gm, sc, raw, t, pose0 = _setup(case, 5, 0.4)
+    mm, op = _priors(case, 5)
+    o = _opts(num_iters_icp=1, ls_max_num_iters=ls_iters, ls_sigma=0.05)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, np.zeros_like(raw), t)
+    pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o, mm)
+    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    tr, rot = se3.pose_error(pose1, pose_o)
+    assert tr < 1e-8 and rot < 1e-8, (tr, rot)
+    assert summ.success and so.success and summ.num_residuals_used == so.num_residuals_used
+    assert summ.num_iters == so.num_iters
+    assert np.abs(s.world_points() - world_o).max() < 1e-7
+    rep = s.robust_report()
+    assert 1 <= rep["ls_iterations"] <= ls_iters and rep["ls_accepted"] >= 1
+    # the solve made progress towards the ground truth
+    assert se3.pose_error(pose1, sc.pose_gt)[0] < se3.pose_error(pose0, sc.pose_gt)[0]
+
+
+@pytest.mark.parametrize("case_name,voxel,loss,prior", [("box_case", 0.4, "CAUCHY", True), ("box_case", 0.5, "HUBER", False),
+                                                        ("street_case", 0.6, "CAUCHY", False),
+                                                        ("box_case", 0.5, "TRUNCATED", True),
+                                                        ("box_case", 0.6, "TOLERANT", False)])
+def test_register_robust_matches_oracle(case_name, voxel, loss, prior, request):
+    case = request.getfixturevalue(case_name)
+    om, gm, sc, raw, t, pose0 = _setup(case, 5, voxel)
+    mm, op = _priors(case, 5) if prior else (None, None)
+    o = _opts(num_iters_icp=8, ls_max_num_iters=5, loss_function=loss, ls_sigma=0.1, ls_tolerant_min_threshold=0.01,
+              threshold_orientation_norm=1e-3, threshold_translation_norm=1e-4)
+    kp = np.zeros(len(t), dtype=cia.WPOINT3D_DTYPE)
+    kp["raw_point"], kp["t"] = raw, t
+    frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+    summ = cia.CT_ICP_Registration(o).Register(gm, kp, frame, mm)
+    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    tr, rot = se3.pose_error(frame.pose14(), pose_o)
+    assert summ.success and so.success
+    assert tr < 1e-6 and rot < 1e-6, (tr, rot)
+    assert summ.num_iters == so.num_iters and summ.num_residuals_used == so.num_residuals_used
+    assert np.abs(kp["world_point"] - world_o).max() < 1e-5
+    if case_name == "box_case" and loss != "TOLERANT":
+        tr_gt, rot_gt = se3.pose_error(frame.pose14(), sc.pose_gt)
+        tr0, _ = se3.pose_error(pose0, sc.pose_gt)
+        assert tr_gt < 0.5 * tr0 and tr_gt < 0.02, (tr_gt, tr0)
+
+
+def test_residual_cap_and_several_closest_neighbors(box_case):
+    case = box_case
+    om, gm, sc, raw, t, pose0 = _setup(case, 5, 0.4)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, np.zeros_like(raw), t)
+    for kw in (dict(max_num_residuals=300), dict(num_closest_neighbors=3), dict(num_closest_neighbors=2, max_num_residuals=501)):
+        o = _opts(num_iters_icp=2, ls_max_num_iters=3, **kw)
+        pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o)
+        pose_o, _, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+        assert summ.num_residuals_used == so.num_residuals_used
+        if "max_num_residuals" in kw:
+            assert summ.num_residuals_used == kw["max_num_residuals"]
+        tr, rot = se3.pose_error(pose1, pose_o)
+        assert tr < 1e-7 and rot < 1e-7, (kw, tr, rot)
+
+
+def test_soft_failure_and_errors(box_case):
+    case = box_case
+    om, gm, sc, raw, t, pose0 = _setup(case, 5, 0.5)
+    s = cia.GnSolver(gm)
+    far = raw[:40] * 50.0                                                  # nothing of the map near these
+    s.set_keypoints(far, np.zeros_like(far), t[:40])
+    o = _opts(num_iters_icp=3, ls_max_num_iters=2)
+    pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o)
+    _, _, so = orc.register_robust(om, far, t[:40], pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+    assert not summ.success and not so.success
+    assert summ.error_log == so.error_log and "not enough keypoints" in summ.error_log
+    assert summ.num_residuals_used == so.num_residuals_used
+    # a timestamp outside the frame: error instead of the reference's CHECK abort
+    t_bad = t[:40].copy()
+    t_bad[7] = sc.t_begin_end[1] + 1.0
+    s.set_keypoints(raw[:40], np.zeros((40, 3)), t_bad)
+    with pytest.raises(cia.CtgnError) as e:
+        s.solve_robust(pose0, sc.t_begin_end, o)
+    assert e.value.status == L.ERR_TIMESTAMP_RANGE
+    s.set_keypoints(raw[:40], np.zeros((40, 3)), t[:40])
+    with pytest.raises(cia.CtgnError) as e:
+        s.solve_robust(pose0, sc.t_begin_end, _opts(num_closest_neighbors=15, min_number_neighbors=10))
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    # and the GN route still works on the same handle afterwards
+    s.set_keypoints(raw, se3.ct_transform(pose0, sc.t_begin_end, t, raw), t)
+    _, sg, _ = s.solve(pose0, sc.t_begin_end, cia.CTICPOptions(solver=cia.GN, debug_print=False, min_number_neighbors=10))
+    assert sg.success
