@@ -73,7 +73,8 @@ class RobustPrior(C.Structure):
 class RobustReport(C.Structure):
     _fields_ = [("cost", C.c_double), ("radius", C.c_double), ("diff_rot_deg", C.c_double), ("diff_trans", C.c_double),
                 ("num_residuals", C.c_int32), ("ls_iterations", C.c_int32), ("ls_accepted", C.c_int32),
-                ("converged", C.c_int32), ("JtJ", C.c_double * 144), ("Jtr", C.c_double * 12)]
+                ("converged", C.c_int32), ("JtJ", C.c_double * 144), ("Jtr", C.c_double * 12),
+                ("step_cycles", C.c_uint64 * 8)]
 
 
 class View(C.Structure):

@@ -1158,6 +1158,7 @@ ctgn_status ctgn_robust_get_report(ctgn_handle h, ctgn_robust_report *out) {
     out->converged = rs.converged;
     for (int i = 0; i < 144; ++i) out->JtJ[i] = rs.H[i];
     for (int i = 0; i < 12; ++i) out->Jtr[i] = rs.g[i];
+    for (int i = 0; i < 8; ++i) out->step_cycles[i] = rs.step_cycles[i];
     return CTGN_OK;
 }
 

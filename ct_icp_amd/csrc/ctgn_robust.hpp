@@ -57,6 +57,7 @@ struct RobustState {
     int icp_iter;             // the reference's loop counter `iter` (:535) as ICPSummary::num_iters reports it
     int error;                // the inner solver gave up (reference throws, :628-631)
     int converged;
+    unsigned long long step_cycles[8];   // shader clocks of the last k_robust_step<0>: stage-in+reduce | control | scale | solve | candidate | write-back
 };
 
 struct RobustBuf {            // per-keypoint output of k_robust_prepare, SoA with stride cap
@@ -247,19 +248,27 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
 // ================================================================================================
 constexpr int CAP_BLOCK = 1024;
 __global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustState *rs, RobustParams prm, RobustBuf rb, int n) {
-    __shared__ int s_cnt[CAP_BLOCK];
     if (st->done) return;
     const int tid = threadIdx.x;
     const int chunk = (n + CAP_BLOCK - 1) / CAP_BLOCK;
     const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
     int cnt = 0;
     for (int k = lo; k < hi; ++k) cnt += rb.rank[k];
-    s_cnt[tid] = cnt;
+    // exclusive scan of the 1024 chunk counts: shuffle scan inside each wave, then the 16 wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __shared__ int s_wave[CAP_BLOCK / 64];
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
+    int base = 0, all = 0;
+    for (int w = 0; w < CAP_BLOCK / 64; ++w) { const int v = s_wave[w]; if (w < wave) base += v; all += v; }
+    int run = base + incl - cnt;
     if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < CAP_BLOCK; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
-        long long total = (long long) run * prm.num_closest;
+        long long total = (long long) all * prm.num_closest;
         if (prm.max_res > 0 && total > prm.max_res) total = prm.max_res;
         rs->n_res = (int) total;
         st->n_used = (int) total;
@@ -267,14 +276,14 @@ __global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustSta
             st->failed = 1;
             st->done = 1;
         } else {                                               // a fresh ceres::Solve: new strategy, new scaling
-            for (int i = 0; i < 14; ++i) rs->x.pose[i] = st->pose[i];
-            pose_ctx_prepare(rs->x);
+            PoseCtx c;                                         // in registers: no global read-after-write chains
+            for (int i = 0; i < 14; ++i) c.pose[i] = st->pose[i];
+            pose_ctx_prepare(c);
+            rs->x = c;
             rs->radius = 1e4; rs->decrease_factor = 2.0;
             rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
         }
     }
-    __syncthreads();
-    int run = s_cnt[tid];
     for (int k = lo; k < hi; ++k) {
         const int v = rb.rank[k];
         rb.rank[k] = v ? run * prm.num_closest : -1;
@@ -456,21 +465,71 @@ __device__ inline double robust_regularisers(const RobustParams &prm, int n_res,
     return cost;
 }
 
+// Lane i < 12 holds row i of a symmetric positive definite 12x12 matrix (rowr) and b_i; returns x_i of A x = b.
+// Right-looking LDL^T with the pivot row broadcast by v_readlane (no LDS), then the two substitutions the same way.
+// All 64 lanes must call it; ok = every pivot positive.
+#define CTGN_BCAST(v, src) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src))
+__device__ __forceinline__ double wave_spd_solve12(double (&rowr)[12], double bi, int i, bool &ok) {
+    ok = true;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const double dk = CTGN_BCAST(rowr[k], k);
+        ok = ok && (dk > 0.0) && isfinite(dk);
+        const double lik = (i > k) ? rowr[k] / dk : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < 12; ++j) {
+            const double vkj = CTGN_BCAST(rowr[j], k);
+            if (i > k) rowr[j] -= lik * vkj;
+        }
+        if (i > k) rowr[k] = lik;
+    }
+    double y = bi, dii = 1.0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {                // forward: after step j, y_j is final
+        const double yj = CTGN_BCAST(y, j);
+        if (i > j) y -= rowr[j] * yj;
+        if (i == j) dii = rowr[j];
+    }
+    y = y / dii;
+#pragma unroll
+    for (int j = 11; j >= 1; --j) {               // backward with L^T: L[j][c] lives in lane j, register c
+        const double xj = CTGN_BCAST(y, j);
+#pragma unroll
+        for (int c = 0; c < j; ++c) {
+            const double ljc = CTGN_BCAST(rowr[c], j);
+            if (i == c) y -= ljc * xj;
+        }
+    }
+    return y;
+}
+
 // ================================================================================================
 // k_robust_step — one block.
 //   PHASE 0 (after k_robust_eval<true>):  reduce the partials, add the regularisers, run the checks of
 //            FinalizeIterationAndCheckIfMinimizerCanContinue, compute the Levenberg-Marquardt step and the candidate
 //   PHASE 1 (after k_robust_eval<false>): candidate cost, function tolerance, accept / reject, radius update
+// The 12x12 work runs on wave 0 with one matrix row per lane; only the quaternion bookkeeping is single-lane.
 // ================================================================================================
 constexpr int STEP_BLOCK = 1024;
+#define RWSYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+// The solver state is staged in LDS for the whole kernel and written back once at the end: a dependent chain of
+// global-memory read-after-writes on one lane costs ~1 us per link on this part.
 template <int PHASE>
 __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partials, int nblocks, GnState *st, RobustState *rs,
                                                              RobustParams prm) {
     __shared__ double s_sys[SYS_N];
+    __shared__ __attribute__((aligned(8))) RobustState R;
+    __shared__ double s_delta[12];
+    __shared__ int s_flag;
+    static_assert(sizeof(RobustState) % 8 == 0, "RobustState is copied as doubles");
+    constexpr int NW = (int) (sizeof(RobustState) / 8);
     if (st->done || rs->ls_done) return;
     if (PHASE == 1 && !rs->step_valid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    unsigned long long tc1 = tc0, tc2 = tc0, tc3 = tc0, tc4 = tc0, tc5 = tc0;
+    for (int w = tid; w < NW; w += STEP_BLOCK) reinterpret_cast<double *>(&R)[w] = reinterpret_cast<const double *>(rs)[w];
     // wave w sums entries w, w + 16, ... over the blocks: lane-strided, then a fixed shuffle tree (deterministic)
     for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
         if (PHASE == 1 && e != 90) continue;
@@ -480,102 +539,130 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
         if (lane == 0) s_sys[e] = acc;
     }
     __syncthreads();
-    if (tid != 0) return;
+    if (wave != 0) return;
 
     const double min_relative_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const double max_radius = 1e16, min_radius = 1e-32;
+    bool stop_all = false;                                 // lane 0: raise GnState::done
+    tc1 = __builtin_readcyclecounter();
     if (PHASE == 0) {
-        double *H = rs->H, *g = rs->g;
-        for (int e = 0; e < 78; ++e) {
-            const int i = c_tri_i[e], j = c_tri_j[e];
-            H[12 * i + j] = s_sys[e];
-            H[12 * j + i] = s_sys[e];
+        const int have_scale = R.have_scale;
+        const double radius = R.radius;
+        const int i = lane < 12 ? lane : 0;
+        for (int e = lane; e < 78; e += 64) {
+            const int r = c_tri_i[e], c = c_tri_j[e];
+            R.H[12 * r + c] = s_sys[e];
+            R.H[12 * c + r] = s_sys[e];
         }
-        for (int i = 0; i < 12; ++i) g[i] = -s_sys[78 + i];
-        double cost = s_sys[90];
-        cost += robust_regularisers(prm, rs->n_res, rs->x.pose, H, g);
-        rs->x_cost = cost;
-        if (!isfinite(cost)) { rs->error = 1; rs->ls_done = 1; st->done = 1; return; }
-        if (!rs->have_scale) {                          // jacobi_scaling: from the first Jacobian of the solve only
-            for (int i = 0; i < 12; ++i) rs->scale[i] = 1.0 / (1.0 + sqrt(H[13 * i]));
-            rs->have_scale = 1;
+        if (lane < 12) R.g[lane] = -s_sys[78 + lane];
+        RWSYNC();
+        if (lane == 0) {
+            const double cost = s_sys[90] + robust_regularisers(prm, R.n_res, R.x.pose, R.H, R.g);
+            R.x_cost = cost;
+            int flag = 0;
+            if (!isfinite(cost)) { R.error = 1; R.ls_done = 1; stop_all = true; flag = 1; }
+            else if (R.ls_iter >= prm.ls_max_iters) { R.ls_done = 1; R.ls_term = 0; flag = 1; }
+            else {
+                double neg[12], moved[14], mx = 0.0;              // gradient tolerance: max norm of x - Plus(x, -g)
+#pragma unroll
+                for (int c = 0; c < 12; ++c) neg[c] = -R.g[c];
+                pose_plus(R.x.pose, neg, moved);
+#pragma unroll
+                for (int c = 0; c < 14; ++c) mx = fmax(mx, fabs(R.x.pose[c] - moved[c]));
+                if (mx <= gradient_tolerance || radius < min_radius) { R.ls_done = 1; R.ls_term = 1; flag = 1; }
+            }
+            if (!flag) { R.ls_iter += 1; R.ls_iters_total += 1; }
+            s_flag = flag;
         }
-        if (rs->ls_iter >= prm.ls_max_iters) { rs->ls_done = 1; rs->ls_term = 0; return; }
-        {   // gradient tolerance: max norm of x - Plus(x, -g)
-            double neg[12], moved[14], mx = 0.0;
-            for (int i = 0; i < 12; ++i) neg[i] = -g[i];
-            pose_plus(rs->x.pose, neg, moved);
-            for (int i = 0; i < 14; ++i) mx = fmax(mx, fabs(rs->x.pose[i] - moved[i]));
-            if (mx <= gradient_tolerance) { rs->ls_done = 1; rs->ls_term = 1; return; }
-        }
-        if (rs->radius < min_radius) { rs->ls_done = 1; rs->ls_term = 1; return; }
-        rs->ls_iter += 1;
-        rs->ls_iters_total += 1;
-        // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian
-        double A[144], Hs[144], gs[12], rhs[12], y[12];
-        const double *sc = rs->scale;
-        for (int i = 0; i < 12; ++i) {
-            gs[i] = sc[i] * g[i];
-            rhs[i] = -gs[i];
-            for (int j = 0; j < 12; ++j) { Hs[12 * i + j] = sc[i] * H[12 * i + j] * sc[j]; A[12 * i + j] = Hs[12 * i + j]; }
-        }
-        for (int i = 0; i < 12; ++i) A[13 * i] += fmin(fmax(Hs[13 * i], min_diag), max_diag) / rs->radius;
-        ldlt_solve12(A, rhs, y);
-        bool ok = true;
-        double yg = 0.0, yHy = 0.0;
-        for (int i = 0; i < 12; ++i) {
-            ok = ok && isfinite(y[i]);
-            yg += y[i] * gs[i];
+        RWSYNC();
+        tc2 = __builtin_readcyclecounter();
+        // jacobi_scaling: from the first Jacobian of the solve only
+        const double sc_i = have_scale ? R.scale[i] : 1.0 / (1.0 + sqrt(R.H[13 * i]));
+        RWSYNC();
+        if (lane < 12) R.scale[lane] = sc_i;
+        if (lane == 0) R.have_scale = 1;
+        RWSYNC();
+        tc3 = __builtin_readcyclecounter();
+        if (!s_flag) {
+            // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian: (Hs + clamp(diag Hs) / radius) y = -gs
+            double rowr[12], hs[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { hs[j] = sc_i * R.H[12 * i + j] * R.scale[j]; rowr[j] = hs[j]; }
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                if (j == i) rowr[j] += fmin(fmax(hs[j], min_diag), max_diag) / radius;
+            const double gs_i = sc_i * R.g[i];
+            bool ok;
+            const double y = wave_spd_solve12(rowr, -gs_i, lane < 12 ? lane : 63, ok);
             double row = 0.0;
-            for (int j = 0; j < 12; ++j) row += Hs[12 * i + j] * y[j];
-            yHy += y[i] * row;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) row += hs[j] * CTGN_BCAST(y, j);
+            const double model_cost_change = -wave_sum_fixed(lane < 12 ? y * (gs_i + 0.5 * row) : 0.0);   // -(J y).(r + J y / 2)
+            const bool finite_all = __ballot(lane < 12 && !isfinite(y)) == 0ull;
+            ok = ok && finite_all && model_cost_change > 0.0;
+            if (lane < 12) s_delta[lane] = y * sc_i;
+            RWSYNC();
+            tc4 = __builtin_readcyclecounter();
+            if (lane == 0) {
+                if (!ok) {                                      // HandleInvalidStep
+                    R.step_valid = 0;
+                    if (++R.invalid >= 5) { R.error = 1; R.ls_done = 1; stop_all = true; }
+                    else R.radius = radius * 0.5;
+                } else {
+                    R.invalid = 0;
+                    R.model_cost_change = model_cost_change;
+                    double delta[12];
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) delta[c] = s_delta[c];
+                    pose_plus(R.x.pose, delta, R.cand.pose);
+                    pose_ctx_prepare(R.cand);
+                    R.step_valid = 1;
+                    double step2 = 0.0, x2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 14; ++c) {
+                        const double d = R.x.pose[c] - R.cand.pose[c];
+                        step2 += d * d;
+                        x2 += R.x.pose[c] * R.x.pose[c];
+                    }
+                    if (sqrt(step2) <= parameter_tolerance * (sqrt(x2) + parameter_tolerance)) { R.ls_done = 1; R.ls_term = 1; }
+                }
+            }
         }
-        const double model_cost_change = -(yg + 0.5 * yHy);
-        ok = ok && model_cost_change > 0.0;
-        if (!ok) {                                      // HandleInvalidStep
-            rs->step_valid = 0;
-            if (++rs->invalid >= 5) { rs->error = 1; rs->ls_done = 1; st->done = 1; return; }
-            rs->radius *= 0.5;
-            return;
-        }
-        rs->invalid = 0;
-        rs->model_cost_change = model_cost_change;
-        double delta[12];
-        for (int i = 0; i < 12; ++i) delta[i] = y[i] * sc[i];
-        pose_plus(rs->x.pose, delta, rs->cand.pose);
-        pose_ctx_prepare(rs->cand);
-        rs->step_valid = 1;
-        double step2 = 0.0, x2 = 0.0;
-        for (int i = 0; i < 14; ++i) {
-            const double d = rs->x.pose[i] - rs->cand.pose[i];
-            step2 += d * d;
-            x2 += rs->x.pose[i] * rs->x.pose[i];
-        }
-        if (sqrt(step2) <= parameter_tolerance * (sqrt(x2) + parameter_tolerance)) { rs->ls_done = 1; rs->ls_term = 1; }
-    } else {
+    } else if (lane == 0) {
         double cand_cost = s_sys[90];
-        cand_cost += robust_regularisers(prm, rs->n_res, rs->cand.pose, nullptr, nullptr);
-        rs->cand_cost = cand_cost;
-        const double cost_change = rs->x_cost - cand_cost;
-        if (fabs(cost_change) <= function_tolerance * rs->x_cost) { rs->ls_done = 1; rs->ls_term = 1; return; }
-        const double rd = cost_change / rs->model_cost_change;
-        if (isfinite(cand_cost) && rd > min_relative_decrease) {             // HandleSuccessfulStep
-            rs->x = rs->cand;
-            for (int i = 0; i < 14; ++i) st->pose[i] = rs->cand.pose[i];
-            st->slerp_theta = rs->cand.theta; st->slerp_sin = rs->cand.sin_theta;
-            st->slerp_linear = rs->cand.linear; st->slerp_negate = rs->cand.negate;
-            const double f = 1.0 - pow(2.0 * rd - 1.0, 3.0);
-            rs->radius = fmin(max_radius, rs->radius / fmax(1.0 / 3.0, f));
-            rs->decrease_factor = 2.0;
-            rs->ls_accepted_total += 1;
-            rs->x_cost = cand_cost;
-        } else {                                                             // StepRejected
-            rs->radius = rs->radius / rs->decrease_factor;
-            rs->decrease_factor *= 2.0;
+        cand_cost += robust_regularisers(prm, R.n_res, R.cand.pose, nullptr, nullptr);
+        R.cand_cost = cand_cost;
+        const double cost_change = R.x_cost - cand_cost;
+        if (fabs(cost_change) <= function_tolerance * R.x_cost) { R.ls_done = 1; R.ls_term = 1; }
+        else {
+            const double rd = cost_change / R.model_cost_change;
+            if (isfinite(cand_cost) && rd > min_relative_decrease) {             // HandleSuccessfulStep
+                R.x = R.cand;
+                for (int c = 0; c < 14; ++c) st->pose[c] = R.cand.pose[c];
+                st->slerp_theta = R.cand.theta; st->slerp_sin = R.cand.sin_theta;
+                st->slerp_linear = R.cand.linear; st->slerp_negate = R.cand.negate;
+                const double t = 2.0 * rd - 1.0, f = 1.0 - t * t * t;
+                R.radius = fmin(max_radius, R.radius / fmax(1.0 / 3.0, f));
+                R.decrease_factor = 2.0;
+                R.ls_accepted_total += 1;
+                R.x_cost = cand_cost;
+            } else {                                                             // StepRejected
+                R.radius = R.radius / R.decrease_factor;
+                R.decrease_factor *= 2.0;
+            }
+            R.step_valid = 0;
         }
-        rs->step_valid = 0;
     }
+    RWSYNC();
+    tc5 = __builtin_readcyclecounter();
+    if (PHASE == 0 && lane == 0) {
+        R.step_cycles[0] = tc1 - tc0; R.step_cycles[1] = tc2 - tc1; R.step_cycles[2] = tc3 - tc2; R.step_cycles[3] = tc4 - tc3;
+        R.step_cycles[4] = tc5 - tc4;
+    }
+    RWSYNC();
+    for (int w = lane; w < NW; w += 64) reinterpret_cast<double *>(rs)[w] = reinterpret_cast<const double *>(&R)[w];
+    if (lane == 0 && stop_all) st->done = 1;
 }
 
 // slam::AngularDistance (include/SlamCore/types.h:142-150), degrees
@@ -593,32 +680,38 @@ __device__ inline double angular_distance_deg(const double *qa, const double *qb
 // End of one ICP iteration (ct_icp.cpp:633-667): normalise, pose change since the previous iteration, stop test.
 __global__ void k_robust_outer(GnState *st, RobustState *rs, RobustParams prm) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || st->done) return;
-    const Quat qb = quat_normalized(Quat{st->pose[0], st->pose[1], st->pose[2], st->pose[3]});
-    const Quat qe = quat_normalized(Quat{st->pose[7], st->pose[8], st->pose[9], st->pose[10]});
-    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
-    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
+    double p[14], prev[14];
+    for (int i = 0; i < 14; ++i) { p[i] = st->pose[i]; prev[i] = rs->prev[i]; }
+    const int icp_iter = rs->icp_iter, iter = st->iter;
+    const Quat qb = quat_normalized(Quat{p[0], p[1], p[2], p[3]});
+    const Quat qe = quat_normalized(Quat{p[7], p[8], p[9], p[10]});
+    p[0] = qb.x; p[1] = qb.y; p[2] = qb.z; p[3] = qb.w;
+    p[7] = qe.x; p[8] = qe.y; p[9] = qe.z; p[10] = qe.w;
     const SlerpPair sp = slerp_prepare(qb, qe);
-    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
     double db = 0.0, de = 0.0;
     for (int c = 0; c < 3; ++c) {
-        db += (rs->prev[4 + c] - st->pose[4 + c]) * (rs->prev[4 + c] - st->pose[4 + c]);
-        de += (rs->prev[11 + c] - st->pose[11 + c]) * (rs->prev[11 + c] - st->pose[11 + c]);
+        db += (prev[4 + c] - p[4 + c]) * (prev[4 + c] - p[4 + c]);
+        de += (prev[11 + c] - p[11 + c]) * (prev[11 + c] - p[11 + c]);
     }
     const double diff_trans = sqrt(db) + sqrt(de);
-    const double diff_rot = angular_distance_deg(st->pose, rs->prev) + angular_distance_deg(st->pose + 7, rs->prev + 7);
-    for (int i = 0; i < 14; ++i) rs->prev[i] = st->pose[i];
+    const double diff_rot = angular_distance_deg(p, prev) + angular_distance_deg(p + 7, prev + 7);
+    for (int i = 0; i < 14; ++i) { st->pose[i] = p[i]; rs->prev[i] = p[i]; }
+    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
     rs->diff_trans = diff_trans; rs->diff_rot = diff_rot;
     st->step_norm = diff_trans;
-    st->iter += 1;
+    st->iter = iter + 1;
     if (diff_rot < prm.thr_rot_deg && diff_trans < prm.thr_trans) { rs->converged = 1; st->done = 1; }   // :662-667: break
-    else rs->icp_iter += 1;
+    else rs->icp_iter = icp_iter + 1;
 }
 
 __global__ void k_robust_init(const GnState *st, RobustState *rs) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int i = 0; i < 14; ++i) { rs->prev[i] = st->pose[i]; rs->x.pose[i] = st->pose[i]; rs->cand.pose[i] = st->pose[i]; }
-    pose_ctx_prepare(rs->x);
-    rs->cand = rs->x;
+    PoseCtx c;
+    for (int i = 0; i < 14; ++i) c.pose[i] = st->pose[i];
+    pose_ctx_prepare(c);
+    for (int i = 0; i < 14; ++i) rs->prev[i] = c.pose[i];
+    rs->x = c;
+    rs->cand = c;
     rs->x_cost = 0.0; rs->cand_cost = 0.0; rs->model_cost_change = 0.0; rs->radius = 1e4; rs->decrease_factor = 2.0;
     rs->diff_trans = 0.0; rs->diff_rot = 0.0;
     rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
@@ -626,6 +719,7 @@ __global__ void k_robust_init(const GnState *st, RobustState *rs) {
     rs->n_res = 0; rs->icp_iter = 0; rs->error = 0; rs->converged = 0;
     for (int i = 0; i < 144; ++i) rs->H[i] = 0.0;
     for (int i = 0; i < 12; ++i) { rs->g[i] = 0.0; rs->scale[i] = 1.0; }
+    for (int i = 0; i < 8; ++i) rs->step_cycles[i] = 0;
 }
 
 }  // namespace ctgn

@@ -181,7 +181,8 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_robust_get_report(self._h, C.byref(r)))
         return dict(cost=r.cost, radius=r.radius, diff_rot_deg=r.diff_rot_deg, diff_trans=r.diff_trans,
                     num_residuals=r.num_residuals, ls_iterations=r.ls_iterations, ls_accepted=r.ls_accepted,
-                    converged=bool(r.converged), JtJ=np.array(r.JtJ).reshape(12, 12), Jtr=np.array(r.Jtr))
+                    converged=bool(r.converged), JtJ=np.array(r.JtJ).reshape(12, 12), Jtr=np.array(r.Jtr),
+                    step_cycles=[int(c) for c in r.step_cycles])
 
     def robust_blocks(self) -> dict:
         n = self._n

@@ -270,6 +270,7 @@ typedef struct {                         /* state of the last ctgn_solve_robust 
     int32_t converged;                   /* the ICP stop test fired                                            */
     double JtJ[144];                     /* loss-corrected normal equations of the last evaluation, row-major, */
     double Jtr[12];                      /* tangent order: begin_quat | end_quat | begin_t | end_t             */
+    uint64_t step_cycles[8];             /* shader clocks of the last LM step kernel, per stage (diagnostics)  */
 } ctgn_robust_report;
 ctgn_status ctgn_robust_get_report(ctgn_handle h, ctgn_robust_report *out);
 /* Residual blocks of the last ICP iteration, per keypoint (any pointer may be NULL): normal[3n], weight[n], alpha[n],
