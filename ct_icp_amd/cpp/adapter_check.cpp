@@ -52,7 +52,20 @@ int main() {
         std::printf("adapter %s n_used=%d iters=%d tr=%.6f %.6f %.6f err=%.2e map_points=%zu\n",
                     (s.success && err < 1e-6) ? "ok" : "FAIL", s.num_residuals_used, s.num_iters, frame.end_pose.tr[0],
                     frame.end_pose.tr[1], frame.end_pose.tr[2], err, map.NumPoints());
-        return (s.success && err < 1e-6) ? 0 : 1;
+        // the `case CERES:` arm on the same map and keypoints
+        TrajectoryFrame frame2;
+        frame2.begin_pose.dest_timestamp = 0.0;
+        frame2.end_pose.dest_timestamp = 1.0;
+        reg.Options().solver = CERES;
+        reg.Options().ls_max_num_iters = 5;
+        reg.Options().threshold_orientation_norm = 1e-6;
+        reg.Options().threshold_translation_norm = 1e-8;
+        ICPSummary s2 = reg.Register(map, kps, frame2, nullptr);
+        double err2 = 0;
+        for (int c = 0; c < 3; ++c) err2 = std::fmax(err2, std::fabs(frame2.end_pose.tr[c] - shift[c]));
+        std::printf("adapter-ceres %s n_res=%d iters=%d err=%.2e\n", (s2.success && err2 < 1e-5) ? "ok" : "FAIL",
+                    s2.num_residuals_used, s2.num_iters, err2);
+        return (s.success && err < 1e-6 && s2.success && err2 < 1e-5) ? 0 : 1;
     } catch (const std::exception &e) {
         std::printf("adapter no-device (%s)\n", e.what());
         return 0;

@@ -55,13 +55,26 @@ struct TrajectoryFrame {
 
 enum CT_ICP_SOLVER { GN, CERES, ROBUST };                    // include/ct_icp/ct_icp.h:35-39
 
-// The fields of ct_icp::CTICPOptions DoRegisterGaussNewton reads (include/ct_icp/ct_icp.h:56-153), same defaults.
+enum LEAST_SQUARES { STANDARD, CAUCHY, HUBER, TOLERANT, TRUNCATED };   // include/ct_icp/ct_icp.h:41-47
+
+// The fields of ct_icp::CTICPOptions DoRegisterGaussNewton / DoRegisterCeres read (include/ct_icp/ct_icp.h:56-153),
+// same defaults.
 struct CTICPOptions {
     int num_iters_icp = 5;
     CT_ICP_SOLVER solver = CERES;
+    int max_num_residuals = -1;
+    double weight_alpha = 0.9;
+    double weight_neighborhood = 0.1;
+    double power_planarity = 2.0;
     int max_number_neighbors = 20;
     int min_number_neighbors = 20;
+    int num_closest_neighbors = 1;
     double threshold_orientation_norm = 0.0001;
+    double threshold_translation_norm = 0.001;
+    LEAST_SQUARES loss_function = CAUCHY;
+    int ls_max_num_iters = 1;
+    double ls_sigma = 0.1;
+    double ls_tolerant_min_threshold = 0.05;
     double max_dist_to_plane_ct_icp = 0.3;
     bool debug_print = true;
 };
@@ -76,11 +89,14 @@ struct ICPSummary {
            avg_duration_solve = 0.;
 };
 
-// The part of ct_icp::PreviousFrameMotionModel GN reads (src/ct_icp/ct_icp.cpp:888-908).
+// The part of ct_icp::PreviousFrameMotionModel the solvers read (GN: src/ct_icp/ct_icp.cpp:888-908; CERES:
+// src/ct_icp/motion_model.cpp:12-61).
 struct PreviousFrameMotionModel {
     struct Options {
         double beta_location_consistency = 0.001;
         double beta_constant_velocity = 0.001;
+        double beta_small_velocity = 0.0;
+        double beta_orientation_consistency = 0.0;
     } options;
     TrajectoryFrame previous_frame;
     const TrajectoryFrame &PreviousFrame() const { return previous_frame; }
@@ -179,7 +195,7 @@ private:
     ctgn_handle h_ = nullptr;
 };
 
-// ct_icp::CT_ICP_Registration for `solver: GN`.
+// ct_icp::CT_ICP_Registration for `solver: GN` and `solver: CERES` (CONTINUOUS_TIME, POINT_TO_PLANE).
 class CT_ICP_Registration {
 public:
     CTICPOptions &Options() { return options_; }
@@ -189,7 +205,8 @@ public:
     // (src/ct_icp/ct_icp.cpp:1026-1037). Updates the frame's poses and the keypoints' world points in place.
     ICPSummary Register(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &keypoints, TrajectoryFrame &trajectory_frame,
                         const PreviousFrameMotionModel *motion_model = nullptr, void * /*strategy: unused by GN*/ = nullptr) {
-        if (options_.solver != GN) throw std::runtime_error("Unsupported Solver Type");      // ct_icp.cpp:1022
+        if (options_.solver == ROBUST) throw std::runtime_error("Unsupported Solver Type");  // ct_icp.cpp:1022
+        if (options_.solver == CERES) return RegisterCeres(voxel_map, keypoints, trajectory_frame, motion_model);
         ctgn_options o;
         ctgn_options_default(&o);
         o.num_iters_icp = options_.num_iters_icp;
@@ -240,6 +257,72 @@ public:
     }
 
 private:
+    // `case CERES:` (src/ct_icp/ct_icp.cpp:1003-1007 -> DoRegisterCeres :457-707)
+    ICPSummary RegisterCeres(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &keypoints, TrajectoryFrame &trajectory_frame,
+                             const PreviousFrameMotionModel *motion_model) {
+        ctgn_robust_options o;
+        ctgn_robust_options_default(&o);
+        o.num_iters_icp = options_.num_iters_icp;
+        o.min_number_neighbors = options_.min_number_neighbors;
+        o.max_number_neighbors = options_.max_number_neighbors;
+        o.debug_print = options_.debug_print ? 1 : 0;
+        o.max_num_residuals = options_.max_num_residuals;
+        o.loss_function = (int32_t) options_.loss_function;
+        o.ls_max_num_iters = options_.ls_max_num_iters;
+        o.num_closest_neighbors = options_.num_closest_neighbors;
+        o.weight_alpha = options_.weight_alpha;
+        o.weight_neighborhood = options_.weight_neighborhood;
+        o.power_planarity = options_.power_planarity;
+        o.max_dist_to_plane_ct_icp = options_.max_dist_to_plane_ct_icp;
+        o.ls_sigma = options_.ls_sigma;
+        o.ls_tolerant_min_threshold = options_.ls_tolerant_min_threshold;
+        o.threshold_orientation_norm = options_.threshold_orientation_norm;
+        o.threshold_translation_norm = options_.threshold_translation_norm;
+        ctgn_robust_prior prior, *pp = nullptr;
+        if (motion_model) {                                                                  // ct_icp.cpp:608-610
+            prior.beta_location_consistency = motion_model->options.beta_location_consistency;
+            prior.beta_constant_velocity = motion_model->options.beta_constant_velocity;
+            prior.beta_small_velocity = motion_model->options.beta_small_velocity;
+            prior.beta_orientation_consistency = motion_model->options.beta_orientation_consistency;
+            std::memcpy(prior.previous_begin_tr, motion_model->PreviousFrame().BeginTr(), 24);
+            std::memcpy(prior.previous_end_tr, motion_model->PreviousFrame().EndTr(), 24);
+            std::memcpy(prior.previous_end_quat, motion_model->PreviousFrame().EndQuat(), 32);
+            pp = &prior;
+        }
+        double pose[14];
+        std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
+        std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
+        std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
+        std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+        const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
+        const size_t n = keypoints.size();
+        WPoint3D dummy{};
+        WPoint3D *base = n ? keypoints.data() : &dummy;
+        ctgn_view raw{base->raw_point, sizeof(WPoint3D), CTGN_F64, 0};
+        ctgn_view ts{&base->timestamp, sizeof(WPoint3D), CTGN_F64, 0};
+        ctgn_summary s;
+        ctgn_status st = ctgn_register_robust(voxel_map.handle(), raw, base->world_point, sizeof(WPoint3D), CTGN_F64, ts, n, pose,
+                                              tbe, &o, pp, &s);
+        if (st == CTGN_ERR_SOLVER) throw std::runtime_error("Error During Optimization");    // ct_icp.cpp:628-631
+        ICPSummary out;
+        if (st != CTGN_OK) {
+            out.success = false;
+            out.error_log = ctgn_last_error(voxel_map.handle());
+            return out;
+        }
+        std::memcpy(trajectory_frame.begin_pose.quat, pose, 32);
+        std::memcpy(trajectory_frame.begin_pose.tr, pose + 4, 24);
+        std::memcpy(trajectory_frame.end_pose.quat, pose + 7, 32);
+        std::memcpy(trajectory_frame.end_pose.tr, pose + 11, 24);
+        out.success = s.success != 0;
+        out.num_residuals_used = s.num_residuals_used;
+        out.num_iters = s.num_iters;
+        out.error_log = s.error_log;
+        out.duration_total = s.duration_total_ms * 1e-3;
+        out.avg_duration_iter = s.num_iters ? s.duration_device_ms * 1e-3 / s.num_iters : 0.0;
+        return out;
+    }
+
     CTICPOptions options_;
 };
 

@@ -337,7 +337,7 @@ def test_cpp_adapter_program():
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ct_icp_amd", "cpp", "adapter_check")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and out.stdout.startswith("adapter ok"), out.stdout + out.stderr
+    assert out.returncode == 0 and out.stdout.startswith("adapter ok") and "adapter-ceres ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_sharded_loop_single_rank_equals_fused(box_case):
