@@ -260,10 +260,16 @@ def main():
                                                  "1 M keypoints spread over the whole map, radius 0.8 (125 voxels), k=20"}[args.workload]
         if args.workload == "B2" and world == 1 and not args.ablate:
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
+            result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
         if not args.no_cpu_baseline and args.workload == "B2":
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
+            if "robust_route" in result:                   # same frame, same settings: the two poses must agree
+                rr, cr = result["robust_route"], result["cpu_baseline"]["robust_route"]
+                tr, rot = se3.pose_error(np.array(rr.pop("pose")), np.array(cr.pop("pose")))
+                rr["gpu_vs_cpu_pose_m_rad"] = [tr, rot]
+                rr["gpu_over_cpu_1core"] = cr["ms_per_frame"] / rr["ms_per_frame"]
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -315,6 +321,40 @@ def measure_frames_per_sec(cia, gm, inp, syn, se3, mm, reps: int = 30):
             "gn_iterations": int(np.median(iters)), "includes": "host WPoint3D buffer -> H2D -> GN loop -> pose + world points D2H"}
 
 
+ROBUST_PROFILE = dict(num_iters_icp=5, ls_max_num_iters=5, max_num_residuals=900, loss_function="CAUCHY", ls_sigma=0.1)
+
+
+def robust_keypoints(inp, syn):
+    sel = syn.grid_sample_indices(inp["raw"], 0.5)
+    return sel[syn.grid_sample_indices(inp["raw"][sel], 1.5)]
+
+
+def measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm, reps: int = 20):
+    """The robust-loss (CERES-profile) route, SURVEY.md 8f row 4: whole `Register(solver=CERES)` calls through the C ABI
+    with the driving profile's solver settings (config/odometry/driving_config.yaml:52-89: 5 ICP x 5 LM iterations, Cauchy
+    0.1, at most 900 residuals) on the reference's keypoint count."""
+    sel = robust_keypoints(inp, syn)
+    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
+    kps = np.zeros(len(sel), dtype=cia.WPOINT3D_DTYPE)
+    kps["raw_point"], kps["t"] = inp["raw"][sel], inp["t"][sel]
+    reg = cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.CERES, debug_print=False, **ROBUST_PROFILE))
+    times = []
+    for _ in range(reps):
+        frame = cia.TrajectoryFrame.from_pose14(pose0, *inp["tbe"])
+        t0 = time.perf_counter()
+        summ = reg.Register(gm, kps, frame, mm)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[3:]))
+    s = cia.GnSolver(gm)
+    rep = s.robust_report()
+    tr, rot = se3.pose_error(frame.pose14(), inp["pose_gt"])
+    return {"value": 1.0 / med, "unit": "frames/s", "ms_per_frame": med * 1e3, "keypoints": int(len(sel)),
+            "residual_blocks": int(summ.num_residuals_used), "icp_iterations": int(summ.num_iters),
+            "lm_iterations": int(rep["ls_iterations"]), "lm_accepted": int(rep["ls_accepted"]),
+            "error_vs_ground_truth_m_rad": [tr, rot], "pose": [float(v) for v in frame.pose14()],
+            "includes": "host WPoint3D buffer -> H2D -> 5 x (search, weights, cap, 5 x LM) -> pose + world points D2H"}
+
+
 def cpu_baseline(inp, pose0, world0, args):
     """The oracle (a port, not the reference: it cannot be built here) timed on this box's host cores on the same
     workload: CPU-N = OpenMP over keypoints on all cores, plus the faithful serial CPU-1 the reference actually runs
@@ -342,7 +382,17 @@ def cpu_baseline(inp, pose0, world0, args):
             v_n, best_threads = v, th
     cores = best_threads
     v_1 = timed(1, 2)
+    # the robust-loss route on one core (the oracle's restatement of DoRegisterCeres is serial)
+    from ct_icp_amd import synthetic as syn
+    sel = robust_keypoints(inp, syn)
+    ro = orc.RobustOptions(**ROBUST_PROFILE)
+    rp = orc.RobustPrior(previous_begin_tr=tuple(inp["prev_b"]), previous_end_tr=tuple(inp["prev_e"]))
+    t0 = time.perf_counter()
+    pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=1)
+    robust_ms = (time.perf_counter() - t0) * 1e3
     return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port",
+            "robust_route": {"ms_per_frame": robust_ms, "cores": 1, "icp_iterations": s_r.num_iters,
+                             "residual_blocks": s_r.num_residuals_used, "pose": [float(v) for v in pose_r]},
             "sample": f"oracle GN loop, {n} keypoints x {iters_n} iterations, OpenMP over keypoints on {cores} threads "
                       f"(same map and sweep as the GPU run)",
             "single_thread_value": v_1,

@@ -1,5 +1,5 @@
-"""Timing of the robust-loss (CERES-profile) route: whole CT_ICP_Registration::Register calls on the GPU against the
-CPU oracle on the same frame. Not the headline metric (bench.py); recorded in DESIGN.md section 9.
+"""Timing of the robust-loss (CERES-profile) route on the GPU: whole CT_ICP_Registration::Register calls
+(DESIGN.md section 9). The CPU comparison lives in bench.py's cpu_baseline leg.
 
   python scripts/robust_bench.py [--reps 20] [--full]
 """
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--full", action="store_true", help="also time the whole 0.5 m-subsampled sweep without a cap")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="accepted for compatibility; this script is GPU-only")
     args = ap.parse_args()
     inp = bench.make_inputs(0, 20)
     gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75))
@@ -60,22 +60,6 @@ def main():
               f"{rep['ls_iterations']} LM iterations ({rep['ls_accepted']} accepted): {med * 1e3:.3f} ms/frame "
               f"({1 / med:.1f} frames/s); error vs ground truth {tr * 100:.2f} cm / {np.degrees(rot):.4f} deg")
         print("      step-kernel clocks (stage-in+reduce | control | scale | solve | candidate):", rep["step_cycles"][:5])
-        if args.no_cpu:
-            continue
-        from oracle import oracle as orc
-        om = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
-        om.insert(inp["map_points"])
-        oo = orc.RobustOptions(o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors, False, o.max_num_residuals,
-                               o.loss_function, o.ls_max_num_iters, o.num_closest_neighbors, o.weight_alpha,
-                               o.weight_neighborhood, o.power_planarity, o.max_dist_to_plane_ct_icp, o.ls_sigma,
-                               o.ls_tolerant_min_threshold, o.threshold_orientation_norm, o.threshold_translation_norm)
-        op = orc.RobustPrior(previous_begin_tr=tuple(inp["prev_b"]), previous_end_tr=tuple(inp["prev_e"]))
-        t0 = time.perf_counter()
-        pose_o, _, so = orc.register_robust(om, raw[sel], t[sel], pose0, inp["tbe"], oo, op, heap_mode=1)
-        cpu = time.perf_counter() - t0
-        tr, rot = se3.pose_error(frame.pose14(), pose_o)
-        print(f"[cpu] oracle, 1 thread: {cpu * 1e3:.1f} ms/frame ({so.num_iters} ICP iterations) -> GPU {cpu / med:.1f}x; "
-              f"GPU vs oracle pose {tr:.2e} m / {rot:.2e} rad")
 
 
 if __name__ == "__main__":
