@@ -47,8 +47,10 @@ struct ctgn_context {
     std::vector<DevLevel> devlevels;
     DevMapScratch dm;
 
-    // keypoints: one device allocation of 7 arrays [rx ry rz t wx wy wz] x cap_kp
-    int n_kp = 0, cap_kp = 0;
+    // keypoints: one device allocation holding 7 arrays [rx ry rz t wx wy wz] of kp_stride (= n rounded up to 64) doubles
+    // back to back, so that one copy moves the whole set (and one copy brings the three world arrays back)
+    int n_kp = 0, cap_kp = 0, kp_stride = 0;
+    bool prefetch_world = false;        // ctgn_register*: bring the world points back with the final state, one sync
     double *d_kp = nullptr;
     uint32_t *d_res = nullptr;          // [cap_kp][SEL_STRIDE] row-phase -> lane-phase hand-over records
     double *h_kp = nullptr;             // pinned staging, same layout
@@ -273,7 +275,7 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
 
 KpView kp_view(ctgn_handle h) {
     KpView v;
-    const size_t c = (size_t) h->cap_kp;
+    const size_t c = (size_t) h->kp_stride;
     v.rx = h->d_kp; v.ry = h->d_kp + c; v.rz = h->d_kp + 2 * c; v.t = h->d_kp + 3 * c;
     v.wx = h->d_kp + 4 * c; v.wy = h->d_kp + 5 * c; v.wz = h->d_kp + 6 * c;
     v.sel = h->d_res;
@@ -728,8 +730,9 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         h->cap_kp = (int) cap;
     }
     h->n_kp = (int) n;
+    h->kp_stride = (int) std::min<size_t>((n + 63) & ~(size_t) 63, (size_t) h->cap_kp);
     HIPCHK(h, hipStreamSynchronize(h->stream));      // staging reuse
-    const size_t c = (size_t) h->cap_kp;
+    const size_t c = (size_t) h->kp_stride;
     double tmin = INFINITY, tmax = -INFINITY;
     for (size_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) {
@@ -743,23 +746,14 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         if (t != t) tmax = NAN;
     }
     h->t_min = tmin; h->t_max = tmax;
-    if (n) {
-        for (int a = 0; a < 7; ++a)
-            HIPCHK(h, hipMemcpyAsync(h->d_kp + a * c, h->h_kp + a * c, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    }
+    if (n) HIPCHK(h, hipMemcpyAsync(h->d_kp, h->h_kp, 7 * c * sizeof(double), hipMemcpyHostToDevice, h->stream));
     ctgn_status st = ensure_debug(h);
     if (st != CTGN_OK) return st;
     return CTGN_OK;
 }
 
-ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride, ctgn_dtype dt, size_t n) {
-    NEED_DEVICE(h);
-    if (n > (size_t) h->n_kp || (!world_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
-    if (n == 0) return CTGN_OK;
-    const size_t c = (size_t) h->cap_kp;
-    for (int a = 0; a < 3; ++a)
-        HIPCHK(h, hipMemcpyAsync(h->h_kp + (4 + a) * c, h->d_kp + (4 + a) * c, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+static void scatter_world_from_staging(ctgn_handle h, void *world_base, size_t stride, ctgn_dtype dt, size_t n) {
+    const size_t c = (size_t) h->kp_stride;
     for (size_t i = 0; i < n; ++i) {
         char *p = static_cast<char *>(world_base) + i * stride;
         for (int a = 0; a < 3; ++a) {
@@ -768,6 +762,23 @@ ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride
             else reinterpret_cast<float *>(p)[a] = (float) v;
         }
     }
+}
+
+// world arrays (4, 5, 6 of the keypoint block) -> pinned staging, enqueued on the stream (no sync)
+static ctgn_status enqueue_world_readback(ctgn_handle h) {
+    const size_t c = (size_t) h->kp_stride, n = (size_t) h->n_kp;
+    if (n) HIPCHK(h, hipMemcpyAsync(h->h_kp + 4 * c, h->d_kp + 4 * c, (2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride, ctgn_dtype dt, size_t n) {
+    NEED_DEVICE(h);
+    if (n > (size_t) h->n_kp || (!world_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CTGN_OK;
+    ctgn_status st = enqueue_world_readback(h);
+    if (st != CTGN_OK) return st;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    scatter_world_from_staging(h, world_base, stride, dt, n);
     return CTGN_OK;
 }
 
@@ -784,7 +795,9 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
         return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "keypoint timestamps must lie in [t_begin, t_end]");
     h->gn_t0 = std::chrono::steady_clock::now();
     fill_params(h, opts, prior);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // h_pose_in is reused: every other user synchronises before returning, only an unfinished stepwise loop can still
+    // have a copy from it in flight
+    if (h->gn_active) HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
     HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);
@@ -847,6 +860,7 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
     }
     HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->gn_active = false;
     const GnState &s = *h->h_state;
@@ -968,9 +982,12 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t
     ctgn_view world{world_base, world_stride, world_dtype, 0};
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
     if (st != CTGN_OK) return st;
+    h->prefetch_world = true;                      // world points ride back with the final state: one synchronisation
     st = ctgn_solve(h, pose_io, tbe, opts, prior, summary);
+    h->prefetch_world = false;
     if (st != CTGN_OK) return st;
-    return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
+    if (n) scatter_world_from_staging(h, world_base, world_stride, world_dtype, n);
+    return CTGN_OK;
 }
 
 
@@ -1066,7 +1083,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     h->prm.min_nb = o->min_number_neighbors;
     h->prm.max_nb = o->max_number_neighbors;
 
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->gn_active) { HIPCHK(h, hipStreamSynchronize(h->stream)); h->gn_active = false; }
     for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
     HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);    // :476-477
@@ -1111,6 +1128,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_rstate, h->d_rstate, sizeof(RobustState), hipMemcpyDeviceToHost, h->stream));
+    if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const GnState &s = *h->h_state;
     const RobustState &rs = *h->h_rstate;
@@ -1141,9 +1159,12 @@ ctgn_status ctgn_register_robust(ctgn_handle h, ctgn_view raw, void *world_base,
     ctgn_view world{world_base, world_stride, world_dtype, 0};
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
     if (st != CTGN_OK) return st;
+    h->prefetch_world = true;
     st = ctgn_solve_robust(h, pose_io, tbe, opts, prior, summary);
+    h->prefetch_world = false;
     if (st != CTGN_OK) return st;
-    return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
+    if (n) scatter_world_from_staging(h, world_base, world_stride, world_dtype, n);
+    return CTGN_OK;
 }
 
 ctgn_status ctgn_robust_get_report(ctgn_handle h, ctgn_robust_report *out) {
