@@ -208,6 +208,21 @@ def main():
         pcs, fast_rounds, all_rounds = pcs_all[:8], pcs_all[8], pcs_all[9]
         print(f"fast-path rounds: {fast_rounds} of {all_rounds}; slowest wave {pcs_all[10] / 1e3:.0f} kclk vs mean "
               f"{sum(pcs) / max(pcs_all[11], 1) / 1e3:.0f} kclk over {pcs_all[11]} wave-launches", file=sys.stderr)
+        tl = solver.wave_timeline().astype(np.float64)
+        if len(tl):
+            dur = tl[:, 1] - tl[:, 0]
+            frac_fast = tl[:, 2] / np.maximum(tl[:, 3], 1)
+            qd = np.percentile(dur, [1, 5, 25, 50, 75, 95, 99, 100]) / 1e3
+            # the clock is per XCD: group the waves by start clock (gaps >> kernel length) and look at each group's own timeline
+            order = np.argsort(tl[:, 0])
+            cuts = np.nonzero(np.diff(tl[order, 0]) > 50 * dur.max())[0] + 1
+            groups = np.split(order, cuts)
+            spans = [(tl[g, 1].max() - tl[g, 0].min()) / 1e3 for g in groups]
+            starts = [(tl[g, 0].max() - tl[g, 0].min()) / 1e3 for g in groups]
+            print(f"wave timeline (last launch, {len(tl)} waves, kclk): duration percentiles 1/5/25/50/75/95/99/100 = " +
+                  "/".join(f"{v:.0f}" for v in qd) + f"; corr(duration, fast-path share) = {np.corrcoef(dur, frac_fast)[0, 1]:.2f}; "
+                  f"{len(groups)} clock domains, span first-start..last-end per domain = " + "/".join(f"{v:.0f}" for v in spans) +
+                  ", start spread per domain = " + "/".join(f"{v:.0f}" for v in starts), file=sys.stderr)
         tot = float(sum(pcs)) or 1.0
         names = ["A transform", "B1 probes", "B2 stream", "B2 prunes", "B3 select", "B4 sums", "C normal/jac", "D accumulate"]
         print("phase cycles: " + ", ".join(f"{n}={100 * c / tot:.1f}%" for n, c in zip(names, pcs)) +

@@ -35,6 +35,9 @@ struct EventPair {
 
 }  // namespace
 
+// phase counters (12, padded to 16) + {start, end, fast rounds, rounds} per wave of the last instrumented launch
+constexpr size_t PROF_WORDS = 16 + 4 * (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES;
+
 struct ctgn_context {
     int device = -1;                    // -1: host-only map mirror, every device entry point fails
     int num_cus = 256;
@@ -494,8 +497,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
-             hipMalloc(reinterpret_cast<void **>(&h->d_prof), 12 * sizeof(unsigned long long)) == hipSuccess &&
-             hipMemsetAsync(h->d_prof, 0, 12 * sizeof(unsigned long long), h->stream) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_prof), PROF_WORDS * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemsetAsync(h->d_prof, 0, PROF_WORDS * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
              hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_sys_own, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
@@ -1290,6 +1293,16 @@ ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->d_prof, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 12 * sizeof(unsigned long long)));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves) {
+    NEED_DEVICE(h);
+    if (!out || !n_waves) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t n = std::min(max_waves, (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES);
+    HIPCHK(h, hipMemcpy(out, h->d_prof + 16, 4 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_waves = n;
     return CTGN_OK;
 }
 

@@ -606,6 +606,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds
     unsigned long long tprev = 0;
     if (PROF) tprev = __builtin_readcyclecounter();
+    const unsigned long long t_wave_start = tprev;
 #define CTGN_TICK(slot)                                                  \
     if (PROF) {                                                          \
         const unsigned long long now_ = __builtin_readcyclecounter();    \
@@ -873,6 +874,9 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
         atomicMax(&prof[10], tot_);            // slowest wave
         atomicAdd(&prof[11], 1ull);            // waves
+        // per-wave timeline of the LAST launch: start and end clock, fast-path rounds, rounds (prof + 16, 4 per wave)
+        unsigned long long *wrec = prof + 16 + 4 * (size_t) (blockIdx.x * ROW_WAVES + wave);
+        wrec[0] = t_wave_start; wrec[1] = __builtin_readcyclecounter(); wrec[2] = pc[8]; wrec[3] = pc[9];
     }
 #undef CTGN_TICK
 }

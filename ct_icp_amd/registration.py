@@ -275,6 +275,14 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_phase_cycles(self._h, out, int(reset)))
         return [int(x) for x in out]
 
+    def wave_timeline(self, max_waves: int = 8192) -> np.ndarray:
+        """(waves, 4) uint64: start clock, end clock, fast-path rounds, rounds of the last variant-3 launch."""
+        out = np.zeros((max_waves, 4), dtype=np.uint64)
+        n = C.c_size_t()
+        L.check(self._h, L.lib().ctgn_wave_timeline(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), max_waves, C.byref(n)))
+        out = out[:n.value]
+        return out[out[:, 1] > 0]
+
     def set_ablation(self, mask: int):
         L.check(self._h, L.lib().ctgn_set_ablation(self._h, mask))
 

@@ -337,6 +337,9 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel
  * fast path, 9 = rounds (counts, per wave), 10 = clocks of the slowest wave (max), 11 = waves. */
 ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset);
+/* Per-wave timeline of the last variant-3 launch: 4 words per wave slot (start clock, end clock, fast-path rounds,
+ * rounds); slots of waves that did not run keep their previous content (zero initially). */
+ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves);
 
 #ifdef __cplusplus
 }
