@@ -26,10 +26,47 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 B_KP, B_SLOT, B_PT = 32, 16, 24    # algorithmic bytes: keypoint record, hash slot, map point (FP64 xyz storage)
 
 
+def collect_pmc_traffic(args, timeout: int = 240):
+    """HBM bytes per launch of the dominant kernel, collected LIVE: two rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`,
+    then `... WRITE_SIZE`; separate passes and no other trace domain, as MI355X_MICROARCH.md prescribes) over a short inner
+    run of this same script and workload. bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE under-counts wide reads by
+    half on gfx950. Returns (bytes or None, source / reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    kernel = "k_accumulate_lane" if args.variant == 1 else "k_accumulate_rows"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="ctgn_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--inner", "--steps", "4", "--warmup", "1", "--workload", args.workload,
+               "--variant", str(args.variant), "--map-frames", str(args.map_frames)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, check=False)
+            rows = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                rows += [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                         if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+            if not rows:
+                return None, f"rocprofv3 --pmc {counter}: no rows for {kernel}"
+            vals[counter] = sum(rows) / len(rows)
+        except Exception as e:        # noqa: BLE001 — measurement nicety: never fail the bench over it
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes), 2*FETCH_SIZE + WRITE_SIZE"
+
+
 def pmc_traffic_bytes():
-    """HBM bytes per accumulate launch from the committed rocprofv3 PMC passes of this workload (bench.py itself
-    cannot collect PMCs): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE,
-    both reported in KB. Returns (bytes or None, source string)."""
+    """Fallback when the live collection is unavailable: the committed rocprofv3 PMC passes of the B2 workload
+    (profiles/). Returns (bytes or None, source string)."""
     import glob
     import re
     fetch = write = None
@@ -124,7 +161,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (all-reduce) loop even with one rank")
     ap.add_argument("--presort", action="store_true", help="experiment: sort the keypoints by home voxel on the host")
     ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes for roofline.traffic")
+    ap.add_argument("--inner", action="store_true", help="the run the PMC passes profile: timed loop only, no extras")
     args = ap.parse_args()
+    if args.inner:
+        args.no_pmc = args.no_cpu_baseline = True
 
     import torch
     import ct_icp_amd as cia
@@ -244,7 +285,14 @@ def main():
     if rank == 0:
         value = total_kp * args.steps / dt
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes() if args.variant == 0 and world == 1 else (None, None)
+        traffic, traffic_src = (None, None)
+        if world == 1 and not args.no_pmc and not args.ablate and dist is None:
+            traffic, traffic_src = collect_pmc_traffic(args)
+        if traffic is None and args.variant == 0 and world == 1 and args.workload == "B2":
+            why = traffic_src
+            traffic, traffic_src = pmc_traffic_bytes()
+            if why and traffic_src:
+                traffic_src += f" [live collection unavailable: {why}]"
         result = {
             "metric": "registered keypoints/sec per GN iter", "value": value, "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -273,7 +321,7 @@ def main():
                                                   "(the reference's keypoint count; latency regime)",
                                             "D": "config D-like: dense analytic street, map {0.5 m, 40 pts} ~0.5 GB (> Infinity Cache), "
                                                  "1 M keypoints spread over the whole map, radius 0.8 (125 voxels), k=20"}[args.workload]
-        if args.workload == "B2" and world == 1 and not args.ablate:
+        if args.workload == "B2" and world == 1 and not args.ablate and not args.inner:
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
         if not args.no_cpu_baseline and args.workload == "B2":
