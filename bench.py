@@ -328,6 +328,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
+                result["gpu_over_cpu_reference_shaped"] = value / world / result["cpu_baseline"]["reference_shaped"]["value"]
             if "robust_route" in result:                   # same frame, same settings: the two poses must agree
                 rr, cr = result["robust_route"], result["cpu_baseline"]["robust_route"]
                 tr, rot = se3.pose_error(np.array(rr.pop("pose")), np.array(cr.pop("pose")))
@@ -445,6 +446,20 @@ def cpu_baseline(inp, pose0, world0, args):
             v_n, best_threads = v, th
     cores = best_threads
     v_1 = timed(1, 2)
+    # the same accumulation on reference-shaped containers (node-based hash map of vectors of 80-byte records,
+    # std::priority_queue of tuples, one heap-allocated neighbour vector per keypoint): the flat-hash oracle above is faster
+    # than the reference's own implementation, this variant is what the ">= 50x" target is fair against
+    rm = orc.RefShapedMap(om)
+    o1 = orc.Options(num_iters_icp=1, threshold_orientation_norm=0.0)
+
+    def timed_ref(threads, reps):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rm.gn_accumulate(raw, w0, t, pose0, inp["tbe"], o1, num_threads=threads)
+        return n * reps / (time.perf_counter() - t0)
+
+    timed_ref(cores, 1)
+    ref_n, ref_1 = timed_ref(cores, 5), timed_ref(1, 1)
     # the robust-loss route on one core (the oracle's restatement of DoRegisterCeres is serial)
     from ct_icp_amd import synthetic as syn
     sel = robust_keypoints(inp, syn)
@@ -454,6 +469,9 @@ def cpu_baseline(inp, pose0, world0, args):
     pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=1)
     robust_ms = (time.perf_counter() - t0) * 1e3
     return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port",
+            "reference_shaped": {"value": ref_n, "single_thread_value": ref_1, "cores": cores,
+                                 "note": "accumulation pass only (search + normal + residual + sums), std::unordered_map<Voxel, "
+                                         "vector<80 B record>> + std::priority_queue: the reference's container shapes"},
             "robust_route": {"ms_per_frame": robust_ms, "cores": 1, "icp_iterations": s_r.num_iters,
                              "residual_blocks": s_r.num_residuals_used, "pose": [float(v) for v in pose_r]},
             "sample": f"oracle GN loop, {n} keypoints x {iters_n} iterations, OpenMP over keypoints on {cores} threads "

@@ -19,7 +19,7 @@ _SO = os.path.join(_HERE, "_build", "libctgn_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds). Returns the .so path."""
-    srcs = [os.path.join(_HERE, f) for f in ("ctgn_oracle.c", "ctgn_oracle_robust.c", "ctgn_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ctgn_oracle.c", "ctgn_oracle_robust.c", "ref_shaped.cpp", "ctgn_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
     return _SO
@@ -120,6 +120,12 @@ def lib():
                                       C.POINTER(_Prior), C.c_int, C.c_int, C.POINTER(_Summary)]
         L.orc_grid_sampling.restype = C.c_size_t
         L.orc_grid_sampling.argtypes = [dp, C.c_size_t, C.c_double, C.POINTER(C.c_uint32)]
+        # reference-shaped containers (ref_shaped.cpp)
+        L.orc_refshaped_create.restype = C.c_void_p
+        L.orc_refshaped_create.argtypes = [dp, C.c_size_t, C.c_double]
+        L.orc_refshaped_destroy.argtypes = [C.c_void_p]
+        L.orc_refshaped_gn_accumulate.argtypes = [C.c_void_p, dp, dp, dp, C.c_size_t, dp, dp, C.POINTER(_Opts), C.c_double,
+                                                  C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int)]
         # robust-loss route (ctgn_oracle_robust.c)
         L.orc_loss_evaluate.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp]
         L.orc_ct_point_to_plane.argtypes = [dp, C.c_double, dp, dp, dp, C.c_double, dp, dp]
@@ -501,3 +507,31 @@ def register_robust(m: Map, raw, t, pose, t_begin_end, opts: RobustOptions, prio
         raise ValueError(f"oracle: register_robust failed (rc={rc})")
     return pose, world, Summary(bool(s.success), s.num_residuals_used, s.num_iters, s.last_step_norm,
                                 s.error_log.decode(), 0.0, 0.0, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference-shaped containers (ref_shaped.cpp): CPU-baseline honesty, SURVEY.md 8d
+# ---------------------------------------------------------------------------------------------------------------------
+class RefShapedMap:
+    """One resolution level of an oracle Map re-bucketed into a node-based hash map of vectors of 80-byte records."""
+
+    def __init__(self, m: Map, radius: float | None = None):
+        map_id, self.resolution, self.nb = m.search_params(radius)
+        self.radius = float(radius if radius else m.default_radius)
+        pts = _f64(m.export(map_id))
+        self._h = lib().orc_refshaped_create(_dp(pts), len(pts), float(self.resolution))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_refshaped_destroy(self._h)
+            self._h = None
+
+    def gn_accumulate(self, raw, world, t, pose, t_begin_end, opts: Options, num_threads=1):
+        raw, world, t = _f64(raw).reshape(-1, 3), _f64(world).reshape(-1, 3), _f64(t).ravel()
+        A, b = np.zeros(144), np.zeros(12)
+        nu = C.c_int(0)
+        o = opts.c()
+        lib().orc_refshaped_gn_accumulate(self._h, _dp(raw), _dp(world), _dp(t), len(t), _dp(_f64(pose).ravel()),
+                                          _dp(_f64(t_begin_end)), C.byref(o), self.radius, int(self.nb), int(num_threads),
+                                          _dp(A), _dp(b), C.byref(nu))
+        return A.reshape(12, 12), b, nu.value

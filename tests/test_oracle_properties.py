@@ -314,3 +314,24 @@ def test_grid_sampling_first_point_per_voxel():
         seen.setdefault(v, i)
     assert sorted(idx.tolist()) == sorted(seen.values())
     assert np.array_equal(np.sort(idx), syn.grid_sample_indices(pts, 1.5))
+
+
+def test_reference_shaped_variant_gives_the_same_system(street_case):
+    """oracle/ref_shaped.cpp (node-based hash map, 80-byte records, std::priority_queue — the CPU baseline's "honest" variant)
+    must produce exactly the oracle's packed system: same neighbour sets, same arithmetic after the search."""
+    from conftest import build_maps
+    from ct_icp_amd import se3, synthetic as syn
+    om, _ = build_maps(street_case, 5)
+    sc = street_case["scans"][5]
+    sel = syn.grid_sample_indices(sc.raw, 0.8)
+    raw, t = sc.raw[sel], sc.t[sel]
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.004, 0.03, seed=2)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    o = orc.Options(num_iters_icp=1, min_number_neighbors=10)
+    A, b, n = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, o, heap_mode=0)
+    rm = orc.RefShapedMap(om)
+    for threads in (1, 3):
+        A2, b2, n2 = rm.gn_accumulate(raw, world0, t, pose0, sc.t_begin_end, o, num_threads=threads)
+        assert n2 == n and n > 300
+        tol = 0.0 if threads == 1 else 1e-12 * np.abs(A).max()
+        assert np.abs(A2 - A).max() <= tol and np.abs(b2 - b).max() <= tol + (0 if threads == 1 else 1e-15)
