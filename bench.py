@@ -324,6 +324,7 @@ def main():
         if args.workload == "B2" and world == 1 and not args.ablate and not args.inner:
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
+            result["frame_stages"] = measure_frame_stages(cia, inp, syn, se3, local_rank)
         if not args.no_cpu_baseline and args.workload == "B2":
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
@@ -383,6 +384,33 @@ def measure_frames_per_sec(cia, gm, inp, syn, se3, mm, reps: int = 30):
     med = float(np.median(times[3:]))
     return {"value": 1.0 / med, "unit": "frames/s", "ms_per_frame": med * 1e3, "keypoints": int(len(sel)),
             "gn_iterations": int(np.median(iters)), "includes": "host WPoint3D buffer -> H2D -> GN loop -> pose + world points D2H"}
+
+
+def measure_frame_stages(cia, inp, syn, se3, device: int):
+    """The steps either side of the path on the frame being registered, host buffers in and out:
+    frame grid sampling (0.5 m), full-scan undistortion, far-voxel eviction + insertion of the sampled frame into a
+    device-resident map that already holds the 20 preceding frames. One warm-up map, one timed map."""
+    raw, t = inp["raw"], inp["t"]
+    out = {}
+    maps = []
+    for _ in range(2):
+        m = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75,
+                                                    device=device, device_updates=True))
+        m.InsertPointCloud(inp["map_points"])
+        maps.append(m)
+    for rep, m in enumerate(maps):
+        t0 = time.perf_counter()
+        keep = np.sort(cia.grid_sampling(m, raw, 0.5))
+        t1 = time.perf_counter()
+        world = cia.transform_points(m, raw, t, inp["pose_gt"], inp["tbe"])
+        t2 = time.perf_counter()
+        m.RemoveElementsFarFromLocation(inp["pose_gt"][11:14], 100.0)
+        kept = m.InsertPointCloud(world[keep])
+        t3 = time.perf_counter()
+        out = {"grid_sampling_ms": (t1 - t0) * 1e3, "undistortion_ms": (t2 - t1) * 1e3, "map_update_ms": (t3 - t2) * 1e3,
+               "points": int(len(t)), "sampled": int(len(keep)), "inserted": int(np.count_nonzero(kept)),
+               "map_points_after": int(m.NumPoints())}
+    return out
 
 
 ROBUST_PROFILE = dict(num_iters_icp=5, ls_max_num_iters=5, max_num_residuals=900, loss_function="CAUCHY", ls_sigma=0.1)
@@ -468,7 +496,20 @@ def cpu_baseline(inp, pose0, world0, args):
     t0 = time.perf_counter()
     pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=1)
     robust_ms = (time.perf_counter() - t0) * 1e3
-    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port",
+    # the steps either side of the path on one core, as the reference runs them (only its undistortion loop is OpenMP)
+    om2 = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
+    om2.insert(inp["map_points"])
+    t0 = time.perf_counter()
+    keep = np.sort(orc.grid_sampling(inp["raw"], 0.5))
+    t1 = time.perf_counter()
+    world = orc.transform_points(inp["pose_gt"], inp["tbe"], inp["t"], inp["raw"], num_threads=cores)
+    t2 = time.perf_counter()
+    om2.remove_far(inp["pose_gt"][11:14], 100.0)
+    kept = om2.insert(world[keep])
+    t3 = time.perf_counter()
+    stages = {"grid_sampling_ms": (t1 - t0) * 1e3, "undistortion_ms": (t2 - t1) * 1e3, "map_update_ms": (t3 - t2) * 1e3,
+              "cores": f"1 (undistortion: {cores}, the reference's OpenMP loop)", "sampled": int(len(keep)), "inserted": int(np.count_nonzero(kept)), "map_points_after": int(om2.num_points())}
+    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port", "frame_stages": stages,
             "reference_shaped": {"value": ref_n, "single_thread_value": ref_1, "cores": cores,
                                  "note": "accumulation pass only (search + normal + residual + sums), std::unordered_map<Voxel, "
                                          "vector<80 B record>> + std::priority_queue: the reference's container shapes"},

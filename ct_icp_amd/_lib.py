@@ -162,3 +162,19 @@ def check(handle, status: int):
         if not msg:
             msg = L.ctgn_status_string(status).decode()
         raise CtgnError(status, msg)
+
+
+def is_device_tensor(obj) -> bool:
+    """A torch tensor living on a GPU (anything with data_ptr() and is_cuda): passed to the library as a device view."""
+    return hasattr(obj, "data_ptr") and bool(getattr(obj, "is_cuda", False))
+
+
+def tensor_view(t, comps: int = 3, offset_elems: int = 0) -> View:
+    """ctgn_view of a device tensor of shape (N, >= comps) or (N,): row stride and dtype taken from the tensor."""
+    import torch
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError("device views must be float32 or float64")
+    if t.dim() == 2 and t.stride(1) != 1:
+        raise ValueError("the components of a point must be contiguous")
+    es = t.element_size()
+    return View(t.data_ptr() + offset_elems * es, t.stride(0) * es, CTGN_F64 if t.dtype == torch.float64 else CTGN_F32, 0)

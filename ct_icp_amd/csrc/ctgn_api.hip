@@ -165,6 +165,44 @@ inline double read_elem(const void *base, size_t stride, ctgn_dtype dt, size_t i
     return dt == CTGN_F64 ? reinterpret_cast<const double *>(p)[c] : (double) reinterpret_cast<const float *>(p)[c];
 }
 
+// A view / output pointer may address device memory (e.g. a torch CUDA tensor): then nothing is staged through the host.
+bool on_device(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return false; }     // plain host memory
+    return a.type == hipMemoryTypeDevice;
+}
+
+inline int grid_for(size_t n) { return (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096)); }
+
+// device view -> SoA doubles on the handle's stream
+ctgn_status gather_device_view(ctgn_handle h, const void *base, size_t stride, ctgn_dtype dt, int ncomp, double *dst, size_t dst_stride,
+                               size_t n) {
+    hipLaunchKernelGGL(k_view_gather, dim3(grid_for(n)), dim3(256), 0, h->stream, static_cast<const char *>(base), stride,
+                       dt == CTGN_F64 ? 1 : 0, ncomp, dst, dst_stride, (int) n);
+    HIPCHK(h, hipGetLastError());
+    return CTGN_OK;
+}
+
+ctgn_status scatter_device_view(ctgn_handle h, const double *src, size_t src_stride, int ncomp, void *base, size_t stride, ctgn_dtype dt,
+                                size_t n) {
+    hipLaunchKernelGGL(k_view_scatter, dim3(grid_for(n)), dim3(256), 0, h->stream, src, src_stride, ncomp, static_cast<char *>(base),
+                       stride, dt == CTGN_F64 ? 1 : 0, (int) n);
+    HIPCHK(h, hipGetLastError());
+    return CTGN_OK;
+}
+
+// min / max of n device doubles -> host (synchronises)
+ctgn_status device_minmax(ctgn_handle h, const double *d_t, size_t n, double *lo, double *hi) {
+    hipLaunchKernelGGL(k_minmax, dim3(1), dim3(1024), 0, h->stream, d_t, (int) n, h->d_pose_in + 14);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_pose_in + 14, h->d_pose_in + 14, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *lo = h->h_pose_in[14];
+    *hi = h->h_pose_in[15];
+    return CTGN_OK;
+}
+
 ctgn_status ensure_edit_buffer(ctgn_handle h, size_t bytes) {
     if (bytes <= h->edit_cap) return CTGN_OK;
     size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
@@ -572,10 +610,15 @@ static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t str
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
     DevMapScratch &S = h->dm;
-    for (size_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz_base, stride, dt, i, a);
-    for (int a = 0; a < 3; ++a)
-        HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (on_device(xyz_base)) {
+        ctgn_status gs = gather_device_view(h, xyz_base, stride, dt, 3, S.pts, S.cap, n);
+        if (gs != CTGN_OK) return gs;
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz_base, stride, dt, i, a);
+        for (int a = 0; a < 3; ++a)
+            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(h, hipMemsetAsync(S.inserted, 0, n, h->stream));
     bool range_error = false, overflow = false;
     for (auto &DL : h->devlevels) {                      // map.h:199-205: every resolution
@@ -583,7 +626,10 @@ static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t str
         range_error = range_error || DL.host.range_error;
         overflow = overflow || DL.host.overflow;
     }
-    if (out) {
+    if (out && on_device(out)) {
+        HIPCHK(h, hipMemcpyAsync(out, S.inserted, n, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else if (out) {
         HIPCHK(h, hipMemcpyAsync(S.h_inserted, S.inserted, n, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         std::memcpy(out, S.h_inserted, n);
@@ -599,6 +645,9 @@ static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t str
 ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
     if (!h || (!xyz_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
     if (h->update_mode == 1) return devmap_insert(h, xyz_base, stride, dt, n, out);
+    if (n && on_device(xyz_base))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "device-memory points need the device-resident map (ctgn_map_set_update_mode(h, 1)); "
+                                              "the host mirror inserts from host memory");
     bool range_error = false;
     for (size_t i = 0; i < n; ++i) {
         double x = read_elem(xyz_base, stride, dt, i, 0), y = read_elem(xyz_base, stride, dt, i, 1),
@@ -720,6 +769,9 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     NEED_DEVICE(h);
     if (n > 0 && (!raw.base || !world.base || !ts.base)) return CTGN_ERR_INVALID_ARGUMENT;
     if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
+    const bool dev = n > 0 && on_device(raw.base);
+    if (n > 0 && (on_device(world.base) != dev || on_device(ts.base) != dev))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the raw, world and timestamp views must all be host memory or all be device memory");
     if ((int) n > h->cap_kp) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_kp) HIPCHK(h, hipFree(h->d_kp));
@@ -737,6 +789,15 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     HIPCHK(h, hipStreamSynchronize(h->stream));      // staging reuse
     const size_t c = (size_t) h->kp_stride;
     double tmin = INFINITY, tmax = -INFINITY;
+    if (dev) {                                       // device-resident views: gathered on the GPU, nothing staged
+        ctgn_status gs = gather_device_view(h, raw.base, raw.stride_bytes, raw.dtype, 3, h->d_kp, c, n);
+        if (gs == CTGN_OK) gs = gather_device_view(h, ts.base, ts.stride_bytes, ts.dtype, 1, h->d_kp + 3 * c, c, n);
+        if (gs == CTGN_OK) gs = gather_device_view(h, world.base, world.stride_bytes, world.dtype, 3, h->d_kp + 4 * c, c, n);
+        if (gs == CTGN_OK) gs = device_minmax(h, h->d_kp + 3 * c, n, &tmin, &tmax);
+        if (gs != CTGN_OK) return gs;
+        h->t_min = tmin; h->t_max = tmax;
+        return ensure_debug(h);
+    }
     for (size_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) {
             h->h_kp[a * c + i] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
@@ -778,6 +839,12 @@ ctgn_status ctgn_get_world_points(ctgn_handle h, void *world_base, size_t stride
     NEED_DEVICE(h);
     if (n > (size_t) h->n_kp || (!world_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
     if (n == 0) return CTGN_OK;
+    if (on_device(world_base)) {
+        ctgn_status ds = scatter_device_view(h, h->d_kp + 4 * (size_t) h->kp_stride, (size_t) h->kp_stride, 3, world_base, stride, dt, n);
+        if (ds != CTGN_OK) return ds;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return CTGN_OK;
+    }
     ctgn_status st = enqueue_world_readback(h);
     if (st != CTGN_OK) return st;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -924,11 +991,16 @@ ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double vo
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
     DevMapScratch &S = h->dm;
-    for (size_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
-    for (int a = 0; a < 3; ++a)
-        HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    DMCHK(h, devmap_grid_sampling(S, n, voxel_size, out_indices, out_count, h->stream));
+    if (on_device(xyz.base)) {
+        ctgn_status gs = gather_device_view(h, xyz.base, xyz.stride_bytes, xyz.dtype, 3, S.pts, S.cap, n);
+        if (gs != CTGN_OK) return gs;
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
+        for (int a = 0; a < 3; ++a)
+            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    DMCHK(h, devmap_grid_sampling(S, n, voxel_size, out_indices, out_count, h->stream));   // out_indices: host or device memory
     return CTGN_OK;
 }
 
@@ -949,6 +1021,26 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         h->tp_cap = cap;
     }
     const size_t c = h->tp_cap;
+    const bool dev = on_device(raw.base);
+    if (on_device(ts.base) != dev || on_device(out_base) != dev)
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the point, timestamp and output views must all be host memory or all be device memory");
+    if (dev) {
+        ctgn_status gs = gather_device_view(h, raw.base, raw.stride_bytes, raw.dtype, 3, h->d_tp, c, n);
+        if (gs == CTGN_OK) gs = gather_device_view(h, ts.base, ts.stride_bytes, ts.dtype, 1, h->d_tp + 3 * c, c, n);
+        double lo = 0, hi = 0;
+        if (gs == CTGN_OK) gs = device_minmax(h, h->d_tp + 3 * c, n, &lo, &hi);
+        if (gs != CTGN_OK) return gs;
+        if (!(tbe[0] <= lo && hi <= tbe[1])) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+        for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
+        HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, h->d_tp, h->d_tp + 4 * c, (int) n, c,
+                           h->d_pose_in, tbe[0], tbe[1]);
+        HIPCHK(h, hipGetLastError());
+        gs = scatter_device_view(h, h->d_tp + 4 * c, c, 3, out_base, out_stride, out_dtype, n);
+        if (gs != CTGN_OK) return gs;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return CTGN_OK;
+    }
     bool in_range = true;
     for (size_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) h->h_tp[a * c + i] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
@@ -985,10 +1077,12 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t
     ctgn_view world{world_base, world_stride, world_dtype, 0};
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
     if (st != CTGN_OK) return st;
-    h->prefetch_world = true;                      // world points ride back with the final state: one synchronisation
+    const bool dev_world = n > 0 && on_device(world_base);
+    h->prefetch_world = !dev_world;                // host views: world points ride back with the final state, one synchronisation
     st = ctgn_solve(h, pose_io, tbe, opts, prior, summary);
     h->prefetch_world = false;
     if (st != CTGN_OK) return st;
+    if (dev_world) return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
     if (n) scatter_world_from_staging(h, world_base, world_stride, world_dtype, n);
     return CTGN_OK;
 }
@@ -1162,10 +1256,12 @@ ctgn_status ctgn_register_robust(ctgn_handle h, ctgn_view raw, void *world_base,
     ctgn_view world{world_base, world_stride, world_dtype, 0};
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
     if (st != CTGN_OK) return st;
-    h->prefetch_world = true;
+    const bool dev_world = n > 0 && on_device(world_base);
+    h->prefetch_world = !dev_world;
     st = ctgn_solve_robust(h, pose_io, tbe, opts, prior, summary);
     h->prefetch_world = false;
     if (st != CTGN_OK) return st;
+    if (dev_world) return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
     if (n) scatter_world_from_staging(h, world_base, world_stride, world_dtype, n);
     return CTGN_OK;
 }

@@ -312,7 +312,7 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
     int count = 0;
     DM_CHK(hipMemcpyAsync(&count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     DM_CHK(hipStreamSynchronize(stream));
-    DM_CHK(hipMemcpyAsync(out_idx_host, S.sel_out, (size_t) count * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipMemcpyAsync(out_idx_host, S.sel_out, (size_t) count * sizeof(uint32_t), hipMemcpyDefault, stream));   // host or device
     DM_CHK(hipStreamSynchronize(stream));
     *out_count = (size_t) count;
     return hipSuccess;

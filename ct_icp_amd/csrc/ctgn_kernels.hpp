@@ -1294,6 +1294,55 @@ __global__ void k_state_init(GnState *st, const double *pose_in, double tb, doub
 }
 
 // ================================================================================================
+// strided views living in device memory (ctgn_view.base may be a device pointer): gather into / scatter from the
+// handle's SoA arrays without touching the host
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_view_gather(const char *base, size_t stride, int is_f64, int ncomp, double *dst,
+                                                      size_t dst_stride, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const char *p = base + (size_t) i * stride;
+        for (int c = 0; c < ncomp; ++c)
+            dst[(size_t) c * dst_stride + i] = is_f64 ? reinterpret_cast<const double *>(p)[c] : (double) reinterpret_cast<const float *>(p)[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_view_scatter(const double *src, size_t src_stride, int ncomp, char *base, size_t stride,
+                                                       int is_f64, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        char *p = base + (size_t) i * stride;
+        for (int c = 0; c < ncomp; ++c) {
+            const double v = src[(size_t) c * src_stride + i];
+            if (is_f64) reinterpret_cast<double *>(p)[c] = v;
+            else reinterpret_cast<float *>(p)[c] = (float) v;
+        }
+    }
+}
+
+// out[0] = min, out[1] = max of t[0..n); NaN anywhere makes out[1] NaN (the host check then fails, as for host views)
+__global__ __launch_bounds__(1024) void k_minmax(const double *t, int n, double *out) {
+    __shared__ double s_lo[16], s_hi[16];
+    __shared__ int s_nan[16];
+    double lo = INFINITY, hi = -INFINITY;
+    int has_nan = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = t[i];
+        if (v != v) has_nan = 1;
+        lo = fmin(lo, v); hi = fmax(hi, v);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, d)); hi = fmax(hi, __shfl_xor(hi, d)); has_nan |= __shfl_xor(has_nan, d);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_nan[wave] = has_nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int) (blockDim.x >> 6); ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); has_nan |= s_nan[w]; }
+        out[0] = lo;
+        out[1] = has_nan ? NAN : hi;
+    }
+}
+
+// ================================================================================================
 // map maintenance + queries
 // ================================================================================================
 __global__ void k_scatter_slots(Slot *slots, const SlotEdit *edits, int n) {

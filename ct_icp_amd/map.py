@@ -85,6 +85,13 @@ class GpuVoxelMap:
     def InsertPointCloud(self, world_points) -> np.ndarray:
         """Insert world points in every resolution (map.h:153-254 / :261-293). Returns the mask of points that
         were kept by at least one resolution (the reference's out_selected_points)."""
+        if L.is_device_tensor(world_points):        # device-resident points (torch CUDA tensor): nothing crosses PCIe
+            import torch
+            v = L.tensor_view(world_points)
+            out_t = torch.zeros(len(world_points), dtype=torch.uint8, device=world_points.device)
+            L.check(self._h, L.lib().ctgn_map_insert(self._h, v.base, v.stride_bytes, v.dtype, len(world_points),
+                                                    C.cast(out_t.data_ptr(), C.POINTER(C.c_uint8))))
+            return out_t.bool()
         a = _as_points(world_points)
         out = np.zeros(len(a), dtype=np.uint8)
         dt = L.CTGN_F64 if a.dtype == np.float64 else L.CTGN_F32

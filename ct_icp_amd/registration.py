@@ -108,9 +108,19 @@ class CT_ICP_Registration:
         return _summary(s)
 
 
-def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end) -> np.ndarray:
+def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end):
     """Full-scan continuous-time undistortion on the GPU (reference src/ct_icp/odometry.cpp:461-486): world[i] =
-    begin.InterpolatePose(end, t[i]) * raw[i]."""
+    begin.InterpolatePose(end, t[i]) * raw[i]. numpy in -> numpy out; torch CUDA tensors in -> torch CUDA tensor out (no host hop)."""
+    if L.is_device_tensor(raw):
+        import torch
+        out = torch.empty((len(raw), 3), dtype=torch.float64, device=raw.device)
+        pose = np.ascontiguousarray(pose14, dtype=np.float64)
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        h = voxel_map.handle
+        L.check(h, L.lib().ctgn_transform_points(h, L.tensor_view(raw), L.tensor_view(t, 1), len(raw), pose.ctypes.data_as(dp),
+                                                tbe.ctypes.data_as(dp), out.data_ptr(), 24, L.CTGN_F64))
+        return out
     raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
     t = np.ascontiguousarray(t, dtype=np.float64).ravel()
     pose = np.ascontiguousarray(pose14, dtype=np.float64)
@@ -127,10 +137,17 @@ def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end) -> np.
 def grid_sampling(voxel_map: GpuVoxelMap, points, voxel_size: float) -> np.ndarray:
     """ct_icp::grid_sampling / sub_sample_frame on the GPU (reference src/ct_icp/ct_icp.cpp:65-101): indices of the first
     point of every voxel, in voxel-key order."""
+    h = voxel_map.handle
+    if L.is_device_tensor(points):                       # device in, device out
+        import torch
+        out_t = torch.zeros(len(points), dtype=torch.int32, device=points.device)
+        cnt = C.c_size_t()
+        L.check(h, L.lib().ctgn_grid_sampling(h, L.tensor_view(points), len(points), float(voxel_size),
+                                             C.cast(out_t.data_ptr(), C.POINTER(C.c_uint32)), C.byref(cnt)))
+        return out_t[:cnt.value].clone()
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
     out = np.zeros(len(pts), dtype=np.uint32)
     cnt = C.c_size_t()
-    h = voxel_map.handle
     L.check(h, L.lib().ctgn_grid_sampling(h, L.View(pts.ctypes.data, 24, L.CTGN_F64, 0), len(pts), float(voxel_size),
                                          out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
     return out[:cnt.value].copy()
@@ -146,6 +163,11 @@ class GnSolver:
         self._n = 0
 
     def set_keypoints(self, raw, world, t):
+        if L.is_device_tensor(raw):                      # torch CUDA tensors: gathered on the device
+            assert len(raw) == len(world) == len(t)
+            self._n = len(t)
+            L.check(self._h, L.lib().ctgn_set_keypoints(self._h, L.tensor_view(raw), L.tensor_view(world), L.tensor_view(t, 1), self._n))
+            return
         raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
         world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
         t = np.ascontiguousarray(t, dtype=np.float64).ravel()
@@ -194,7 +216,12 @@ class GnSolver:
                                                        rank.ctypes.data_as(C.POINTER(C.c_int32)), n))
         return dict(normal=normal, weight=weight, alpha=alpha, ref=ref, rank=rank)
 
-    def world_points(self) -> np.ndarray:
+    def world_points(self, out=None):
+        """Host copy of the (re-transformed) world points, or — given a torch CUDA tensor (N, 3) — written in place on the device."""
+        if out is not None and L.is_device_tensor(out):
+            v = L.tensor_view(out)
+            L.check(self._h, L.lib().ctgn_get_world_points(self._h, v.base, v.stride_bytes, v.dtype, self._n))
+            return out
         out = np.zeros((self._n, 3))
         L.check(self._h, L.lib().ctgn_get_world_points(self._h, out.ctypes.data, 24, L.CTGN_F64, self._n))
         return out

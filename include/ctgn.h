@@ -20,6 +20,10 @@
  *   - poses are 7 doubles (qx, qy, qz, qw, tx, ty, tz): Eigen's coeffs() order, the same order as
  *     slam::TSE3::operator[] (reference include/SlamCore/types.h:378-385).
  *   - all host buffers are borrowed for the duration of the call only.
+ *   - point / timestamp views and point outputs may address DEVICE memory of the handle's GPU instead (detected with
+ *     hipPointerGetAttributes): ctgn_set_keypoints, ctgn_get_world_points, ctgn_register*, ctgn_transform_points,
+ *     ctgn_grid_sampling (input and out_indices) and, with the device-resident map, ctgn_map_insert (input and
+ *     out_inserted). Nothing is then staged through the host; all views of one call must live on the same side.
  *   - a handle owns one HIP device + one HIP stream and is NOT re-entrant (the reference's Odometry is
  *     not thread-safe either, include/ct_icp/odometry.h:275-287).
  *   - there is NO CPU fallback: every call fails with CTGN_ERR_NO_DEVICE when no gfx950 device exists.

@@ -445,6 +445,16 @@ void orc_transform_point(const double pose[14], const double tbe[2], double t, c
     out[0] = r[0] + tr[0]; out[1] = r[1] + tr[1]; out[2] = r[2] + tr[2];
 }
 
+/* Batch form: the full-scan undistortion loop of Odometry::DoRegister (src/ct_icp/odometry.cpp:461-486, the reference's
+ * only OpenMP loop on this route). */
+void orc_transform_points(const double pose[14], const double tbe[2], const double *t, const double *raw, size_t n,
+                          double *out, int num_threads) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(num_threads > 1 ? num_threads : 1) schedule(static)
+#endif
+    for (long i = 0; i < (long) n; ++i) orc_transform_point(pose, tbe, t[i], raw + 3 * i, out + 3 * i);
+}
+
 /* Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations. Stands in for
  * Eigen::JacobiSVD<Matrix3d>(C, ComputeFullV) on a symmetric matrix (neighborhood.h:293): singular values
  * = |eigenvalues| sorted descending, V = eigenvectors (sign per column arbitrary; the caller orients). */

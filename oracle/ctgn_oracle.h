@@ -98,6 +98,8 @@ void orc_matrix_to_quat(const double R[9], double q[4]);
 /* TPose::InterpolatePose(...) * raw  (types.h:453-470 -> :360-366 -> :353-357). */
 void orc_transform_point(const double pose[14], const double t_begin_end[2], double t, const double raw[3],
                          double out[3]);
+void orc_transform_points(const double pose[14], const double t_begin_end[2], const double *t, const double *raw, size_t n,
+                          double *out, int num_threads);                       /* odometry.cpp:461-486 */
 /* TNeighborhood::ComputeNeighborhood(A2D|NORMAL) (neighborhood.h:225-257,285-316). Returns 0 if <5 pts. */
 int orc_neighborhood(const double *pts_xyz, int n, double normal[3], double *a2d);
 /* symmetric 3x3 eigen-decomposition, eigenvalues descending, V columns = eigenvectors (row-major 3x3) */

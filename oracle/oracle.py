@@ -106,6 +106,7 @@ def lib():
         L.orc_quat_to_matrix.argtypes = [dp, dp]
         L.orc_matrix_to_quat.argtypes = [dp, dp]
         L.orc_transform_point.argtypes = [dp, dp, C.c_double, dp, dp]
+        L.orc_transform_points.argtypes = [dp, dp, dp, dp, C.c_size_t, dp, C.c_int]
         L.orc_neighborhood.restype = C.c_int
         L.orc_neighborhood.argtypes = [dp, C.c_int, dp, dp]
         L.orc_sym_eigen3.argtypes = [dp, dp, dp]
@@ -313,13 +314,11 @@ def grid_sampling(raw, voxel_size) -> np.ndarray:
     return out[:k].copy()
 
 
-def transform_points(pose, t_begin_end, t, raw) -> np.ndarray:
+def transform_points(pose, t_begin_end, t, raw, num_threads=1) -> np.ndarray:
     raw, t = _f64(raw).reshape(-1, 3), _f64(t).ravel()
     pose, tbe = _f64(pose).ravel(), _f64(t_begin_end)
     out = np.zeros_like(raw)
-    L = lib()
-    for i in range(len(t)):
-        L.orc_transform_point(_dp(pose), _dp(tbe), float(t[i]), _dp(raw[i]), _dp(out[i]))
+    lib().orc_transform_points(_dp(pose), _dp(tbe), _dp(t), _dp(raw), len(t), _dp(out), int(num_threads))
     return out
 
 

@@ -553,3 +553,53 @@ def test_sequence_of_frames_end_to_end(street_case):
         assert gm.NumPoints() == om.num_points() and gm.NumVoxels(0) == om.num_voxels(0)
         prev_g, prev_o = pose_g, pose_o
     assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(om.export(0)))
+
+
+# ------------------------------------------------------------------------------------------------- device-memory views
+def test_device_memory_views_match_host_views(street_case):
+    """Every entry point that takes point views also takes them in device memory (torch CUDA tensors here): identical results,
+    nothing staged through the host."""
+    import torch
+    case = street_case
+    dev = torch.device("cuda", 0)
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    opts = dict(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius, device_updates=True)
+    gh, gd = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(**opts)), cia.GpuVoxelMap(cia.GpuVoxelMapOptions(**opts))
+    for j in range(4):
+        sc = case["scans"][j]
+        keep_h = np.sort(cia.grid_sampling(gh, sc.raw, 0.5))
+        raw_d, t_d = torch.from_numpy(sc.raw).to(dev), torch.from_numpy(sc.t).to(dev)
+        keep_d = torch.sort(cia.grid_sampling(gd, raw_d, 0.5).long()).values
+        assert np.array_equal(keep_h, keep_d.cpu().numpy())
+        world_h = cia.transform_points(gh, sc.raw[keep_h], sc.t[keep_h], sc.pose_gt, sc.t_begin_end)
+        world_d = cia.transform_points(gd, raw_d[keep_d], t_d[keep_d], sc.pose_gt, sc.t_begin_end)
+        assert world_d.is_cuda and np.array_equal(world_h, world_d.cpu().numpy())
+        kept_h = gh.InsertPointCloud(world_h)
+        kept_d = gd.InsertPointCloud(world_d)
+        assert np.array_equal(kept_h, kept_d.cpu().numpy())
+    assert gh.NumPoints() == gd.NumPoints() and np.array_equal(_sorted_rows(gh.MapAsPointCloud(0)), _sorted_rows(gd.MapAsPointCloud(0)))
+    # registration with resident device keypoints; float32 strided device view (a (N, 8) tensor, xyz in columns 0..2, t in 3)
+    sc, raw, t, pose0, world0 = _keypoints(case, 4, 0.6)
+    o = _opts(num_iters_icp=4, min_number_neighbors=10)
+    sh, sd = cia.GnSolver(gh), cia.GnSolver(gd)
+    sh.set_keypoints(raw, world0, t)
+    sd.set_keypoints(torch.from_numpy(raw).to(dev), torch.from_numpy(world0).to(dev), torch.from_numpy(t).to(dev))
+    ph, smh, _ = sh.solve(pose0, sc.t_begin_end, o)
+    pd, smd, _ = sd.solve(pose0, sc.t_begin_end, o)
+    assert np.array_equal(ph, pd) and smh.num_residuals_used == smd.num_residuals_used
+    out_d = torch.empty((len(t), 3), dtype=torch.float64, device=dev)
+    assert np.array_equal(sd.world_points(out_d).cpu().numpy(), sh.world_points())
+    packed = torch.zeros((len(t), 8), dtype=torch.float32, device=dev)
+    packed[:, 0:3] = torch.from_numpy(raw.astype(np.float32)).to(dev)
+    w32 = cia.transform_points(gd, packed[:, 0:3], torch.from_numpy(t).to(dev), pose0, sc.t_begin_end)
+    w32_h = cia.transform_points(gh, raw.astype(np.float32).astype(np.float64), t, pose0, sc.t_begin_end)
+    assert np.array_equal(w32.cpu().numpy(), w32_h)
+    # mixing host and device views in one call is refused; a timestamp outside the frame is still caught on the device
+    with pytest.raises(cia.CtgnError) as e:
+        sd.set_keypoints(torch.from_numpy(raw).to(dev), torch.from_numpy(world0).to(dev), torch.from_numpy(t))
+    assert e.value.status == L.ERR_UNSUPPORTED
+    t_bad = torch.from_numpy(t).to(dev).clone()
+    t_bad[5] = sc.t_begin_end[1] + 1.0
+    with pytest.raises(cia.CtgnError) as e:
+        cia.transform_points(gd, torch.from_numpy(raw).to(dev), t_bad, pose0, sc.t_begin_end)
+    assert e.value.status == L.ERR_TIMESTAMP_RANGE
