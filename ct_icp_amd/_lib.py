@@ -146,6 +146,15 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). ct_icp_amd has no CPU fallback.")
+        # One process, one HIP runtime: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64. If libctgn pulls in the
+        # system copies first, a later `import torch` finds no GPU (measured on the MI355X box). Loading torch first makes
+        # libctgn's dependencies resolve to the already-loaded copies. CTGN_NO_TORCH_PRELOAD=1 skips this (torch-free users).
+        import sys
+        if "torch" not in sys.modules and not os.environ.get("CTGN_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)      # AttributeError if the symbol is not exported

@@ -1202,15 +1202,10 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
         if (st != CTGN_OK) break;
         hipLaunchKernelGGL(k_robust_prepare, dim3(grid_lane), dim3(256), 0, h->stream, mv, kv, h->d_state, r, rb);
         hipLaunchKernelGGL(k_robust_cap, dim3(1), dim3(CAP_BLOCK), 0, h->stream, h->d_state, h->d_rstate, r, rb, n);
-        for (int j = 0; j < std::max(1, r.ls_max_iters); ++j) {                          // ceres::Solve, :627
-            hipLaunchKernelGGL(k_robust_eval<true>, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
+        for (int j = 0; j <= r.ls_max_iters; ++j) {        // ceres::Solve, :627: evaluation 0 at x, then one per candidate
+            hipLaunchKernelGGL(k_robust_eval, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
                                h->d_partials);
-            hipLaunchKernelGGL(k_robust_step<0>, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
-                               h->d_rstate, r);
-            if (r.ls_max_iters == 0) break;
-            hipLaunchKernelGGL(k_robust_eval<false>, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
-                               h->d_partials);
-            hipLaunchKernelGGL(k_robust_step<1>, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
+            hipLaunchKernelGGL(k_robust_step, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
                                h->d_rstate, r);
         }
         hipLaunchKernelGGL(k_robust_outer, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate, r);

@@ -5,10 +5,12 @@
 //   k_accumulate_rows   the same neighbour search as the GN route (ctgn_kernels.hpp)
 //   k_robust_prepare    lane per keypoint: normal + a2D + weight (:569-579), the num_closest_neighbors reference points
 //   k_robust_cap        max_num_residuals cap in keypoint order (:415-426), soft failure (:612-624), solver reset
-//   ls_max_num_iters x [ k_robust_eval<true>   residual + closed-form Jacobian + loss -> packed J^T J | J^T r | cost
-//                        k_robust_step<0>      regularisers (motion_model.cpp:12-61), Levenberg-Marquardt step, candidate
-//                        k_robust_eval<false>  cost at the candidate
-//                        k_robust_step<1> ]    accept / reject, trust-region radius
+//   (ls_max_num_iters + 1) x [ k_robust_eval   residual + closed-form Jacobian + loss -> packed J^T J | J^T r | cost, at the
+//                                              start pose first, then at each candidate
+//                              k_robust_step ] regularisers (motion_model.cpp:12-61); accept / reject the candidate just evaluated
+//                                              and update the radius; checks; next Levenberg-Marquardt step -> next candidate
+//   One full evaluation per LM iteration instead of Ceres' two (cost at the candidate, then Jacobian at the accepted point): an
+//   accepted candidate's normal equations ARE the next iteration's, a rejected one leaves the previous ones in place.
 //   k_robust_outer      normalise, ICP stop test (:640-667)
 // Everything stays on the device; the host enqueues the fixed worst-case sequence and the kernels turn into no-ops once
 // the device-side flags say the inner solve or the ICP loop is finished.
@@ -52,12 +54,13 @@ struct RobustState {
     double x_cost, cand_cost, model_cost_change, radius, decrease_factor;
     double diff_trans, diff_rot;
     int have_scale, ls_iter, ls_done, ls_term, invalid, step_valid;
+    int eval_at_x, _pad0;     // 1: the pending evaluation is of x (start of a solve), 0: of cand
     int ls_iters_total, ls_accepted_total;
     int n_res;                // residual blocks of the current ICP iteration
     int icp_iter;             // the reference's loop counter `iter` (:535) as ICPSummary::num_iters reports it
     int error;                // the inner solver gave up (reference throws, :628-631)
     int converged;
-    unsigned long long step_cycles[8];   // shader clocks of the last k_robust_step<0>: stage-in+reduce | control | scale | solve | candidate | write-back
+    unsigned long long step_cycles[8];   // shader clocks of the last k_robust_step: stage-in+reduce | control | scale | solve | candidate | write-back
 };
 
 struct RobustBuf {            // per-keypoint output of k_robust_prepare, SoA with stride cap
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustSta
             rs->x = c;
             rs->radius = 1e4; rs->decrease_factor = 2.0;
             rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
+            rs->eval_at_x = 1;
         }
     }
     for (int k = lo; k < hi; ++k) {
@@ -292,23 +296,22 @@ __global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustSta
 }
 
 // ================================================================================================
-// k_robust_eval — lane per keypoint, its num_closest residual blocks in turn.
-//   FULL : residual + Jacobian at rs->x, loss + Triggs corrector (Ceres corrector.cc), packed J^T J | -J^T r | cost
-//   !FULL: cost at rs->cand
+// k_robust_eval — lane per keypoint, its num_closest residual blocks in turn: residual + Jacobian at rs->x (first
+// evaluation of a solve) or rs->cand, loss + Triggs corrector (Ceres corrector.cc), packed J^T J | -J^T r | cost.
 // ================================================================================================
 constexpr int EVAL_BLOCK = 256;
 constexpr int EVAL_REC = 15;                 // 12 J | r | cost | pad (odd stride: conflict-free LDS writes)
 
-template <bool FULL>
 __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnState *st, const RobustState *rs, RobustParams prm,
                                                              RobustBuf rb, double *partials) {
     __shared__ double s_rec[EVAL_BLOCK / 64][64 * EVAL_REC];
     __shared__ double s_comb[EVAL_BLOCK / 64][SYS_N];
     __shared__ PoseCtx s_ctx;
     if (st->done || rs->ls_done) return;
-    if (!FULL && !rs->step_valid) return;
+    const int at_x = rs->eval_at_x;
+    if (!at_x && !rs->step_valid) return;        // the last step was invalid: nothing new to evaluate
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ctx = FULL ? rs->x : rs->cand;
+    if (tid == 0) s_ctx = at_x ? rs->x : rs->cand;
     __syncthreads();
     double acc0 = 0.0, acc1 = 0.0;
     const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
             if (used) {
                 const size_t at = (size_t) i * rb.cap + k;
                 const Vec3 ref{rb.ref[at], rb.ref[ncap + at], rb.ref[2 * ncap + at]};
-                r = ct_residual<FULL>(s_ctx, alpha, raw, ref, m, J);
+                r = ct_residual<true>(s_ctx, alpha, raw, ref, m, J);
                 const double s = r * r;
                 if (prm.loss == LOSS_STANDARD) {
                     cost = 0.5 * s;
@@ -346,60 +349,43 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
                     double rho[3];
                     loss_evaluate(prm.loss, prm.sigma, prm.tol_min, s, rho);
                     cost = 0.5 * rho[0];
-                    if (FULL) {
-                        const double sqrt_rho1 = sqrt(rho[1]);
-                        double residual_scaling, alpha_sq_norm;
-                        if (s == 0.0 || rho[2] <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
-                        else {
-                            const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
-                            const double al = 1.0 - sqrt(D);
-                            residual_scaling = sqrt_rho1 / (1.0 - al);
-                            alpha_sq_norm = al / s;
-                        }
-                        const double js = sqrt_rho1 * (1.0 - alpha_sq_norm * s);
-#pragma unroll
-                        for (int c = 0; c < 12; ++c) J[c] *= js;
-                        r *= residual_scaling;
+                    const double sqrt_rho1 = sqrt(rho[1]);
+                    double residual_scaling, alpha_sq_norm;
+                    if (s == 0.0 || rho[2] <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
+                    else {
+                        const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+                        const double al = 1.0 - sqrt(D);
+                        residual_scaling = sqrt_rho1 / (1.0 - al);
+                        alpha_sq_norm = al / s;
                     }
+                    const double js = sqrt_rho1 * (1.0 - alpha_sq_norm * s);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) J[c] *= js;
+                    r *= residual_scaling;
                 }
             }
-            if (FULL) {
-                double *rec = s_rec[wave];
-                double *my = rec + lane * EVAL_REC;
+            double *rec = s_rec[wave];
+            double *my = rec + lane * EVAL_REC;
 #pragma unroll
-                for (int c = 0; c < 12; ++c) my[c] = used ? J[c] : 0.0;
-                my[12] = used ? r : 0.0;
-                my[13] = cost;
-                for (int j = 0; j < 64; ++j) {
-                    const double *rj = rec + j * EVAL_REC;
-                    acc0 += rj[e0i] * rj[e0j];
-                    if (e1kind == 0) acc1 += rj[e1i] * rj[e1j];
-                    else if (e1kind == 1) acc1 -= rj[e1i] * rj[12];
-                    else if (e1kind == 2) acc1 += rj[13];
-                }
-            } else {
-                acc1 += cost;                   // every lane: its own blocks
+            for (int c = 0; c < 12; ++c) my[c] = used ? J[c] : 0.0;
+            my[12] = used ? r : 0.0;
+            my[13] = cost;
+            for (int j = 0; j < 64; ++j) {
+                const double *rj = rec + j * EVAL_REC;
+                acc0 += rj[e0i] * rj[e0j];
+                if (e1kind == 0) acc1 += rj[e1i] * rj[e1j];
+                else if (e1kind == 1) acc1 -= rj[e1i] * rj[12];
+                else if (e1kind == 2) acc1 += rj[13];
             }
         }
     }
-    if (FULL) {
-        s_comb[wave][lane] = acc0;
-        if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
-        __syncthreads();
-        if (tid < SYS_N) {
-            double s = 0.0;
-            for (int w = 0; w < EVAL_BLOCK / 64; ++w) s += s_comb[w][tid];
-            partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
-        }
-    } else {
-        const double s = wave_sum_fixed(acc1);
-        if (lane == 0) s_comb[wave][0] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < EVAL_BLOCK / 64; ++w) t += s_comb[w][0];
-            partials[(size_t) 90 * MAX_PARTIAL_BLOCKS + blockIdx.x] = t;
-        }
+    s_comb[wave][lane] = acc0;
+    if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+    __syncthreads();
+    if (tid < SYS_N) {
+        double t = 0.0;
+        for (int w = 0; w < EVAL_BLOCK / 64; ++w) t += s_comb[w][tid];
+        partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = t;
     }
 }
 
@@ -504,39 +490,41 @@ __device__ __forceinline__ double wave_spd_solve12(double (&rowr)[12], double bi
 }
 
 // ================================================================================================
-// k_robust_step — one block.
-//   PHASE 0 (after k_robust_eval<true>):  reduce the partials, add the regularisers, run the checks of
-//            FinalizeIterationAndCheckIfMinimizerCanContinue, compute the Levenberg-Marquardt step and the candidate
-//   PHASE 1 (after k_robust_eval<false>): candidate cost, function tolerance, accept / reject, radius update
-// The 12x12 work runs on wave 0 with one matrix row per lane; only the quaternion bookkeeping is single-lane.
+// k_robust_step — one block, after every k_robust_eval:
+//   reduce the partials of the pose just evaluated (x at the start of a solve, otherwise the candidate) and add the
+//   regularisers; for a candidate: function tolerance, accept / reject, trust-region radius; then the checks of
+//   FinalizeIterationAndCheckIfMinimizerCanContinue, the next Levenberg-Marquardt step and the next candidate.
+// The 12x12 work runs on wave 0 with one matrix row per lane; only the quaternion bookkeeping is single-lane. The solver
+// state is staged in LDS for the whole kernel and written back once at the end: a dependent chain of global-memory
+// read-after-writes on one lane costs ~1 us per link on this part.
 // ================================================================================================
 constexpr int STEP_BLOCK = 1024;
 #define RWSYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-// The solver state is staged in LDS for the whole kernel and written back once at the end: a dependent chain of
-// global-memory read-after-writes on one lane costs ~1 us per link on this part.
-template <int PHASE>
 __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partials, int nblocks, GnState *st, RobustState *rs,
                                                              RobustParams prm) {
     __shared__ double s_sys[SYS_N];
     __shared__ __attribute__((aligned(8))) RobustState R;
+    __shared__ double s_Hc[144], s_gc[12];              // normal equations of the pose just evaluated
     __shared__ double s_delta[12];
     __shared__ int s_flag;
     static_assert(sizeof(RobustState) % 8 == 0, "RobustState is copied as doubles");
     constexpr int NW = (int) (sizeof(RobustState) / 8);
     if (st->done || rs->ls_done) return;
-    if (PHASE == 1 && !rs->step_valid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tc0 = __builtin_readcyclecounter();
     unsigned long long tc1 = tc0, tc2 = tc0, tc3 = tc0, tc4 = tc0, tc5 = tc0;
     for (int w = tid; w < NW; w += STEP_BLOCK) reinterpret_cast<double *>(&R)[w] = reinterpret_cast<const double *>(rs)[w];
+    __syncthreads();
+    const bool have_eval = R.eval_at_x || R.step_valid;        // did the preceding k_robust_eval run?
     // wave w sums entries w, w + 16, ... over the blocks: lane-strided, then a fixed shuffle tree (deterministic)
-    for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
-        if (PHASE == 1 && e != 90) continue;
-        double acc = 0.0;
-        for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
-        acc = wave_sum_fixed(acc);
-        if (lane == 0) s_sys[e] = acc;
+    if (have_eval) {
+        for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
+            double acc = 0.0;
+            for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
+            acc = wave_sum_fixed(acc);
+            if (lane == 0) s_sys[e] = acc;
+        }
     }
     __syncthreads();
     if (wave != 0) return;
@@ -546,117 +534,135 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
     const double max_radius = 1e16, min_radius = 1e-32;
     bool stop_all = false;                                 // lane 0: raise GnState::done
     tc1 = __builtin_readcyclecounter();
-    if (PHASE == 0) {
-        const int have_scale = R.have_scale;
-        const double radius = R.radius;
-        const int i = lane < 12 ? lane : 0;
+    const int have_scale = R.have_scale;
+    const int i = lane < 12 ? lane : 0;
+    if (have_eval) {
         for (int e = lane; e < 78; e += 64) {
             const int r = c_tri_i[e], c = c_tri_j[e];
-            R.H[12 * r + c] = s_sys[e];
-            R.H[12 * c + r] = s_sys[e];
+            s_Hc[12 * r + c] = s_sys[e];
+            s_Hc[12 * c + r] = s_sys[e];
         }
-        if (lane < 12) R.g[lane] = -s_sys[78 + lane];
-        RWSYNC();
-        if (lane == 0) {
-            const double cost = s_sys[90] + robust_regularisers(prm, R.n_res, R.x.pose, R.H, R.g);
-            R.x_cost = cost;
-            int flag = 0;
-            if (!isfinite(cost)) { R.error = 1; R.ls_done = 1; stop_all = true; flag = 1; }
-            else if (R.ls_iter >= prm.ls_max_iters) { R.ls_done = 1; R.ls_term = 0; flag = 1; }
-            else {
-                double neg[12], moved[14], mx = 0.0;              // gradient tolerance: max norm of x - Plus(x, -g)
-#pragma unroll
-                for (int c = 0; c < 12; ++c) neg[c] = -R.g[c];
-                pose_plus(R.x.pose, neg, moved);
-#pragma unroll
-                for (int c = 0; c < 14; ++c) mx = fmax(mx, fabs(R.x.pose[c] - moved[c]));
-                if (mx <= gradient_tolerance || radius < min_radius) { R.ls_done = 1; R.ls_term = 1; flag = 1; }
-            }
-            if (!flag) { R.ls_iter += 1; R.ls_iters_total += 1; }
-            s_flag = flag;
-        }
-        RWSYNC();
-        tc2 = __builtin_readcyclecounter();
-        // jacobi_scaling: from the first Jacobian of the solve only
-        const double sc_i = have_scale ? R.scale[i] : 1.0 / (1.0 + sqrt(R.H[13 * i]));
-        RWSYNC();
-        if (lane < 12) R.scale[lane] = sc_i;
-        if (lane == 0) R.have_scale = 1;
-        RWSYNC();
-        tc3 = __builtin_readcyclecounter();
-        if (!s_flag) {
-            // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian: (Hs + clamp(diag Hs) / radius) y = -gs
-            double rowr[12], hs[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) { hs[j] = sc_i * R.H[12 * i + j] * R.scale[j]; rowr[j] = hs[j]; }
-#pragma unroll
-            for (int j = 0; j < 12; ++j)
-                if (j == i) rowr[j] += fmin(fmax(hs[j], min_diag), max_diag) / radius;
-            const double gs_i = sc_i * R.g[i];
-            bool ok;
-            const double y = wave_spd_solve12(rowr, -gs_i, lane < 12 ? lane : 63, ok);
-            double row = 0.0;
-#pragma unroll
-            for (int j = 0; j < 12; ++j) row += hs[j] * CTGN_BCAST(y, j);
-            const double model_cost_change = -wave_sum_fixed(lane < 12 ? y * (gs_i + 0.5 * row) : 0.0);   // -(J y).(r + J y / 2)
-            const bool finite_all = __ballot(lane < 12 && !isfinite(y)) == 0ull;
-            ok = ok && finite_all && model_cost_change > 0.0;
-            if (lane < 12) s_delta[lane] = y * sc_i;
-            RWSYNC();
-            tc4 = __builtin_readcyclecounter();
-            if (lane == 0) {
-                if (!ok) {                                      // HandleInvalidStep
-                    R.step_valid = 0;
-                    if (++R.invalid >= 5) { R.error = 1; R.ls_done = 1; stop_all = true; }
-                    else R.radius = radius * 0.5;
-                } else {
-                    R.invalid = 0;
-                    R.model_cost_change = model_cost_change;
-                    double delta[12];
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) delta[c] = s_delta[c];
-                    pose_plus(R.x.pose, delta, R.cand.pose);
-                    pose_ctx_prepare(R.cand);
-                    R.step_valid = 1;
-                    double step2 = 0.0, x2 = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 14; ++c) {
-                        const double d = R.x.pose[c] - R.cand.pose[c];
-                        step2 += d * d;
-                        x2 += R.x.pose[c] * R.x.pose[c];
+        if (lane < 12) s_gc[lane] = -s_sys[78 + lane];
+    }
+    RWSYNC();
+    if (lane == 0) {
+        int flag = 0, take = 0;                            // take: s_Hc / s_gc become the current normal equations
+        if (have_eval) {
+            const double *pose_e = R.eval_at_x ? R.x.pose : R.cand.pose;
+            const double cost = s_sys[90] + robust_regularisers(prm, R.n_res, pose_e, s_Hc, s_gc);
+            if (R.eval_at_x) {                             // Ceres' iteration 0
+                R.x_cost = cost;
+                R.eval_at_x = 0;
+                take = 1;
+                if (!isfinite(cost)) { R.error = 1; R.ls_done = 1; stop_all = true; flag = 1; }
+            } else {                                       // the candidate of the step computed last time
+                R.cand_cost = cost;
+                const double cost_change = R.x_cost - cost;
+                if (fabs(cost_change) <= function_tolerance * R.x_cost) { R.ls_done = 1; R.ls_term = 1; flag = 1; }
+                else {
+                    const double rd = cost_change / R.model_cost_change;
+                    if (isfinite(cost) && rd > min_relative_decrease) {          // HandleSuccessfulStep
+                        R.x = R.cand;
+                        for (int c = 0; c < 14; ++c) st->pose[c] = R.cand.pose[c];
+                        st->slerp_theta = R.cand.theta; st->slerp_sin = R.cand.sin_theta;
+                        st->slerp_linear = R.cand.linear; st->slerp_negate = R.cand.negate;
+                        const double t = 2.0 * rd - 1.0, f = 1.0 - t * t * t;
+                        R.radius = fmin(max_radius, R.radius / fmax(1.0 / 3.0, f));
+                        R.decrease_factor = 2.0;
+                        R.ls_accepted_total += 1;
+                        R.x_cost = cost;
+                        take = 1;
+                    } else {                                                     // StepRejected
+                        R.radius = R.radius / R.decrease_factor;
+                        R.decrease_factor *= 2.0;
                     }
-                    if (sqrt(step2) <= parameter_tolerance * (sqrt(x2) + parameter_tolerance)) { R.ls_done = 1; R.ls_term = 1; }
                 }
+                R.step_valid = 0;
             }
         }
-    } else if (lane == 0) {
-        double cand_cost = s_sys[90];
-        cand_cost += robust_regularisers(prm, R.n_res, R.cand.pose, nullptr, nullptr);
-        R.cand_cost = cand_cost;
-        const double cost_change = R.x_cost - cand_cost;
-        if (fabs(cost_change) <= function_tolerance * R.x_cost) { R.ls_done = 1; R.ls_term = 1; }
+        s_flag = flag | (take << 1);
+    }
+    RWSYNC();
+    if (s_flag & 2) {                                      // adopt the evaluated normal equations
+        for (int e = lane; e < 144; e += 64) R.H[e] = s_Hc[e];
+        if (lane < 12) R.g[lane] = s_gc[lane];
+    }
+    RWSYNC();
+    const double radius = R.radius;
+    if (lane == 0 && !(s_flag & 1)) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        int flag = 0;
+        if (R.ls_iter >= prm.ls_max_iters) { R.ls_done = 1; R.ls_term = 0; flag = 1; }
         else {
-            const double rd = cost_change / R.model_cost_change;
-            if (isfinite(cand_cost) && rd > min_relative_decrease) {             // HandleSuccessfulStep
-                R.x = R.cand;
-                for (int c = 0; c < 14; ++c) st->pose[c] = R.cand.pose[c];
-                st->slerp_theta = R.cand.theta; st->slerp_sin = R.cand.sin_theta;
-                st->slerp_linear = R.cand.linear; st->slerp_negate = R.cand.negate;
-                const double t = 2.0 * rd - 1.0, f = 1.0 - t * t * t;
-                R.radius = fmin(max_radius, R.radius / fmax(1.0 / 3.0, f));
-                R.decrease_factor = 2.0;
-                R.ls_accepted_total += 1;
-                R.x_cost = cand_cost;
-            } else {                                                             // StepRejected
-                R.radius = R.radius / R.decrease_factor;
-                R.decrease_factor *= 2.0;
+            double neg[12], moved[14], mx = 0.0;              // gradient tolerance: max norm of x - Plus(x, -g)
+#pragma unroll
+            for (int c = 0; c < 12; ++c) neg[c] = -R.g[c];
+            pose_plus(R.x.pose, neg, moved);
+#pragma unroll
+            for (int c = 0; c < 14; ++c) mx = fmax(mx, fabs(R.x.pose[c] - moved[c]));
+            if (mx <= gradient_tolerance || radius < min_radius) { R.ls_done = 1; R.ls_term = 1; flag = 1; }
+        }
+        if (!flag) { R.ls_iter += 1; R.ls_iters_total += 1; }
+        s_flag = flag;
+    }
+    RWSYNC();
+    tc2 = __builtin_readcyclecounter();
+    // jacobi_scaling: from the first Jacobian of the solve only
+    const double sc_i = have_scale ? R.scale[i] : 1.0 / (1.0 + sqrt(R.H[13 * i]));
+    RWSYNC();
+    if (lane < 12) R.scale[lane] = sc_i;
+    if (lane == 0) R.have_scale = 1;
+    RWSYNC();
+    tc3 = __builtin_readcyclecounter();
+    tc4 = tc3;
+    if (!(s_flag & 1)) {
+        // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian: (Hs + clamp(diag Hs) / radius) y = -gs
+        double rowr[12], hs[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { hs[j] = sc_i * R.H[12 * i + j] * R.scale[j]; rowr[j] = hs[j]; }
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            if (j == i) rowr[j] += fmin(fmax(hs[j], min_diag), max_diag) / radius;
+        const double gs_i = sc_i * R.g[i];
+        bool ok;
+        const double y = wave_spd_solve12(rowr, -gs_i, lane < 12 ? lane : 63, ok);
+        double row = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) row += hs[j] * CTGN_BCAST(y, j);
+        const double model_cost_change = -wave_sum_fixed(lane < 12 ? y * (gs_i + 0.5 * row) : 0.0);   // -(J y).(r + J y / 2)
+        const bool finite_all = __ballot(lane < 12 && !isfinite(y)) == 0ull;
+        ok = ok && finite_all && model_cost_change > 0.0;
+        if (lane < 12) s_delta[lane] = y * sc_i;
+        RWSYNC();
+        tc4 = __builtin_readcyclecounter();
+        if (lane == 0) {
+            if (!ok) {                                      // HandleInvalidStep
+                R.step_valid = 0;
+                if (++R.invalid >= 5) { R.error = 1; R.ls_done = 1; stop_all = true; }
+                else R.radius = radius * 0.5;
+            } else {
+                R.invalid = 0;
+                R.model_cost_change = model_cost_change;
+                double delta[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) delta[c] = s_delta[c];
+                pose_plus(R.x.pose, delta, R.cand.pose);
+                pose_ctx_prepare(R.cand);
+                R.step_valid = 1;
+                double step2 = 0.0, x2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 14; ++c) {
+                    const double d = R.x.pose[c] - R.cand.pose[c];
+                    step2 += d * d;
+                    x2 += R.x.pose[c] * R.x.pose[c];
+                }
+                if (sqrt(step2) <= parameter_tolerance * (sqrt(x2) + parameter_tolerance)) { R.ls_done = 1; R.ls_term = 1; }
             }
-            R.step_valid = 0;
         }
     }
     RWSYNC();
     tc5 = __builtin_readcyclecounter();
-    if (PHASE == 0 && lane == 0) {
+    if (lane == 0) {
         R.step_cycles[0] = tc1 - tc0; R.step_cycles[1] = tc2 - tc1; R.step_cycles[2] = tc3 - tc2; R.step_cycles[3] = tc4 - tc3;
         R.step_cycles[4] = tc5 - tc4;
     }
@@ -715,6 +721,7 @@ __global__ void k_robust_init(const GnState *st, RobustState *rs) {
     rs->x_cost = 0.0; rs->cand_cost = 0.0; rs->model_cost_change = 0.0; rs->radius = 1e4; rs->decrease_factor = 2.0;
     rs->diff_trans = 0.0; rs->diff_rot = 0.0;
     rs->have_scale = 0; rs->ls_iter = 0; rs->ls_done = 0; rs->ls_term = 0; rs->invalid = 0; rs->step_valid = 0;
+    rs->eval_at_x = 1; rs->_pad0 = 0;
     rs->ls_iters_total = 0; rs->ls_accepted_total = 0;
     rs->n_res = 0; rs->icp_iter = 0; rs->error = 0; rs->converged = 0;
     for (int i = 0; i < 144; ++i) rs->H[i] = 0.0;
