@@ -896,8 +896,9 @@ inline size_t rows_kernel_smem() {
 // all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
 // ================================================================================================
 constexpr int RES_BLOCK = 256;
+constexpr int GG = 8;                // neighbours gathered per group: 3 x GG independent loads in flight per lane
 
-__global__ __launch_bounds__(RES_BLOCK) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
+__global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                  double *partials, DebugView dbg, int ablate) {
     __shared__ double s_rec[RES_BLOCK / 64][64 * 13];
     __shared__ double s_comb[RES_BLOCK / 64][SYS_N];
@@ -934,20 +935,20 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual_reduce(MapView map, KpVi
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int g = 0; g < KMAX / 8; ++g) {
-                if (8 * g < res_n) {
-                    double gx[8], gy[8], gz[8];
+            for (int g = 0; g < KMAX / GG; ++g) {
+                if (GG * g < res_n) {
+                    double gx[GG], gy[GG], gz[GG];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const uint32_t off = (8 * g + q < res_n) ? rec32[1 + 8 * g + q] : 0u;
+                    for (int q = 0; q < GG; ++q) {
+                        const uint32_t off = (GG * g + q < res_n) ? rec32[1 + GG * g + q] : 0u;
                         gx[q] = *reinterpret_cast<const double *>(pbase + off);
                         gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
                         gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
                     }
                     if (g == 0) res_q = Vec3{gx[0], gy[0], gz[0]};      // points[0]: the farthest kept (ct_icp.cpp:791)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (8 * g + q < res_n) {
+                    for (int q = 0; q < GG; ++q) {
+                        if (GG * g + q < res_n) {
                             const double x = gx[q], y = gy[q], z = gz[q];
                             res_S.x += x; res_S.y += y; res_S.z += z;
                             res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
