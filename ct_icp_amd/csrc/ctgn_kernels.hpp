@@ -891,7 +891,8 @@ inline size_t rows_kernel_smem() {
 // k_residual_reduce — second half of the accumulate step for the row kernel: one lane per keypoint.
 //   reads the keypoint's neighbour set (count + block-storage offsets, nearest first) left by k_accumulate_rows,
 //   gathers the points, sums mean / covariance in the reference's order, 3x3 eigen-solve -> normal + a2D, gates,
-//   residual, 12-vector u (ct_icp.cpp:769-841), then the packed u u^T | -u r | count per block (:843-850).
+//   residual, 12-vector u (ct_icp.cpp:769-841), then the packed u u^T | -u r | count per block (:843-850) as the 13 x 13
+//   product U^T U of the wave's 64 records on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64).
 // Splitting it off keeps the neighbour-search kernel free of the eigen-solver's registers and runs this part with
 // all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
 // ================================================================================================
@@ -907,13 +908,9 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
     const uint32_t blk8 = (uint32_t) map.blk * 8u;
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
-    // entry descriptors: e0 = lane (< 78: upper-tri product), e1 = lane + 64 (product | -u_i * r | count | none)
-    double acc0 = 0.0, acc1 = 0.0;
-    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
-    int e1i = 0, e1j = 0, e1kind = 2;          // kind 0: product, 1: -u*r, 2: count / none
-    double e1sign = 1.0;
-    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
-    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; e1sign = -1.0; }
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    d4_t accm = {0.0, 0.0, 0.0, 0.0};
+    int n_used_wave = 0;
     const int ntiles = (kp.n + RES_BLOCK - 1) / RES_BLOCK;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int my_kp = tile * RES_BLOCK + tid;
@@ -971,24 +968,38 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                 dbg.used[my_kp] = used ? 1 : 0;
             }
         }
-        // packed u u^T | -u r | count: each wave stages its 64 records in LDS and every lane sums the 1-2 packed
-        // entries it owns over them (LDS-transposed accumulation; fixed order)
+        // packed u u^T | -u r | count. With U the wave's 64 x 13 matrix of records (u | r), the sums are the 13 x 13 product
+        // U^T U: sixteen v_mfma_f64_16x16x4_f64 per tile, K = 4 keypoints each; lane l feeds U[k0 + (l >> 4)][l & 15] as both
+        // A[i = l & 15][k] and B[k][j = l & 15] (one LDS read per lane and step — the lane-per-entry loop this replaces read
+        // four doubles per lane and keypoint and was bound by LDS bandwidth). Accumulation order is fixed: deterministic.
         double *rec = s_rec[wave];
         double *my = rec + lane * 13;
 #pragma unroll
         for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
         my[12] = used ? rr : 0.0;
-        const unsigned long long ub = __ballot(used);
-        for (int j = 0; j < ((ablate & 128) ? 0 : 64); ++j) {
-            const double *rj = rec + j * 13;
-            acc0 += rj[e0i] * rj[e0j];
-            if (e1kind != 2) acc1 += e1sign * rj[e1i] * rj[e1j];
+        n_used_wave += __popcll(__ballot(used));
+        if (!(ablate & 128)) {
+            const int comp = lane & 15;
+#pragma unroll 4
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const double v = (comp < 13) ? rec[(k0 + (lane >> 4)) * 13 + comp] : 0.0;
+                accm = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accm, 0, 0, 0);
+            }
         }
-        if (e1kind == 2 && lane == 26) acc1 += (double) __popcll(ub);
     }
-    // block combine: fixed order over the waves
-    s_comb[wave][lane] = acc0;
-    if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+    // block combine: lane l holds (U^T U)[row = (l >> 4) + 4 m][col = l & 15], m = 0..3 (the f64 MFMA's C/D layout); the upper
+    // triangle goes to the packed entries, column 12 (sum u_i r) to -J^T r; fixed order over the waves
+    if (lane < SYS_N - SYS_USED) s_comb[wave][SYS_USED + lane] = 0.0;
+    {
+        const int col = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = (lane >> 4) + 4 * m;
+            if (row < 12 && col >= row && col < 12) s_comb[wave][row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
+            if (row < 12 && col == 12) s_comb[wave][78 + row] = -accm[m];
+        }
+        if (lane == 0) s_comb[wave][90] = (double) n_used_wave;
+    }
     __syncthreads();
     if (tid < SYS_N) {
         double s = 0.0;
