@@ -313,12 +313,8 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ctx = at_x ? rs->x : rs->cand;
     __syncthreads();
-    double acc0 = 0.0, acc1 = 0.0;
-    const int e0i = c_tri_i[lane], e0j = c_tri_j[lane];
-    int e1i = 0, e1j = 0, e1kind = 3;          // 0: product, 1: -J_i * r, 2: cost, 3: none
-    if (lane + 64 < 78) { e1i = c_tri_i[lane + 64]; e1j = c_tri_j[lane + 64]; e1kind = 0; }
-    else if (lane + 64 < 90) { e1i = lane + 64 - 78; e1j = 12; e1kind = 1; }
-    else if (lane + 64 == 90) { e1kind = 2; }
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    d4_t accm = {0.0, 0.0, 0.0, 0.0};
     const int ntiles = (kp.n + EVAL_BLOCK - 1) / EVAL_BLOCK;
     const size_t ncap = (size_t) prm.num_closest * rb.cap;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -364,23 +360,34 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
                     r *= residual_scaling;
                 }
             }
+            // U = the wave's 64 x 15 records (J | r | cost | 1): the packed sums are entries of U^T U, sixteen FP64 MFMAs
+            // (see k_residual_reduce); cost rides along as (U^T U)[13][14]
             double *rec = s_rec[wave];
             double *my = rec + lane * EVAL_REC;
 #pragma unroll
             for (int c = 0; c < 12; ++c) my[c] = used ? J[c] : 0.0;
             my[12] = used ? r : 0.0;
             my[13] = cost;
-            for (int j = 0; j < 64; ++j) {
-                const double *rj = rec + j * EVAL_REC;
-                acc0 += rj[e0i] * rj[e0j];
-                if (e1kind == 0) acc1 += rj[e1i] * rj[e1j];
-                else if (e1kind == 1) acc1 -= rj[e1i] * rj[12];
-                else if (e1kind == 2) acc1 += rj[13];
+            my[14] = 1.0;
+            const int comp = lane & 15;
+#pragma unroll 4
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const double v = (comp < EVAL_REC) ? rec[(k0 + (lane >> 4)) * EVAL_REC + comp] : 0.0;
+                accm = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accm, 0, 0, 0);
             }
         }
     }
-    s_comb[wave][lane] = acc0;
-    if (lane < SYS_N - 64) s_comb[wave][64 + lane] = (lane + 64 < SYS_USED) ? acc1 : 0.0;
+    if (lane < SYS_N - SYS_USED) s_comb[wave][SYS_USED + lane] = 0.0;
+    {
+        const int col = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = (lane >> 4) + 4 * m;
+            if (row < 12 && col >= row && col < 12) s_comb[wave][row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
+            if (row < 12 && col == 12) s_comb[wave][78 + row] = -accm[m];
+            if (row == 13 && col == 14) s_comb[wave][90] = accm[m];
+        }
+    }
     __syncthreads();
     if (tid < SYS_N) {
         double t = 0.0;
