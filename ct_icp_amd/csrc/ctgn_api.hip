@@ -38,6 +38,11 @@ struct EventPair {
 // phase counters (12, padded to 16) + {start, end, fast rounds, rounds} per wave of the last instrumented launch
 constexpr size_t PROF_WORDS = 16 + 4 * (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES;
 
+// doubles kept behind the 7 keypoint arrays: [0,16) the input pose of a ctgn_register call (it rides in with the keypoints),
+// [16, ...) the final GnState (it rides out with the world points)
+constexpr size_t KP_TAIL = 16 + (sizeof(GnState) + 7) / 8;
+static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState is mirrored by one thread block as doubles");
+
 struct ctgn_context {
     int device = -1;                    // -1: host-only map mirror, every device entry point fails
     int num_cus = 256;
@@ -54,6 +59,8 @@ struct ctgn_context {
     // back to back, so that one copy moves the whole set (and one copy brings the three world arrays back)
     int n_kp = 0, cap_kp = 0, kp_stride = 0;
     bool prefetch_world = false;        // ctgn_register*: bring the world points back with the final state, one sync
+    const double *pose_with_kp = nullptr;   // ctgn_register: pose to append to the keypoint upload (one copy instead of two)
+    bool pose_on_device = false;            // ... and it has been uploaded behind the keypoint arrays
     double *d_kp = nullptr;
     uint32_t *d_res = nullptr;          // [cap_kp][SEL_STRIDE] row-phase -> lane-phase hand-over records
     double *h_kp = nullptr;             // pinned staging, same layout
@@ -769,6 +776,7 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     NEED_DEVICE(h);
     if (n > 0 && (!raw.base || !world.base || !ts.base)) return CTGN_ERR_INVALID_ARGUMENT;
     if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
+    h->pose_on_device = false;
     const bool dev = n > 0 && on_device(raw.base);
     if (n > 0 && (on_device(world.base) != dev || on_device(ts.base) != dev))
         return fail(h, CTGN_ERR_UNSUPPORTED, "the raw, world and timestamp views must all be host memory or all be device memory");
@@ -779,9 +787,9 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         if (h->h_kp) HIPCHK(h, hipHostFree(h->h_kp));
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), cap * 7 * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), (cap * 7 + KP_TAIL) * sizeof(double)));
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), cap * SEL_STRIDE * sizeof(uint32_t)));
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), cap * 7 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
     h->n_kp = (int) n;
@@ -810,7 +818,14 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         if (t != t) tmax = NAN;
     }
     h->t_min = tmin; h->t_max = tmax;
-    if (n) HIPCHK(h, hipMemcpyAsync(h->d_kp, h->h_kp, 7 * c * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->pose_on_device = false;
+    size_t words = 7 * c;
+    if (n && h->pose_with_kp) {                    // ctgn_register: the pose shares the upload
+        for (int i = 0; i < 14; ++i) h->h_kp[7 * c + i] = h->pose_with_kp[i];
+        words += 16;
+        h->pose_on_device = true;
+    }
+    if (n) HIPCHK(h, hipMemcpyAsync(h->d_kp, h->h_kp, words * sizeof(double), hipMemcpyHostToDevice, h->stream));
     ctgn_status st = ensure_debug(h);
     if (st != CTGN_OK) return st;
     return CTGN_OK;
@@ -868,9 +883,15 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     // h_pose_in is reused: every other user synchronises before returning, only an unfinished stepwise loop can still
     // have a copy from it in flight
     if (h->gn_active) HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
-    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);
+    const double *d_pose = h->d_pose_in;
+    if (h->pose_on_device) {                          // already behind the keypoint arrays (ctgn_register)
+        d_pose = h->d_kp + 7 * (size_t) h->kp_stride;
+        h->pose_on_device = false;
+    } else {
+        for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
+        HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
     h->launched_iters = 0;
     h->events_used = 0;
@@ -923,16 +944,24 @@ ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done) {
 ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summary) {
     NEED_DEVICE(h);
     if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
+    const bool merged = h->prefetch_world && h->n_kp > 0;      // world points + state in ONE device-to-host copy
+    const size_t c = (size_t) h->kp_stride;
     if (h->n_kp > 0) {
         const int grid = std::max(1, std::min((h->n_kp + 255) / 256, 2048));
-        hipLaunchKernelGGL(k_transform, dim3(grid), dim3(256), 0, h->stream, kp_view(h), h->d_state);
+        hipLaunchKernelGGL(k_transform, dim3(grid), dim3(256), 0, h->stream, kp_view(h), h->d_state,
+                           merged ? h->d_kp + 7 * c + 16 : nullptr);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
-    if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
+    if (merged) {
+        HIPCHK(h, hipMemcpyAsync(h->h_kp + 4 * c, h->d_kp + 4 * c, (3 * c + KP_TAIL) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->gn_active = false;
+    if (merged) std::memcpy(h->h_state, h->h_kp + 7 * c + 16, sizeof(GnState));
     const GnState &s = *h->h_state;
     if (h->profiling) harvest_events(h, s.iter + (s.failed ? 1 : 0));
     if (h->gn_opts.debug_print > 1)
@@ -1075,11 +1104,14 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t
                           ctgn_view ts, size_t n, double pose_io[14], const double tbe[2], const ctgn_options *opts,
                           const ctgn_motion_prior *prior, ctgn_summary *summary) {
     ctgn_view world{world_base, world_stride, world_dtype, 0};
+    if (h) h->pose_with_kp = pose_io;              // host views: the pose rides in with the keypoints, one upload
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
-    if (st != CTGN_OK) return st;
+    if (h) h->pose_with_kp = nullptr;
+    if (st != CTGN_OK) { if (h) h->pose_on_device = false; return st; }
     const bool dev_world = n > 0 && on_device(world_base);
     h->prefetch_world = !dev_world;                // host views: world points ride back with the final state, one synchronisation
     st = ctgn_solve(h, pose_io, tbe, opts, prior, summary);
+    h->pose_on_device = false;
     h->prefetch_world = false;
     if (st != CTGN_OK) return st;
     if (dev_world) return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);

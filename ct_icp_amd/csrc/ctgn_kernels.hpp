@@ -62,7 +62,7 @@ struct GnParams {
     double prev_b[3], prev_e[3];
 };
 
-struct GnState {
+struct alignas(8) GnState {
     double pose[14];         // begin (qx qy qz qw tx ty tz) | end
     double tbe[2];
     double slerp_theta, slerp_sin;
@@ -1256,7 +1256,11 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
 #undef WSYNC
 
 // Re-transform every keypoint with the final pose (ct_icp.cpp:964-966 of the last executed iteration).
-__global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st) {
+// state_copy (optional): the GnState is mirrored right behind the world arrays so that one device-to-host copy brings
+// back both the world points and the final state.
+__global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st, double *state_copy = nullptr) {
+    if (state_copy && blockIdx.x == 0 && threadIdx.x < sizeof(GnState) / 8)
+        state_copy[threadIdx.x] = reinterpret_cast<const double *>(st)[threadIdx.x];
     if (st->failed || st->iter == 0) return;      // failure: world points stay as the failing iteration saw them
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.n; i += gridDim.x * blockDim.x) {
         Vec3 raw{kp.rx[i], kp.ry[i], kp.rz[i]};
