@@ -179,3 +179,35 @@ def test_soft_failure_and_errors(box_case):
     s.set_keypoints(raw, se3.ct_transform(pose0, sc.t_begin_end, t, raw), t)
     _, sg, _ = s.solve(pose0, sc.t_begin_end, cia.CTICPOptions(solver=cia.GN, debug_print=False, min_number_neighbors=10))
     assert sg.success
+
+
+def test_full_scan_properties(street_case):
+    """Size-independent properties on a whole scan (every return a keypoint, no oracle needed): the solve is invariant under a
+    permutation of the keypoints (no cap), the cost never rises with more inner iterations, and the world points it leaves are
+    the continuous-time transform of the raw points by the pose it returns."""
+    case = street_case
+    _, gm = build_maps(case, 6, with_gpu=True)
+    sc = case["scans"][6]
+    raw, t = sc.raw, sc.t
+    assert len(t) > 30000
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=11)
+    s = cia.GnSolver(gm)
+    costs, poses = [], []
+    for ls in (0, 1, 2, 4):
+        o = _opts(num_iters_icp=1, ls_max_num_iters=ls, min_number_neighbors=20)
+        s.set_keypoints(raw, np.zeros_like(raw), t)
+        pose, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o)
+        rep = s.robust_report()
+        costs.append(rep["cost"])
+        poses.append(pose)
+        assert summ.success and summ.num_residuals_used > 20000
+    assert all(c1 <= c0 * (1 + 1e-12) for c0, c1 in zip(costs, costs[1:])), costs
+    assert costs[-1] < 0.9 * costs[0]
+    world = s.world_points()
+    assert np.abs(world - se3.ct_transform(poses[-1], sc.t_begin_end, t, raw)).max() < 1e-9
+    perm = np.random.default_rng(3).permutation(len(t))
+    s.set_keypoints(raw[perm], np.zeros_like(raw), t[perm])
+    pose_p, summ_p, _ = s.solve_robust(pose0, sc.t_begin_end, _opts(num_iters_icp=1, ls_max_num_iters=4, min_number_neighbors=20))
+    tr, rot = se3.pose_error(pose_p, poses[-1])
+    assert tr < 1e-9 and rot < 1e-9, (tr, rot)
+    assert summ_p.num_residuals_used == summ.num_residuals_used
