@@ -325,7 +325,7 @@ def main():
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["frame_stages"] = measure_frame_stages(cia, inp, syn, se3, local_rank)
-        if not args.no_cpu_baseline and args.workload == "B2":
+        if not args.no_cpu_baseline and args.workload == "B2" and world == 1:      # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
