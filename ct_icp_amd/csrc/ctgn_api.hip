@@ -998,9 +998,31 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
     }
     MapView mv;
     st = make_map_view(h, -1.0, &mv);
+    // Measurement hook (CTGN_GRAPH=1): run the iteration loop as one hipGraph captured from the stream. Kept out of the default
+    // path: the loop is bound by the GPU-side latency of its dependent launches, not by host launch cost.
+    static const bool use_graph = std::getenv("CTGN_GRAPH") != nullptr;
+    const bool capture = use_graph && st == CTGN_OK && !h->profiling && h->variant != 3;
+    hipGraph_t graph = nullptr;
+    if (capture && hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+        return fail(h, CTGN_ERR_HIP, "[HIP] hipStreamBeginCapture");
     for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {       // ct_icp.cpp:745
         st = launch_accumulate(h, mv, it == 0);
         if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
+    }
+    if (capture) {
+        hipGraphExec_t exec = nullptr;
+        const auto tg0 = std::chrono::steady_clock::now();
+        bool ok = hipStreamEndCapture(h->stream, &graph) == hipSuccess && graph &&
+                  hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        const auto tg1 = std::chrono::steady_clock::now();
+        ok = ok && hipGraphLaunch(exec, h->stream) == hipSuccess;
+        if (opts->debug_print > 1)
+            std::fprintf(stderr, "[ctgn] hipGraph: end-capture + instantiate %.1f us\n",
+                         std::chrono::duration<double, std::micro>(tg1 - tg0).count());
+        if (ok) hipStreamSynchronize(h->stream);
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) st = fail(h, CTGN_ERR_HIP, "[HIP] graph capture / launch failed");
     }
     if (st != CTGN_OK) {
         h->gn_active = false;
