@@ -18,6 +18,11 @@ def golden():
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "gn_small.npz")))
 
 
+@pytest.fixture(scope="session")
+def golden_robust():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "robust_small.npz")))
+
+
 def _sphere_pattern(n_az, n_el, el_lim=75.0):
     el = np.radians(np.linspace(-el_lim, el_lim, n_el))
     az = np.linspace(0, 2 * np.pi, n_az, endpoint=False)

@@ -211,3 +211,38 @@ def test_full_scan_properties(street_case):
     tr, rot = se3.pose_error(pose_p, poses[-1])
     assert tr < 1e-9 and rot < 1e-9, (tr, rot)
     assert summ_p.num_residuals_used == summ.num_residuals_used
+
+
+def test_golden_vectors_through_the_gpu(golden, golden_robust):
+    """tests/golden/robust_small.npz (NumPy/SciPy derivation, no oracle involved): blocks, weights, cost, normal equations."""
+    g, gr = golden, golden_robust
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(float(g["resolution"]), float(g["min_dist"]),
+                                                                                  int(g["max_pts"]))], default_radius=float(g["radius"])))
+    gm.InsertPointCloud(g["insert_points"])
+    betas = gr["betas"]
+    mm = cia.PreviousFrameMotionModel(beta_location_consistency=betas[0], beta_constant_velocity=betas[1], beta_small_velocity=betas[2],
+                                      beta_orientation_consistency=betas[3])
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([[0, 0, 0, 1], gr["prev_b"], gr["prev_q"], gr["prev_e"]]), 0.0, 0.0)
+    o = cia.CTICPOptions(solver=cia.CERES, debug_print=False, num_iters_icp=1, ls_max_num_iters=0, min_number_neighbors=int(g["min_nb"]),
+                         max_number_neighbors=int(g["k"]), loss_function="CAUCHY", ls_sigma=float(gr["sigma"]),
+                         weight_alpha=float(gr["weight_alpha"]), weight_neighborhood=float(gr["weight_neighborhood"]),
+                         power_planarity=float(gr["power_planarity"]), max_dist_to_plane_ct_icp=float(g["max_dist"]))
+    s = cia.GnSolver(gm)
+    s.set_keypoints(g["raw"], np.zeros_like(g["raw"]), g["t"])
+    _, summ, _ = s.solve_robust(gr["pose0"], g["tbe"], o, mm)
+    got = s.robust_blocks()
+    kp = gr["keypoint"]
+    assert summ.num_residuals_used == len(kp) and np.array_equal(np.nonzero(got["rank"] >= 0)[0], kp)
+    assert np.array_equal(got["ref"][kp], gr["ref"])
+    assert np.abs(got["weight"][kp] - gr["weight"]).max() < 1e-10
+    rep = s.robust_report()
+    assert abs(rep["cost"] - gr["cost"]) < 1e-9 * gr["cost"]
+    assert np.abs(rep["JtJ"] - gr["JtJ"]).max() < 1e-8 * np.abs(gr["JtJ"]).max()
+    assert np.abs(rep["Jtr"] - gr["Jtr"]).max() < 1e-8 * np.abs(gr["Jtr"]).max()
+    # and a full inner solve lands on SciPy's minimum of the same fixed blocks
+    o.ls_max_num_iters = 50
+    s.set_keypoints(g["raw"], np.zeros_like(g["raw"]), g["t"])
+    pose, _, _ = s.solve_robust(gr["pose0"], g["tbe"], o, mm)
+    assert s.robust_report()["cost"] <= float(gr["cost_opt"]) * (1 + 1e-5)
+    tr, rot = se3.pose_error(pose, gr["pose_opt"])
+    assert tr < 2e-3 and rot < 1e-3, (tr, rot)          # flat valley along the regularised directions; Ceres stops at 1e-6 relative

@@ -233,3 +233,44 @@ def test_register_robust_recovers_ground_truth(box_case):
     tiny = orc.RobustOptions(min_number_neighbors=10)
     _, _, s2 = orc.register_robust(om, raw[:3] * 100.0, t[:3], init, tuple(sc.t_begin_end), tiny)
     assert not s2.success and "not enough keypoints" in s2.error_log
+
+
+# ---------------------------------------------------------------- golden vectors (tests/golden/make_golden_robust.py)
+def _golden_setup(golden, golden_robust):
+    g, gr = golden, golden_robust
+    om = orc.Map(resolutions=[(float(g["resolution"]), float(g["min_dist"]), int(g["max_pts"]))], default_radius=float(g["radius"]))
+    om.insert(g["insert_points"])
+    betas = gr["betas"]
+    opts = orc.RobustOptions(num_iters_icp=1, ls_max_num_iters=0, min_number_neighbors=int(g["min_nb"]), max_number_neighbors=int(g["k"]),
+                             loss_function="CAUCHY", ls_sigma=float(gr["sigma"]), weight_alpha=float(gr["weight_alpha"]),
+                             weight_neighborhood=float(gr["weight_neighborhood"]), power_planarity=float(gr["power_planarity"]),
+                             max_dist_to_plane_ct_icp=float(g["max_dist"]))
+    prior = orc.RobustPrior(beta_location_consistency=betas[0], beta_constant_velocity=betas[1], beta_small_velocity=betas[2],
+                            beta_orientation_consistency=betas[3], previous_begin_tr=tuple(gr["prev_b"]),
+                            previous_end_tr=tuple(gr["prev_e"]), previous_end_quat=tuple(gr["prev_q"]))
+    return om, opts, prior
+
+
+def test_oracle_reproduces_the_numpy_golden_vectors(golden, golden_robust):
+    """Blocks, weights, cost and loss-corrected normal equations of the independent NumPy derivation; its SciPy minimiser."""
+    g, gr = golden, golden_robust
+    om, opts, prior = _golden_setup(g, gr)
+    pose0 = gr["pose0"]
+    world0 = orc.transform_points(pose0, g["tbe"], g["t"], g["raw"])
+    blocks = orc.robust_build(om, g["raw"], world0, g["t"], g["tbe"], opts, heap_mode=0)
+    assert np.array_equal(blocks["keypoint"], gr["keypoint"])
+    assert np.abs(blocks["ref"] - gr["ref"]).max() == 0.0
+    assert np.abs(blocks["weight"] - gr["weight"]).max() < 1e-10
+    assert np.abs(blocks["alpha"] - gr["alpha"]).max() < 1e-15
+    sign = np.sign(np.sum(blocks["normal"] * gr["normal"], axis=1))
+    planar = gr["weight"] > 0.1
+    assert np.abs(blocks["normal"][planar] * sign[planar, None] - gr["normal"][planar]).max() < 1e-8
+    cost, H, grad = orc.robust_evaluate(blocks, opts, prior, pose0)
+    assert abs(cost - gr["cost"]) < 1e-9 * gr["cost"]
+    assert np.abs(H - gr["JtJ"]).max() < 1e-8 * np.abs(gr["JtJ"]).max()
+    assert np.abs(grad - gr["Jtr"]).max() < 1e-8 * np.abs(gr["Jtr"]).max()
+    # the oracle's Levenberg-Marquardt on the same blocks reaches SciPy's minimum; its gradient vanishes there
+    pose, rep = orc.robust_solve_fixed(blocks, opts, prior, pose0, 100)
+    assert rep["final_cost"] <= float(gr["cost_opt"]) * (1 + 1e-5)
+    _, Ho, go = orc.robust_evaluate(blocks, opts, prior, gr["pose_opt"])
+    assert np.max(np.abs(go) / np.sqrt(np.diag(Ho))) < 1e-6 * np.sqrt(2 * float(gr["cost_opt"]))
