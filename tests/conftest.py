@@ -58,6 +58,24 @@ def street_case():
     return dict(scene=scene, knots=knots, scans=scans, resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
 
 
+@pytest.fixture(scope="session")
+def config_a_case():
+    """BASELINE.json configs[0]: the reference's synthetic courtyard (tests/golden/config_a.npz, generated from the reference's
+    own scene file by tests/golden/make_config_a.py) with the odometry values of config/synthetic_ct_icp_config.yaml as SURVEY.md
+    section 8d reads them: voxel_size 0.1, sample_voxel_size 0.5, map 0.5 m x 20 pts, min distance 0.05, radius 0.8 (125 voxels)."""
+    from ct_icp_amd import se3, synthetic as syn
+    d = dict(np.load(os.path.join(ROOT, "tests", "golden", "config_a.npz")))
+    offs = np.concatenate([[0], np.cumsum(d["counts"])])
+    scans = []
+    for j in range(len(d["counts"])):
+        raw, t = d["raw"][offs[j]:offs[j + 1]], d["t"][offs[j]:offs[j + 1]]
+        keep = np.sort(syn.grid_sample_indices(raw, 0.1))                         # odometry voxel_size
+        raw, t = raw[keep], t[keep]
+        scans.append(syn.Scan(raw=raw, t=t, world_gt=se3.ct_transform(d["pose_gt"][j], d["tbe"][j], t, raw), pose_gt=d["pose_gt"][j],
+                              t_begin_end=d["tbe"][j]))
+    return dict(scans=scans, resolutions=[(0.5, 0.05, 20)], default_radius=0.8, sample_voxel_size=0.5)
+
+
 def build_maps(case, n_map_frames, with_gpu=False, device=0, subsample=None):
     """Insert the first n_map_frames scans (ground-truth world points) into an oracle map and, optionally, a
     GpuVoxelMap, through their own insert rules."""

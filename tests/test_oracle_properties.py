@@ -335,3 +335,30 @@ def test_reference_shaped_variant_gives_the_same_system(street_case):
         assert n2 == n and n > 300
         tol = 0.0 if threads == 1 else 1e-12 * np.abs(A).max()
         assert np.abs(A2 - A).max() <= tol and np.abs(b2 - b).max() <= tol + (0 if threads == 1 else 1e-15)
+
+
+def test_config_a_reference_scene(config_a_case):
+    """BASELINE.json configs[0] — the reference's own synthetic courtyard, GN solver, 30 iterations (the plumbing config): the
+    oracle registers a frame against a map of the four preceding ones and recovers the ground-truth motion (cf. the reference's
+    integration test, test/integration/testint_odometry.cpp:57-88); so does the robust-loss route."""
+    from conftest import build_maps
+    from ct_icp_amd import se3, synthetic as syn
+    case = config_a_case
+    om, _ = build_maps(case, 4)
+    sc = case["scans"][4]
+    sel = np.sort(syn.grid_sample_indices(sc.raw, case["sample_voxel_size"]))
+    raw, t = sc.raw[sel], sc.t[sel]
+    assert len(t) > 800
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.01, 0.05, seed=1)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    o = orc.Options(num_iters_icp=30, min_number_neighbors=20, max_number_neighbors=20, threshold_orientation_norm=1e-6)
+    pose, world, s = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, o, None)
+    assert s.success and s.num_residuals_used > 300
+    tr, rot = se3.pose_error(pose, sc.pose_gt)
+    tr0, rot0 = se3.pose_error(pose0, sc.pose_gt)
+    assert tr < 0.7 * tr0 and rot < 0.5 * rot0, (tr, rot, tr0, rot0)      # sparse random samples, poles and spheres in the scene
+    ro = orc.RobustOptions(num_iters_icp=30, ls_max_num_iters=5, min_number_neighbors=20, threshold_orientation_norm=1e-5,
+                           threshold_translation_norm=1e-6)
+    pose_r, _, sr = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, ro)
+    tr_r, rot_r = se3.pose_error(pose_r, sc.pose_gt)
+    assert sr.success and tr_r < 0.7 * tr0 and rot_r < 0.5 * rot0, (tr_r, rot_r)
