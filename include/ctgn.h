@@ -6,12 +6,15 @@
  * together with the read side of the local voxel map it queries
  *   ct_icp::MultipleResolutionVoxelMap::RadiusSearchInPlace (reference include/ct_icp/map.h:449-514)
  * and the write side needed to keep that map resident on the GPU
- *   InsertPointInVoxelMap / RemoveElementsFarFromLocation  (reference include/ct_icp/map.h:261-293, 305-322).
+ *   InsertPointInVoxelMap / RemoveElementsFarFromLocation  (reference include/ct_icp/map.h:261-293, 305-322),
+ * plus the rows either side of the path: grid sampling, full-scan undistortion, device-resident map
+ * maintenance, and the robust-loss route the shipped configs select
+ *   ct_icp::CT_ICP_Registration::DoRegisterCeres          (reference src/ct_icp/ct_icp.cpp:457-707; ctgn_register_robust).
  *
  * The reference has no C ABI / FFI for this path (it is C++ member calls inside libCT_ICP.so), so the
  * entry points below are what a maintainer would bind from
  *   - a `GpuVoxelMap : ct_icp::ISlamMap` (reference include/ct_icp/map.h:14-83) -> ctgn_map_* calls
- *   - the `case GN:` arm of SELECT_SOLVER (reference src/ct_icp/ct_icp.cpp:1008-1014) -> ctgn_register
+ *   - the `case GN:` / `case CERES:` arms of SELECT_SOLVER (reference src/ct_icp/ct_icp.cpp:1003-1014) -> ctgn_register / ctgn_register_robust
  * INTEGRATION.md shows that binding; ct_icp_amd/cpp/ct_icp_gpu.hpp is the C++ adapter.
  *
  * Conventions
