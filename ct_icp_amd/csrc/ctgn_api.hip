@@ -1235,9 +1235,15 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     h->prm.max_nb = o->max_number_neighbors;
 
     if (h->gn_active) { HIPCHK(h, hipStreamSynchronize(h->stream)); h->gn_active = false; }
-    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
-    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_pose_in, tbe[0], tbe[1]);    // :476-477
+    const double *d_pose = h->d_pose_in;
+    if (h->pose_on_device) {                          // already behind the keypoint arrays (ctgn_register_robust)
+        d_pose = h->d_kp + 7 * (size_t) h->kp_stride;
+        h->pose_on_device = false;
+    } else {
+        for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
+        HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);    // :476-477
     hipLaunchKernelGGL(k_robust_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_loop_start, h->stream));
@@ -1268,14 +1274,19 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     h->profiling = saved_prof;
     if (st != CTGN_OK) { hipStreamSynchronize(h->stream); return st; }
     if (n > 0) {                                                                          // :685 (not after a failure)
-        hipLaunchKernelGGL(k_transform, dim3(grid_lane), dim3(256), 0, h->stream, kv, h->d_state);
+        hipLaunchKernelGGL(k_transform, dim3(grid_lane), dim3(256), 0, h->stream, kv, h->d_state,
+                           h->prefetch_world ? h->d_kp + 7 * (size_t) h->kp_stride + 16 : nullptr);
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    const bool merged = h->prefetch_world && n > 0;            // world points + GnState in one device-to-host copy
+    const size_t cs = (size_t) h->kp_stride;
+    if (merged) HIPCHK(h, hipMemcpyAsync(h->h_kp + 4 * cs, h->d_kp + 4 * cs, (3 * cs + KP_TAIL) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    else HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_rstate, h->d_rstate, sizeof(RobustState), hipMemcpyDeviceToHost, h->stream));
-    if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
+    if (h->prefetch_world && !merged) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (merged) std::memcpy(h->h_state, h->h_kp + 7 * cs + 16, sizeof(GnState));
     const GnState &s = *h->h_state;
     const RobustState &rs = *h->h_rstate;
     if (rs.error) return fail(h, CTGN_ERR_SOLVER, "the inner solver reported an unusable solution");
@@ -1303,12 +1314,15 @@ ctgn_status ctgn_register_robust(ctgn_handle h, ctgn_view raw, void *world_base,
                                  ctgn_view ts, size_t n, double pose_io[14], const double tbe[2], const ctgn_robust_options *opts,
                                  const ctgn_robust_prior *prior, ctgn_summary *summary) {
     ctgn_view world{world_base, world_stride, world_dtype, 0};
+    if (h) h->pose_with_kp = pose_io;
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n);
-    if (st != CTGN_OK) return st;
+    if (h) h->pose_with_kp = nullptr;
+    if (st != CTGN_OK) { if (h) h->pose_on_device = false; return st; }
     const bool dev_world = n > 0 && on_device(world_base);
     h->prefetch_world = !dev_world;
     st = ctgn_solve_robust(h, pose_io, tbe, opts, prior, summary);
     h->prefetch_world = false;
+    h->pose_on_device = false;
     if (st != CTGN_OK) return st;
     if (dev_world) return ctgn_get_world_points(h, world_base, world_stride, world_dtype, n);
     if (n) scatter_world_from_staging(h, world_base, world_stride, world_dtype, n);

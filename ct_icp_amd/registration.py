@@ -74,6 +74,10 @@ def _summary(s: L.Summary) -> ICPSummary:
 class CT_ICP_Registration:
     def __init__(self, options: CTICPOptions | None = None):
         self._options = options or CTICPOptions(solver=GN)
+        self._buf = np.zeros(16)                                   # pose (14) | t_begin, t_end
+        dp = C.POINTER(C.c_double)
+        self._pose_ptr = self._buf.ctypes.data_as(dp)
+        self._tbe_ptr = C.cast(self._buf.ctypes.data + 14 * 8, dp)
 
     def Options(self) -> CTICPOptions:
         return self._options
@@ -90,21 +94,27 @@ class CT_ICP_Registration:
             raise TypeError("keypoints must be a WPOINT3D_DTYPE structured array")
         h = voxel_map.handle
         n = len(keypoints)
-        raw = L.View(keypoints.ctypes.data + 0, keypoints.strides[0] if n else 64, L.CTGN_F64, 0)
-        ts = L.View(keypoints.ctypes.data + 24, keypoints.strides[0] if n else 64, L.CTGN_F64, 0)
-        pose = np.ascontiguousarray(trajectory_frame.pose14(), dtype=np.float64)
-        tbe = np.array([trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp])
+        # (the wrapper itself is on the latency path of a 0.16 ms call: one .ctypes lookup, a reused 16-double buffer for
+        # pose | timestamps)
+        base = keypoints.ctypes.data
+        stride = keypoints.strides[0] if n else 64
+        raw = L.View(base, stride, L.CTGN_F64, 0)
+        ts = L.View(base + 24, stride, L.CTGN_F64, 0)
+        b, e = trajectory_frame.begin_pose, trajectory_frame.end_pose
+        buf = self._buf
+        buf[0:4], buf[4:7], buf[7:11], buf[11:14] = b.quat, b.tr, e.quat, e.tr
+        buf[14], buf[15] = b.dest_timestamp, e.dest_timestamp
+        pose, tbe = self._pose_ptr, self._tbe_ptr
         s = L.Summary()
-        dp = C.POINTER(C.c_double)
         if self._options.solver == GN:
             opts, prior, fn = _c_options(self._options), _c_prior(motion_model), L.lib().ctgn_register
         else:
             opts, prior, fn = _c_robust_options(self._options), _c_robust_prior(motion_model), L.lib().ctgn_register_robust
-        st = fn(h, raw, keypoints.ctypes.data + 32, keypoints.strides[0] if n else 64, L.CTGN_F64, ts, n,
-                pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+        st = fn(h, raw, base + 32, stride, L.CTGN_F64, ts, n, pose, tbe, C.byref(opts),
                 C.byref(prior) if prior is not None else None, C.byref(s))
-        L.check(h, st)
-        trajectory_frame.set_pose14(pose)
+        if st != L.OK:
+            L.check(h, st)
+        b.quat, b.tr, e.quat, e.tr = buf[0:4].copy(), buf[4:7].copy(), buf[7:11].copy(), buf[11:14].copy()
         return _summary(s)
 
 
