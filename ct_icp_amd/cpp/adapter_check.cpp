@@ -52,6 +52,15 @@ int main() {
         std::printf("adapter %s n_used=%d iters=%d tr=%.6f %.6f %.6f err=%.2e map_points=%zu\n",
                     (s.success && err < 1e-6) ? "ok" : "FAIL", s.num_residuals_used, s.num_iters, frame.end_pose.tr[0],
                     frame.end_pose.tr[1], frame.end_pose.tr[2], err, map.NumPoints());
+        // raw-points insertion with poses + the in-place query spellings
+        {
+            std::vector<WPoint3D> extra(kps.begin(), kps.begin() + 500);
+            std::vector<size_t> kept;
+            map.InsertPointCloud(extra, frame.begin_pose, frame.end_pose, kept);
+            Neighborhood nb;
+            map.ComputeNeighborhoodInPlace(extra[0].world_point, 5, nb);
+            if (nb.size() == 0) { std::printf("adapter FAIL: empty neighbourhood\n"); return 1; }
+        }
         // the `case CERES:` arm on the same map and keypoints
         TrajectoryFrame frame2;
         frame2.begin_pose.dest_timestamp = 0.0;

@@ -183,6 +183,27 @@ public:
     Neighborhood RadiusSearch(const double query[3], double radius, int max_num_neighbors) {
         return ComputeNeighborhoods(std::vector<double>(query, query + 3), max_num_neighbors, radius)[0];
     }
+    // the in-place spellings of ISlamMap (include/ct_icp/map.h:47-82)
+    void RadiusSearchInPlace(const double query[3], Neighborhood &neighborhood, double radius, int max_num_neighbors) {
+        neighborhood = RadiusSearch(query, radius, max_num_neighbors);
+    }
+    void ComputeNeighborhoodInPlace(const double query[3], int max_num_neighbors, Neighborhood &neighborhood) {
+        neighborhood = RadiusSearch(query, -1.0 /* default_radius, map.h:527-530 */, max_num_neighbors);
+    }
+    // InsertPointCloud(pointcloud, frame_poses, out_indices) for a frame that only carries RAW points (map.h:153-184): the world
+    // points are derived from the begin / end pose first (continuous-time interpolation by timestamp), on the GPU, then inserted.
+    void InsertPointCloud(std::vector<WPoint3D> &frame, const Pose &begin_pose, const Pose &end_pose, std::vector<size_t> &out_selected_points) {
+        if (!frame.empty()) {
+            double pose[14];
+            std::memcpy(pose, begin_pose.quat, 32); std::memcpy(pose + 4, begin_pose.tr, 24);
+            std::memcpy(pose + 7, end_pose.quat, 32); std::memcpy(pose + 11, end_pose.tr, 24);
+            const double tbe[2] = {begin_pose.dest_timestamp, end_pose.dest_timestamp};
+            ctgn_view raw{frame[0].raw_point, sizeof(WPoint3D), CTGN_F64, 0};
+            ctgn_view ts{&frame[0].timestamp, sizeof(WPoint3D), CTGN_F64, 0};
+            check(ctgn_transform_points(h_, raw, ts, frame.size(), pose, tbe, frame[0].world_point, sizeof(WPoint3D), CTGN_F64));
+        }
+        InsertPointCloud(frame, out_selected_points);
+    }
 
     ctgn_handle handle() const { return h_; }
     const Options &GetOptions() const { return options_; }
