@@ -324,7 +324,12 @@ def main():
         if args.workload == "B2" and world == 1 and not args.ablate and not args.inner:
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
-            result["frame_stages"] = measure_frame_stages(cia, inp, syn, se3, local_rank)
+            result["frame_stages"] = fs = measure_frame_stages(cia, inp, syn, se3, local_rank)
+            # the whole per-frame loop of Odometry::DoRegister on this 132 k-point frame, every data-parallel step through the
+            # library with host buffers in and out: the steps either side + one Register call on the sampled keypoints
+            for route, reg_ms in (("gn", result["frames_per_sec"]["ms_per_frame"]), ("robust", result["robust_route"]["ms_per_frame"])):
+                ms = fs["grid_sampling_ms"] + fs["keypoint_sampling_ms"] + reg_ms + fs["undistortion_ms"] + fs["map_update_ms"]
+                result.setdefault("frame_pipeline", {})[route] = {"ms_per_frame": ms, "frames_per_sec": 1e3 / ms}
         if not args.no_cpu_baseline and args.workload == "B2" and world == 1:      # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args)
             if result["cpu_baseline"]["value"]:
@@ -402,13 +407,15 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
         t0 = time.perf_counter()
         keep = np.sort(cia.grid_sampling(m, raw, 0.5))
         t1 = time.perf_counter()
+        kp = cia.grid_sampling(m, raw[keep], 1.5)                    # keypoint selection (odometry.cpp:538)
+        t1b = time.perf_counter()
         world = cia.transform_points(m, raw, t, inp["pose_gt"], inp["tbe"])
         t2 = time.perf_counter()
         m.RemoveElementsFarFromLocation(inp["pose_gt"][11:14], 100.0)
         kept = m.InsertPointCloud(world[keep])
         t3 = time.perf_counter()
-        out = {"grid_sampling_ms": (t1 - t0) * 1e3, "undistortion_ms": (t2 - t1) * 1e3, "map_update_ms": (t3 - t2) * 1e3,
-               "points": int(len(t)), "sampled": int(len(keep)), "inserted": int(np.count_nonzero(kept)),
+        out = {"grid_sampling_ms": (t1 - t0) * 1e3, "keypoint_sampling_ms": (t1b - t1) * 1e3, "undistortion_ms": (t2 - t1b) * 1e3,
+               "map_update_ms": (t3 - t2) * 1e3, "points": int(len(t)), "sampled": int(len(keep)), "keypoints": int(len(kp)), "inserted": int(np.count_nonzero(kept)),
                "map_points_after": int(m.NumPoints())}
     return out
 
