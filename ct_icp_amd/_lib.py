@@ -77,6 +77,11 @@ class RobustReport(C.Structure):
                 ("step_cycles", C.c_uint64 * 8)]
 
 
+class AdaptiveSamplingOptions(C.Structure):
+    _fields_ = [("num_points_per_voxel", C.c_int32), ("max_num_points", C.c_int32), ("num_bands", C.c_int32),
+                ("reserved", C.c_int32), ("distance", C.c_double * 16), ("voxel_size", C.c_double * 16)]
+
+
 class View(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_bytes", C.c_size_t), ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
@@ -106,6 +111,9 @@ SYMBOLS = {
     "ctgn_solve": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
     "ctgn_get_world_points": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
     "ctgn_grid_sampling": (C.c_int, [_H, View, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "ctgn_adaptive_sampling_options_default": (None, [C.POINTER(AdaptiveSamplingOptions)]),
+    "ctgn_adaptive_sampling": (C.c_int, [_H, View, C.c_size_t, C.POINTER(AdaptiveSamplingOptions), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_size_t)]),
     "ctgn_transform_points": (C.c_int, [_H, View, View, C.c_size_t, _dp, _dp, C.c_void_p, C.c_size_t, C.c_int]),
     "ctgn_register": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
                                 C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),

@@ -61,6 +61,25 @@ int main() {
             map.ComputeNeighborhoodInPlace(extra[0].world_point, 5, nb);
             if (nb.size() == 0) { std::printf("adapter FAIL: empty neighbourhood\n"); return 1; }
         }
+        // the steps either side of the path: both samplers and the undistortion loop
+        bool side_ok = true;
+        {
+            std::vector<WPoint3D> sampled;
+            grid_sampling(map, kps, sampled, 1.0);
+            std::vector<WPoint3D> copy = kps;
+            sub_sample_frame(map, copy, 1.0);
+            std::vector<size_t> adaptive = AdaptiveSamplePointsInGrid(map, kps, AdaptiveGridSamplingOptions());
+            side_ok = !sampled.empty() && sampled.size() < kps.size() && copy.size() == sampled.size() && !adaptive.empty() &&
+                      adaptive.size() < kps.size();
+            TransformFrame(map, copy, frame);
+            double dmax = 0;
+            for (const WPoint3D &p : copy)
+                for (int c = 0; c < 3; ++c) dmax = std::fmax(dmax, std::fabs(p.world_point[c] - p.raw_point[c] - (1.0 - p.timestamp) * frame.begin_pose.tr[c] -
+                                                     p.timestamp * frame.end_pose.tr[c]));
+            side_ok = side_ok && dmax < 1e-5;                     // the optimised rotations are the identity to ~1e-7
+            std::printf("adapter-sampling %s grid=%zu adaptive=%zu undistort-err=%.1e\n", side_ok ? "ok" : "FAIL", sampled.size(),
+                        adaptive.size(), dmax);
+        }
         // the `case CERES:` arm on the same map and keypoints
         TrajectoryFrame frame2;
         frame2.begin_pose.dest_timestamp = 0.0;
@@ -74,7 +93,7 @@ int main() {
         for (int c = 0; c < 3; ++c) err2 = std::fmax(err2, std::fabs(frame2.end_pose.tr[c] - shift[c]));
         std::printf("adapter-ceres %s n_res=%d iters=%d err=%.2e\n", (s2.success && err2 < 1e-5) ? "ok" : "FAIL",
                     s2.num_residuals_used, s2.num_iters, err2);
-        return (s.success && err < 1e-6 && s2.success && err2 < 1e-5) ? 0 : 1;
+        return (s.success && err < 1e-6 && s2.success && err2 < 1e-5 && side_ok) ? 0 : 1;
     } catch (const std::exception &e) {
         std::printf("adapter no-device (%s)\n", e.what());
         return 0;

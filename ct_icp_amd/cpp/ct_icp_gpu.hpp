@@ -347,4 +347,72 @@ private:
     CTICPOptions options_;
 };
 
+// ---- the steps either side of the path, same names as the reference's free functions (the map argument carries the device handle)
+
+// ct_icp::grid_sampling (src/ct_icp/ct_icp.cpp:86-101): keypoints = the first point of every voxel of the RAW coordinates
+inline void grid_sampling(GpuVoxelMap &voxel_map, const std::vector<WPoint3D> &frame, std::vector<WPoint3D> &keypoints,
+                          double size_voxel_subsampling) {
+    keypoints.clear();
+    if (frame.empty()) return;
+    std::vector<uint32_t> idx(frame.size());
+    size_t count = 0;
+    ctgn_view xyz{const_cast<double *>(frame[0].raw_point), sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_status st = ctgn_grid_sampling(voxel_map.handle(), xyz, frame.size(), size_voxel_subsampling, idx.data(), &count);
+    if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn: ") + ctgn_last_error(voxel_map.handle()));
+    keypoints.reserve(count);
+    for (size_t k = 0; k < count; ++k) keypoints.push_back(frame[idx[k]]);
+}
+
+// ct_icp::sub_sample_frame (src/ct_icp/ct_icp.cpp:65-83): in-place variant
+inline void sub_sample_frame(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &frame, double size_voxel) {
+    std::vector<WPoint3D> kept;
+    grid_sampling(voxel_map, frame, kept, size_voxel);
+    frame.swap(kept);
+}
+
+// ct_icp::AdaptiveGridSamplingOptions / AdaptiveSamplePointsInGrid (include/ct_icp/algorithm/sampling.h:13-26,55-110)
+struct AdaptiveGridSamplingOptions {
+    int num_points_per_voxel = 1;
+    int max_num_points = -1;
+    std::vector<std::pair<double, double>> distance_voxel_size = {{0.5, 0.1}, {2.0, 0.2}, {4., 0.4}, {8., 0.8}, {16., 1.6}, {200., -1.}};
+};
+inline std::vector<size_t> AdaptiveSamplePointsInGrid(GpuVoxelMap &voxel_map, const std::vector<WPoint3D> &frame,
+                                                      const AdaptiveGridSamplingOptions &options) {
+    std::vector<size_t> indices;
+    if (frame.empty()) return indices;
+    ctgn_adaptive_sampling_options o;
+    ctgn_adaptive_sampling_options_default(&o);
+    if (options.distance_voxel_size.size() > CTGN_ADAPTIVE_MAX_BANDS) throw std::runtime_error("ctgn: too many sampling bands");
+    o.num_points_per_voxel = options.num_points_per_voxel;
+    o.max_num_points = options.max_num_points;
+    o.num_bands = (int32_t) options.distance_voxel_size.size();
+    for (size_t j = 0; j < options.distance_voxel_size.size(); ++j) {
+        o.distance[j] = options.distance_voxel_size[j].first;
+        o.voxel_size[j] = options.distance_voxel_size[j].second;
+    }
+    std::vector<uint32_t> idx(frame.size());
+    size_t count = 0;
+    ctgn_view xyz{const_cast<double *>(frame[0].raw_point), sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_status st = ctgn_adaptive_sampling(voxel_map.handle(), xyz, frame.size(), &o, idx.data(), &count);
+    if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn: ") + ctgn_last_error(voxel_map.handle()));
+    indices.assign(idx.begin(), idx.begin() + count);
+    return indices;
+}
+
+// the undistortion loop of Odometry::DoRegister (src/ct_icp/odometry.cpp:461-486): world_point = InterpolatePose(t) * raw_point
+inline void TransformFrame(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &frame, const TrajectoryFrame &trajectory_frame) {
+    if (frame.empty()) return;
+    double pose[14];
+    std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
+    std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
+    std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
+    std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+    const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
+    ctgn_view raw{frame[0].raw_point, sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_view ts{&frame[0].timestamp, sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_status st = ctgn_transform_points(voxel_map.handle(), raw, ts, frame.size(), pose, tbe, frame[0].world_point, sizeof(WPoint3D),
+                                           CTGN_F64);
+    if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn: ") + ctgn_last_error(voxel_map.handle()));
+}
+
 }  // namespace ct_icp_gpu

@@ -1055,6 +1055,51 @@ ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double vo
     return CTGN_OK;
 }
 
+void ctgn_adaptive_sampling_options_default(ctgn_adaptive_sampling_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->num_points_per_voxel = 1;
+    o->max_num_points = -1;
+    o->num_bands = 6;
+    const double d[6] = {0.5, 2.0, 4.0, 8.0, 16.0, 200.0}, v[6] = {0.1, 0.2, 0.4, 0.8, 1.6, -1.0};   // sampling.h:18-25
+    for (int j = 0; j < 6; ++j) { o->distance[j] = d[j]; o->voxel_size[j] = v[j]; }
+}
+
+ctgn_status ctgn_adaptive_sampling(ctgn_handle h, ctgn_view xyz, size_t n, const ctgn_adaptive_sampling_options *opts,
+                                   uint32_t *out_indices, size_t *out_count) {
+    NEED_DEVICE(h);
+    if (!out_count || !opts || (n && (!xyz.base || !out_indices))) return CTGN_ERR_INVALID_ARGUMENT;
+    *out_count = 0;
+    if (opts->num_bands < 2 || opts->num_bands > CTGN_ADAPTIVE_MAX_BANDS || opts->num_points_per_voxel < 1)
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "adaptive sampling: 2..16 bands and num_points_per_voxel >= 1 expected");
+    AdaptiveBands bands{};
+    bands.num_bands = opts->num_bands;
+    bands.num_points_per_voxel = opts->num_points_per_voxel;
+    for (int j = 0; j < opts->num_bands; ++j) { bands.distance[j] = opts->distance[j]; bands.voxel_size[j] = opts->voxel_size[j]; }
+    for (int j = 0; j + 1 < opts->num_bands; ++j) {
+        if (!(bands.distance[j] < bands.distance[j + 1]) || !(bands.voxel_size[j] > 0))
+            return fail(h, CTGN_ERR_INVALID_ARGUMENT, "adaptive sampling: distances must ascend and used voxel sizes be positive");
+        if (!(bands.distance[j + 1] / bands.voxel_size[j] < (double) (1 << 19)))
+            return fail(h, CTGN_ERR_INVALID_ARGUMENT, "adaptive sampling: band voxel coordinates exceed 20 bits");
+    }
+    if (n == 0) return CTGN_OK;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DMCHK(h, devmap_scratch_reserve(h->dm, n));
+    DevMapScratch &S = h->dm;
+    if (on_device(xyz.base)) {
+        ctgn_status gs = gather_device_view(h, xyz.base, xyz.stride_bytes, xyz.dtype, 3, S.pts, S.cap, n);
+        if (gs != CTGN_OK) return gs;
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
+        for (int a = 0; a < 3; ++a)
+            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    DMCHK(h, devmap_adaptive_sampling(S, n, bands, opts->max_num_points, out_indices, out_count, h->stream));
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const double pose[14], const double tbe[2],
                                   void *out_base, size_t out_stride, ctgn_dtype out_dtype) {
     NEED_DEVICE(h);

@@ -144,18 +144,64 @@ __global__ void k_dm_rehash(const Slot *old_slots, uint64_t old_n, Slot *slots, 
     }
 }
 
-// grid sampling keys: static_cast<short>(p / voxel_size) per axis (ct_icp.cpp:70-72), three int16 packed in 48 bits
-__global__ void k_gs_keys(const double *pts, size_t cap, size_t n, double voxel_size, uint64_t *keys, uint32_t *idx) {
+// grid sampling keys: static_cast<short>(p / voxel_size) per axis (ct_icp.cpp:70-72), three int16 packed in 48 bits.
+// Grid sampling without a sort: every point claims its voxel's slot in a scratch hash table and lowers the slot's point index
+// with atomicMin; a point survives iff it is the smallest index of its voxel, i.e. the first one the reference's loop inserts
+// (ct_icp.cpp:73-75). Integer atomics only: the result does not depend on the execution order.
+constexpr unsigned long long GS_EMPTY = ~0ull;
+__global__ void k_gs_hash(const double *pts, size_t cap, size_t n, double voxel_size, unsigned long long *tkeys, uint32_t *tfirst,
+                          uint32_t mask, uint32_t *slot_of) {
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint16_t vx = (uint16_t) (short) (int) (pts[i] / voxel_size), vy = (uint16_t) (short) (int) (pts[cap + i] / voxel_size),
                    vz = (uint16_t) (short) (int) (pts[2 * cap + i] / voxel_size);
-    keys[i] = (uint64_t) vx | ((uint64_t) vy << 16) | ((uint64_t) vz << 32);
+    const unsigned long long key = (unsigned long long) vx | ((unsigned long long) vy << 16) | ((unsigned long long) vz << 32);
+    unsigned long long hsh = key * 0x9E3779B97F4A7C15ull;
+    uint32_t s = (uint32_t) (hsh >> 32) & mask;
+    for (;;) {
+        unsigned long long cur = *reinterpret_cast<volatile unsigned long long *>(&tkeys[s]);
+        if (cur == GS_EMPTY) cur = atomicCAS(&tkeys[s], GS_EMPTY, key);
+        if (cur == GS_EMPTY || cur == key) break;
+        s = (s + 1) & mask;
+    }
+    atomicMin(&tfirst[s], (uint32_t) i);
+    slot_of[i] = s;
+}
+__global__ void k_gs_first_flags(const uint32_t *tfirst, const uint32_t *slot_of, size_t n, uint8_t *flags) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = tfirst[slot_of[i]] == (uint32_t) i ? 1 : 0;
+}
+
+// Adaptive sampling keys (sampling.h:65-79): band from the range |p| (std::lower_bound on the distance list, minus one),
+// voxel = int(p / size[band]) per axis; band in bits 60.., z, y, x biased by 2^19 in 20 bits each. Points outside
+// [distance[0], distance[last]) — and |p| == distance[0], where the reference indexes entry -1 — get the invalid key and
+// sort to the end. The explicit _rn intrinsics keep the compiler from contracting x*x + y*y + z*z into FMAs, so the range
+// rounds like the host's.
+constexpr uint64_t AS_INVALID = ~0ull;
+__global__ void k_as_keys(const double *pts, size_t cap, size_t n, AdaptiveBands bands, uint64_t *keys, uint32_t *idx) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = pts[i], y = pts[cap + i], z = pts[2 * cap + i];
+    const double d = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)), __dmul_rn(z, z)));
+    int lw = 0;
+    while (lw < bands.num_bands && bands.distance[lw] < d) ++lw;
+    uint64_t key = AS_INVALID;
+    if (d >= bands.distance[0] && d < bands.distance[bands.num_bands - 1] && lw >= 1) {
+        const int band = lw - 1;
+        const double sz = bands.voxel_size[band];
+        const int vx = (int) (x / sz), vy = (int) (y / sz), vz = (int) (z / sz);
+        key = ((uint64_t) band << 60) | ((uint64_t) (uint32_t) (vz + (1 << 19)) << 40) | ((uint64_t) (uint32_t) (vy + (1 << 19)) << 20) |
+              (uint64_t) (uint32_t) (vx + (1 << 19));
+    }
+    keys[i] = key;
     idx[i] = (uint32_t) i;
 }
-__global__ void k_gs_heads(const uint64_t *keys, size_t n, uint8_t *flags) {
+// sorted keys (stable: indices ascend inside a run): keep the first k positions of every run
+__global__ void k_as_flags(const uint64_t *keys, size_t n, uint32_t k, uint8_t *flags) {
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    flags[i] = (key != AS_INVALID && (i < k || keys[i - k] != key)) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -216,10 +262,18 @@ hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n) {
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.sel_count), sizeof(int)));
     DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_pts), cap * 3 * sizeof(double), hipHostMallocDefault));
     DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_inserted), cap, hipHostMallocDefault));
-    size_t tmp = 0, tmp2 = 0;
+    DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_count), sizeof(int), hipHostMallocDefault));
+    size_t gs_cap = 1024;
+    while (gs_cap < 2 * cap) gs_cap <<= 1;
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_keys), gs_cap * sizeof(unsigned long long)));
+    DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_first), gs_cap * sizeof(uint32_t)));
+    S.gs_cap = gs_cap;
+    size_t tmp = 0, tmp2 = 0, tmp3 = 0;
+    DM_CHK(hipcub::DeviceSelect::Flagged(nullptr, tmp3, hipcub::CountingInputIterator<uint32_t>(0u), S.inserted, S.sel_out, S.sel_count,
+                                         (int) cap, (hipStream_t) 0));
     DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) cap, 0, 64, (hipStream_t) 0));
     DM_CHK(hipcub::DeviceSelect::Flagged(nullptr, tmp2, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) cap, (hipStream_t) 0));
-    tmp = std::max(tmp, tmp2);
+    tmp = std::max(std::max(tmp, tmp2), tmp3);
     DM_CHK(hipMalloc(&S.cub_temp, tmp));
     S.cub_temp_bytes = tmp;
     S.cap = cap;
@@ -238,6 +292,9 @@ void devmap_scratch_free(DevMapScratch &S) {
     if (S.cub_temp) (void) hipFree(S.cub_temp);
     if (S.h_pts) (void) hipHostFree(S.h_pts);
     if (S.h_inserted) (void) hipHostFree(S.h_inserted);
+    if (S.h_count) (void) hipHostFree(S.h_count);
+    if (S.gs_keys) (void) hipFree(S.gs_keys);
+    if (S.gs_first) (void) hipFree(S.gs_first);
     S = DevMapScratch{};
 }
 
@@ -299,22 +356,49 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
     *out_count = 0;
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned) ((n + 255) / 256);
-    hipLaunchKernelGGL(k_gs_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, voxel_size, S.keys, S.idx);
+    size_t tcap = 1024;                                  // >= 2 slots per point: short probe sequences
+    while (tcap < 2 * n) tcap <<= 1;
+    if (tcap > S.gs_cap) return hipErrorInvalidValue;
+    DM_CHK(hipMemsetAsync(S.gs_keys, 0xFF, tcap * sizeof(unsigned long long), stream));
+    DM_CHK(hipMemsetAsync(S.gs_first, 0xFF, tcap * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, voxel_size, S.gs_keys, S.gs_first, (uint32_t) (tcap - 1),
+                       S.idx);
+    hipLaunchKernelGGL(k_gs_first_flags, dim3(grid), dim3(256), 0, stream, S.gs_first, S.idx, n, S.inserted);
     DM_CHK(hipGetLastError());
     size_t tmp = S.cub_temp_bytes;
-    // stable sort: inside a run of equal keys the original indices stay ascending, so the head of a run is the
-    // first-inserted point of its voxel (ct_icp.cpp:73-75)
-    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 48, stream));
-    hipLaunchKernelGGL(k_gs_heads, dim3(grid), dim3(256), 0, stream, S.keys_alt, n, S.inserted);
-    DM_CHK(hipGetLastError());
-    tmp = S.cub_temp_bytes;
-    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) n, stream));
-    int count = 0;
-    DM_CHK(hipMemcpyAsync(&count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, hipcub::CountingInputIterator<uint32_t>(0u), S.inserted, S.sel_out, S.sel_count,
+                                         (int) n, stream));
+    DM_CHK(hipMemcpyAsync(S.h_count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     DM_CHK(hipStreamSynchronize(stream));
+    const int count = *S.h_count;
     DM_CHK(hipMemcpyAsync(out_idx_host, S.sel_out, (size_t) count * sizeof(uint32_t), hipMemcpyDefault, stream));   // host or device
     DM_CHK(hipStreamSynchronize(stream));
     *out_count = (size_t) count;
+    return hipSuccess;
+}
+
+hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBands &bands, int max_num_points, uint32_t *out_idx,
+                                    size_t *out_count, hipStream_t stream) {
+    *out_count = 0;
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_as_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, bands, S.keys, S.idx);
+    DM_CHK(hipGetLastError());
+    size_t tmp = S.cub_temp_bytes;
+    // stable sort on (band, z, y, x): indices stay ascending inside a voxel, so its first k positions are the k indices the
+    // reference's loop pushes (sampling.h:80-85)
+    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 64, stream));
+    hipLaunchKernelGGL(k_as_flags, dim3(grid), dim3(256), 0, stream, S.keys_alt, n, (uint32_t) bands.num_points_per_voxel, S.inserted);
+    DM_CHK(hipGetLastError());
+    tmp = S.cub_temp_bytes;
+    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) n, stream));
+    DM_CHK(hipMemcpyAsync(S.h_count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DM_CHK(hipStreamSynchronize(stream));
+    size_t count = (size_t) *S.h_count;
+    if (max_num_points > 0 && count > (size_t) max_num_points + 1) count = (size_t) max_num_points + 1;   // `size() > max` (sampling.h:96-106)
+    DM_CHK(hipMemcpyAsync(out_idx, S.sel_out, count * sizeof(uint32_t), hipMemcpyDefault, stream));   // host or device
+    DM_CHK(hipStreamSynchronize(stream));
+    *out_count = count;
     return hipSuccess;
 }
 

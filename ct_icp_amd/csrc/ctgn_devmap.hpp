@@ -50,6 +50,20 @@ struct DevMapScratch {                   // per handle, shared by the levels
     size_t cap = 0;
     double *h_pts = nullptr;             // pinned
     uint8_t *h_inserted = nullptr;       // pinned
+    // grid sampling: open-addressing table voxel key -> smallest point index (2 x cap slots, power of two)
+    unsigned long long *gs_keys = nullptr;
+    uint32_t *gs_first = nullptr;
+    size_t gs_cap = 0;
+    int *h_count = nullptr;              // pinned read-back word
+};
+
+// AdaptiveGridSamplingOptions (reference include/ct_icp/algorithm/sampling.h:13-26), passed to the key kernel by value
+constexpr int AS_MAX_BANDS = 16;
+struct AdaptiveBands {
+    int num_bands;
+    int num_points_per_voxel;
+    double distance[AS_MAX_BANDS];
+    double voxel_size[AS_MAX_BANDS];
 };
 
 // All functions return hipSuccess or the failing HIP error; they enqueue on `stream` and synchronise where a read-back
@@ -63,10 +77,16 @@ void devmap_scratch_free(DevMapScratch &S);
 hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStream_t stream);
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream);
 // sub_sample_frame / grid_sampling (reference src/ct_icp/ct_icp.cpp:65-101): index of the first point of every voxel of
-// the staged points (voxel = static_cast<short>(p / voxel_size) per axis). Output in voxel-key order (the reference's
-// robin_map iteration order is unspecified). out_idx_host must hold n entries.
+// the staged points (voxel = static_cast<short>(p / voxel_size) per axis). Output in ascending index order = the order in
+// which the reference's loop first meets the voxels (its robin_map iteration order is unspecified). out_idx_host (host or
+// device memory) must hold n entries.
 hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, uint32_t *out_idx_host, size_t *out_count,
                                 hipStream_t stream);
+// AdaptiveSamplePointsInGrid (reference include/ct_icp/algorithm/sampling.h:55-110): range band -> voxel size, the first
+// num_points_per_voxel indices of every (band, voxel); order band, voxel (z, y, x), index; at most max_num_points + 1
+// indices when max_num_points > 0 (the reference stops on size() > max). The band list must be validated by the caller.
+hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBands &bands, int max_num_points, uint32_t *out_idx,
+                                    size_t *out_count, hipStream_t stream);
 hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream);
 
 }  // namespace ctgn

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 from .map import GpuVoxelMap
-from .types import CERES, GN, CTICPOptions, ICPSummary, PreviousFrameMotionModel, TrajectoryFrame, WPOINT3D_DTYPE
+from .types import CERES, GN, AdaptiveGridSamplingOptions, CTICPOptions, ICPSummary, PreviousFrameMotionModel, TrajectoryFrame, WPOINT3D_DTYPE
 
 
 def _view(arr: np.ndarray, offset: int = 0) -> L.View:
@@ -146,7 +146,7 @@ def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end):
 
 def grid_sampling(voxel_map: GpuVoxelMap, points, voxel_size: float) -> np.ndarray:
     """ct_icp::grid_sampling / sub_sample_frame on the GPU (reference src/ct_icp/ct_icp.cpp:65-101): indices of the first
-    point of every voxel, in voxel-key order."""
+    point of every voxel, ascending (= the order in which the reference's loop first meets the voxels)."""
     h = voxel_map.handle
     if L.is_device_tensor(points):                       # device in, device out
         import torch
@@ -160,6 +160,37 @@ def grid_sampling(voxel_map: GpuVoxelMap, points, voxel_size: float) -> np.ndarr
     cnt = C.c_size_t()
     L.check(h, L.lib().ctgn_grid_sampling(h, L.View(pts.ctypes.data, 24, L.CTGN_F64, 0), len(pts), float(voxel_size),
                                          out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
+    return out[:cnt.value].copy()
+
+
+def _c_adaptive_options(options: AdaptiveGridSamplingOptions) -> "L.AdaptiveSamplingOptions":
+    pairs = list(options.distance_voxel_size)
+    if len(pairs) > 16:
+        raise ValueError("at most 16 distance / voxel-size pairs")
+    c = L.AdaptiveSamplingOptions()
+    c.num_points_per_voxel, c.max_num_points, c.num_bands = int(options.num_points_per_voxel), int(options.max_num_points), len(pairs)
+    for j, (d, v) in enumerate(pairs):
+        c.distance[j], c.voxel_size[j] = float(d), float(v)
+    return c
+
+
+def AdaptiveSamplePointsInGrid(voxel_map: GpuVoxelMap, points, options: AdaptiveGridSamplingOptions = None) -> np.ndarray:
+    """ct_icp::AdaptiveSamplePointsInGrid on the GPU (reference include/ct_icp/algorithm/sampling.h:55-110; `sampling: ADAPTIVE`
+    of Odometry::TryRegister, src/ct_icp/odometry.cpp:539-545): indices kept by the range-banded grid, ordered by band, voxel,
+    index. `points` is an (n, 3) array of SENSOR-frame points, or a torch CUDA tensor (device in, device out)."""
+    h = voxel_map.handle
+    c = _c_adaptive_options(options or AdaptiveGridSamplingOptions())
+    cnt = C.c_size_t()
+    if L.is_device_tensor(points):
+        import torch
+        out_t = torch.zeros(max(len(points), 1), dtype=torch.int32, device=points.device)
+        L.check(h, L.lib().ctgn_adaptive_sampling(h, L.tensor_view(points), len(points), C.byref(c),
+                                                 C.cast(out_t.data_ptr(), C.POINTER(C.c_uint32)), C.byref(cnt)))
+        return out_t[:cnt.value].clone()
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(max(len(pts), 1), dtype=np.uint32)
+    L.check(h, L.lib().ctgn_adaptive_sampling(h, L.View(pts.ctypes.data, 24, L.CTGN_F64, 0), len(pts), C.byref(c),
+                                             out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
     return out[:cnt.value].copy()
 
 

@@ -137,3 +137,12 @@ class PreviousFrameMotionModel:
 
     def PreviousFrame(self) -> TrajectoryFrame:
         return self.previous_frame
+
+
+@dataclass
+class AdaptiveGridSamplingOptions:
+    """ct_icp::AdaptiveGridSamplingOptions (reference include/ct_icp/algorithm/sampling.h:13-26), same names and defaults."""
+    num_points_per_voxel: int = 1
+    max_num_points: int = -1
+    distance_voxel_size: list = field(default_factory=lambda: [(0.5, 0.1), (2.0, 0.2), (4.0, 0.4), (8.0, 0.8), (16.0, 1.6),
+                                                               (200.0, -1.0)])

@@ -198,9 +198,34 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw_xyz, ctgn_view ti
 
 /* sub_sample_frame / grid_sampling on the GPU (reference src/ct_icp/ct_icp.cpp:65-101): keeps the
  * FIRST point of every voxel of size `voxel_size`, voxel = static_cast<short>(p / voxel_size) per axis. Writes the kept
- * indices (at most n) to out_indices and their number to out_count. Order: by voxel key (the reference's order is the
- * unspecified tsl::robin_map iteration order). */
+ * indices (at most n) to out_indices and their number to out_count. Order: ascending index, i.e. the order in which the
+ * reference's loop first meets the voxels (its output order is the unspecified tsl::robin_map iteration order). */
 ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double voxel_size, uint32_t *out_indices, size_t *out_count);
+
+/* AdaptiveGridSamplingOptions (reference include/ct_icp/algorithm/sampling.h:13-26): distance / voxel_size are the pairs of
+ * distance_voxel_size, ascending in distance; the voxel size of the last pair is never used. */
+#define CTGN_ADAPTIVE_MAX_BANDS 16
+typedef struct ctgn_adaptive_sampling_options {
+    int32_t num_points_per_voxel;   /* 1 */
+    int32_t max_num_points;         /* -1: unlimited */
+    int32_t num_bands;              /* 6 */
+    int32_t reserved;
+    double distance[CTGN_ADAPTIVE_MAX_BANDS];     /* 0.5, 2, 4, 8, 16, 200 */
+    double voxel_size[CTGN_ADAPTIVE_MAX_BANDS];   /* 0.1, 0.2, 0.4, 0.8, 1.6, -1 */
+} ctgn_adaptive_sampling_options;
+void ctgn_adaptive_sampling_options_default(ctgn_adaptive_sampling_options *o);
+
+/* AdaptiveSamplePointsInGrid on the GPU (reference include/ct_icp/algorithm/sampling.h:55-110 — the keypoint sampling of
+ * `sampling: ADAPTIVE`, src/ct_icp/odometry.cpp:539-545): a point at range d = |p| with distance[0] <= d < distance[last] falls
+ * in band j = (first pair with distance >= d) - 1 and in voxel int(p / voxel_size[j]) per axis; every (band, voxel) keeps its
+ * first num_points_per_voxel indices. Output order: band, then voxel (z, y, x ascending), then index (the reference walks
+ * std::unordered_maps, order unspecified); with max_num_points > 0 at most max_num_points + 1 indices are written — the
+ * reference stops on `size() > max` (:96-106). d == distance[0] exactly is undefined behaviour in the reference (entry -1)
+ * and is dropped here. out_indices (host or device memory) must hold n entries. CTGN_ERR_INVALID_ARGUMENT for a band list that
+ * is not ascending, has fewer than 2 or more than CTGN_ADAPTIVE_MAX_BANDS pairs, a used voxel size <= 0, or a band whose
+ * voxel coordinates would not fit 20 bits (distance[j + 1] / voxel_size[j] >= 2^19). */
+ctgn_status ctgn_adaptive_sampling(ctgn_handle h, ctgn_view xyz, size_t n, const ctgn_adaptive_sampling_options *opts,
+                                   uint32_t *out_indices, size_t *out_count);
 
 /* One-shot drop-in for `case GN:` of SELECT_SOLVER (ct_icp.cpp:1008-1014) =
  * ctgn_set_keypoints + ctgn_solve + ctgn_get_world_points (world points are rewritten in place). */

@@ -814,3 +814,70 @@ size_t orc_grid_sampling(const double *raw_xyz, size_t n, double voxel_size, uin
     free(table);
     return kept;
 }
+
+/* AdaptiveSamplePointsInGrid — include/ct_icp/algorithm/sampling.h:55-110 (the keypoint sampling of the NCLT profile,
+ * odometry.cpp:539-545). Per point: range d = |p|; band = (first list entry with distance >= d) - 1, taken only when
+ * distance[0] <= d < distance[last] (:69-76); voxel = int(p / voxel_size[band]) per axis (types.cxx:13-20); a voxel keeps
+ * its first num_points_per_voxel indices (:80-85). d == distance[0] exactly indexes entry -1 in the reference (undefined
+ * behaviour): such a point is dropped here. Emission (:93-108): band by band, voxel by voxel, stopping once MORE than
+ * max_num_points indices have been written (the reference tests `size() > max`, so max + 1 survive). The reference walks
+ * each band's std::unordered_map in its unspecified iteration order; the order fixed here is ascending (z, y, x) voxel
+ * coordinate inside a band, indices ascending inside a voxel. Returns the number of indices written, or (size_t) -1 on an
+ * invalid band list (not ascending, or a used band with a non-positive voxel size). */
+typedef struct { int band, x, y, z; uint32_t first_slot, count; } orc_as_voxel;
+
+static int orc_as_cmp(const void *a, const void *b) {
+    const orc_as_voxel *u = (const orc_as_voxel *) a, *v = (const orc_as_voxel *) b;
+    if (u->band != v->band) return u->band < v->band ? -1 : 1;
+    if (u->z != v->z) return u->z < v->z ? -1 : 1;
+    if (u->y != v->y) return u->y < v->y ? -1 : 1;
+    if (u->x != v->x) return u->x < v->x ? -1 : 1;
+    return 0;
+}
+
+size_t orc_adaptive_sampling(const double *raw_xyz, size_t n, int num_points_per_voxel, int max_num_points, int num_bands,
+                             const double *distance, const double *voxel_size, uint32_t *out_indices) {
+    if (num_bands < 2 || num_points_per_voxel < 1) return (size_t) -1;
+    for (int j = 0; j + 1 < num_bands; ++j)
+        if (!(distance[j] < distance[j + 1]) || !(voxel_size[j] > 0)) return (size_t) -1;
+    const size_t k = (size_t) num_points_per_voxel;
+    size_t cap = 1024;
+    while (cap < 4 * n + 16) cap <<= 1;
+    int64_t *table = (int64_t *) malloc(sizeof(int64_t) * cap);          /* slot -> voxel number */
+    orc_as_voxel *vox = (orc_as_voxel *) malloc(sizeof(orc_as_voxel) * (n + 1));
+    uint32_t *kept = (uint32_t *) malloc(sizeof(uint32_t) * (n + 1) * k);  /* voxel v keeps kept[v*k .. v*k+count) */
+    for (size_t i = 0; i < cap; ++i) table[i] = -1;
+    size_t nvox = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double x = raw_xyz[3 * i], y = raw_xyz[3 * i + 1], z = raw_xyz[3 * i + 2];
+        const double d = sqrt(x * x + y * y + z * z);
+        int lw = 0;                                                      /* std::lower_bound: first entry with distance >= d */
+        while (lw < num_bands && distance[lw] < d) ++lw;
+        if (!(d >= distance[0] && d < distance[num_bands - 1])) continue;
+        const int band = lw - 1;
+        if (band < 0) continue;                                          /* d == distance[0]: UB in the reference, dropped */
+        const double sz = voxel_size[band];
+        const int vx = (int) (x / sz), vy = (int) (y / sz), vz = (int) (z / sz);
+        size_t s = (size_t) ((orc_hash3(vx, vy, vz) + 0x9E3779B97F4A7C15ull * (uint64_t) (band + 1)) & (cap - 1));
+        int64_t v = -1;
+        while (table[s] >= 0) {
+            const orc_as_voxel *c = &vox[table[s]];
+            if (c->band == band && c->x == vx && c->y == vy && c->z == vz) { v = table[s]; break; }
+            s = (s + 1) & (cap - 1);
+        }
+        if (v < 0) {
+            v = (int64_t) nvox++;
+            table[s] = v;
+            vox[v].band = band; vox[v].x = vx; vox[v].y = vy; vox[v].z = vz; vox[v].first_slot = (uint32_t) v; vox[v].count = 0;
+        }
+        if (vox[v].count < k) kept[(size_t) v * k + vox[v].count++] = (uint32_t) i;
+    }
+    qsort(vox, nvox, sizeof(orc_as_voxel), orc_as_cmp);
+    const size_t limit = max_num_points > 0 ? (size_t) max_num_points : (size_t) 0x7fffffff;   /* kMaxNumPoints, :59 */
+    size_t out = 0;
+    for (size_t v = 0; v < nvox && out <= limit; ++v)
+        for (uint32_t j = 0; j < vox[v].count && out <= limit; ++j)
+            out_indices[out++] = kept[(size_t) vox[v].first_slot * k + j];
+    free(table); free(vox); free(kept);
+    return out;
+}

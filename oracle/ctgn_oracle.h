@@ -130,6 +130,12 @@ int orc_register_gn(const orc_map *m, const double *raw_xyz, double *world_xyz, 
  * iteration order is unspecified). Returns the number of kept indices. */
 size_t orc_grid_sampling(const double *raw_xyz, size_t n, double voxel_size, uint32_t *out_indices);
 
+/* AdaptiveSamplePointsInGrid (include/ct_icp/algorithm/sampling.h:55-110): range-banded grid sampling, first
+ * num_points_per_voxel indices per voxel, at most max_num_points + 1 indices (sic, :96-106); order band, then voxel (z, y, x),
+ * then index (the reference's std::unordered_map order is unspecified). (size_t) -1 on an invalid band list. */
+size_t orc_adaptive_sampling(const double *raw_xyz, size_t n, int num_points_per_voxel, int max_num_points, int num_bands,
+                             const double *distance, const double *voxel_size, uint32_t *out_indices);
+
 /* ---- robust-loss (CERES-profile) route: DoRegisterCeres, ct_icp.cpp:457-707 (ctgn_oracle_robust.c) ---- */
 enum { ORC_LOSS_STANDARD = 0, ORC_LOSS_CAUCHY = 1, ORC_LOSS_HUBER = 2, ORC_LOSS_TOLERANT = 3, ORC_LOSS_TRUNCATED = 4 };
 

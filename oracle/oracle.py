@@ -121,6 +121,8 @@ def lib():
                                       C.POINTER(_Prior), C.c_int, C.c_int, C.POINTER(_Summary)]
         L.orc_grid_sampling.restype = C.c_size_t
         L.orc_grid_sampling.argtypes = [dp, C.c_size_t, C.c_double, C.POINTER(C.c_uint32)]
+        L.orc_adaptive_sampling.restype = C.c_size_t
+        L.orc_adaptive_sampling.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_uint32)]
         # reference-shaped containers (ref_shaped.cpp)
         L.orc_refshaped_create.restype = C.c_void_p
         L.orc_refshaped_create.argtypes = [dp, C.c_size_t, C.c_double]
@@ -311,6 +313,23 @@ def grid_sampling(raw, voxel_size) -> np.ndarray:
     raw = _f64(raw).reshape(-1, 3)
     out = np.zeros(len(raw), dtype=np.uint32)
     k = lib().orc_grid_sampling(_dp(raw), len(raw), float(voxel_size), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out[:k].copy()
+
+
+# AdaptiveGridSamplingOptions::distance_voxel_size defaults (include/ct_icp/algorithm/sampling.h:18-25)
+ADAPTIVE_DEFAULT_BANDS = ((0.5, 0.1), (2.0, 0.2), (4.0, 0.4), (8.0, 0.8), (16.0, 1.6), (200.0, -1.0))
+
+
+def adaptive_sampling(raw, distance_voxel_size=ADAPTIVE_DEFAULT_BANDS, num_points_per_voxel=1, max_num_points=-1) -> np.ndarray:
+    """AdaptiveSamplePointsInGrid (sampling.h:55-110); order: band, voxel (z, y, x), index."""
+    raw = _f64(raw).reshape(-1, 3)
+    bands = _f64(np.asarray(distance_voxel_size, dtype=np.float64).reshape(-1, 2))
+    dist, size = np.ascontiguousarray(bands[:, 0]), np.ascontiguousarray(bands[:, 1])
+    out = np.zeros(max(len(raw), 1), dtype=np.uint32)
+    k = lib().orc_adaptive_sampling(_dp(raw), len(raw), int(num_points_per_voxel), int(max_num_points), len(dist), _dp(dist),
+                                    _dp(size), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if k == C.c_size_t(-1).value:
+        raise ValueError("oracle: invalid adaptive sampling options")
     return out[:k].copy()
 
 

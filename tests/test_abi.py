@@ -34,15 +34,17 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header(tmp_path):
     """Compile a tiny C program against include/ctgn.h and compare sizeof/offsetof with the ctypes mirror."""
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ctgn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ctgn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(ctgn_map_options),sizeof(ctgn_options),sizeof(ctgn_motion_prior),sizeof(ctgn_summary),'
                     'sizeof(ctgn_view),sizeof(ctgn_resolution_param),offsetof(ctgn_summary,error_log),'
-                    'offsetof(ctgn_map_options,initial_voxel_capacity));return 0;}\n')
+                    'offsetof(ctgn_map_options,initial_voxel_capacity),sizeof(ctgn_adaptive_sampling_options),'
+                    'offsetof(ctgn_adaptive_sampling_options,voxel_size));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [C.sizeof(L.MapOptions), C.sizeof(L.Options), C.sizeof(L.MotionPrior), C.sizeof(L.Summary), C.sizeof(L.View),
-            C.sizeof(L.ResolutionParam), L.Summary.error_log.offset, L.MapOptions.initial_voxel_capacity.offset]
+            C.sizeof(L.ResolutionParam), L.Summary.error_log.offset, L.MapOptions.initial_voxel_capacity.offset,
+            C.sizeof(L.AdaptiveSamplingOptions), L.AdaptiveSamplingOptions.voxel_size.offset]
     assert got == want
 
 
@@ -58,6 +60,11 @@ def test_defaults_match_the_reference():
     d = cia.CTICPOptions()
     assert (o.num_iters_icp, o.min_number_neighbors, o.max_number_neighbors) == (d.num_iters_icp, d.min_number_neighbors, d.max_number_neighbors)
     assert (o.max_dist_to_plane_ct_icp, o.threshold_orientation_norm) == (d.max_dist_to_plane_ct_icp, d.threshold_orientation_norm)
+    a = L.AdaptiveSamplingOptions()
+    lib.ctgn_adaptive_sampling_options_default(C.byref(a))
+    da = cia.AdaptiveGridSamplingOptions()                                # sampling.h:13-26
+    assert (a.num_points_per_voxel, a.max_num_points, a.num_bands) == (da.num_points_per_voxel, da.max_num_points, 6)
+    assert [(a.distance[j], a.voxel_size[j]) for j in range(6)] == [tuple(map(float, p)) for p in da.distance_voxel_size]
     assert cia.WPOINT3D_DTYPE.itemsize == 64 and cia.WPOINT3D_DTYPE.fields["world_point"][1] == 32   # types.h:35-41
 
 
@@ -78,6 +85,9 @@ def test_no_cpu_fallback_without_a_device():
     m.InsertPointCloud(np.random.default_rng(0).uniform(-3, 3, (500, 3)))
     with pytest.raises(cia.CtgnError) as e:
         m.ComputeNeighborhood([0, 0, 0], 20)
+    assert e.value.status == L.ERR_NO_DEVICE
+    with pytest.raises(cia.CtgnError) as e:
+        cia.AdaptiveSamplePointsInGrid(m, np.ones((10, 3)))
     assert e.value.status == L.ERR_NO_DEVICE
     s = cia.GnSolver(m)
     with pytest.raises(cia.CtgnError) as e:

@@ -493,11 +493,38 @@ def test_grid_sampling_on_device(config_b_full):
         got = cia.grid_sampling(gm, sc.raw, size)
         want = orc.grid_sampling(sc.raw, size)
         assert len(got) == len(want) <= len(sc.raw)                       # test_A_grid_sampling.cxx:7-23
-        assert np.array_equal(np.sort(got), np.sort(want))
+        assert np.array_equal(got, want)                                  # same set AND first-insertion order
     sub = sc.raw[cia.grid_sampling(gm, sc.raw, 0.5)]
     kp = cia.grid_sampling(gm, sub, 1.5)
     assert np.array_equal(np.sort(kp), np.sort(orc.grid_sampling(sub, 1.5))) and 500 < len(kp) < 5000
     assert len(cia.grid_sampling(gm, np.zeros((0, 3)), 1.0)) == 0
+
+
+def test_adaptive_sampling_on_device(config_b_full):
+    """SURVEY 8f row 2, adaptive variant: AdaptiveSamplePointsInGrid (reference include/ct_icp/algorithm/sampling.h:55-110, the
+    NCLT profile's keypoint sampling) on the GPU returns exactly the oracle's indices in the same order, for the default bands,
+    several points per voxel, the max_num_points stop (max + 1 survive), custom bands, float32 strided input and a CUDA tensor."""
+    import torch
+    gm, sc = config_b_full
+    raw = sc.raw
+    for k, mx in ((1, -1), (3, -1), (1, 1500), (2, 7)):
+        o = cia.AdaptiveGridSamplingOptions(num_points_per_voxel=k, max_num_points=mx)
+        got = cia.AdaptiveSamplePointsInGrid(gm, raw, o)
+        want = orc.adaptive_sampling(raw, o.distance_voxel_size, k, mx)
+        assert np.array_equal(got, want) and (mx < 0 or len(got) == mx + 1)
+    d = np.linalg.norm(raw[cia.AdaptiveSamplePointsInGrid(gm, raw)], axis=1)
+    assert d.min() >= 0.5 and d.max() < 200.0
+    custom = cia.AdaptiveGridSamplingOptions(distance_voxel_size=[(1.0, 0.5), (30.0, 2.0), (60.0, -1.0)], num_points_per_voxel=2)
+    assert np.array_equal(cia.AdaptiveSamplePointsInGrid(gm, raw, custom), orc.adaptive_sampling(raw, custom.distance_voxel_size, 2, -1))
+    raw_d = torch.from_numpy(raw).to("cuda:0")
+    got_d = cia.AdaptiveSamplePointsInGrid(gm, raw_d)
+    assert got_d.is_cuda and np.array_equal(got_d.cpu().numpy().astype(np.uint32), orc.adaptive_sampling(raw))
+    on_first = np.array([[0.5, 0.0, 0.0], [0.3, 0.4, 0.0], [1.0, 0.0, 0.0], [0.1, 0.0, 0.0], [0.0, 250.0, 0.0]])
+    assert cia.AdaptiveSamplePointsInGrid(gm, on_first).tolist() == [2]
+    assert len(cia.AdaptiveSamplePointsInGrid(gm, np.zeros((0, 3)))) == 0
+    for bad in ([(2.0, 0.1), (1.0, 0.2)], [(1.0, 0.1)], [(0.5, -1.0), (2.0, 0.1)], [(0.5, 1e-6), (200.0, -1.0)]):
+        with pytest.raises(cia.CtgnError):
+            cia.AdaptiveSamplePointsInGrid(gm, raw[:100], cia.AdaptiveGridSamplingOptions(distance_voxel_size=bad))
 
 
 def test_sequence_of_frames_end_to_end(street_case):

@@ -316,6 +316,61 @@ def test_grid_sampling_first_point_per_voxel():
     assert np.array_equal(np.sort(idx), syn.grid_sample_indices(pts, 1.5))
 
 
+def _adaptive_python(pts, bands, k, max_points):
+    """sampling.h:55-110 restated with Python containers: one dict per band, at most k indices per voxel."""
+    import bisect
+    dist = [b[0] for b in bands]
+    maps = [dict() for _ in bands]
+    for i, p in enumerate(pts):
+        d = float(np.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]))
+        lw = bisect.bisect_left(dist, d)                       # std::lower_bound (:67-72)
+        if not (dist[0] <= d < dist[-1]) or lw == 0:
+            continue
+        size = bands[lw - 1][1]
+        vox = tuple(int(c / size) for c in p)                  # int() truncates toward zero like the C cast
+        lst = maps[lw - 1].setdefault(vox, [])
+        if len(lst) < k:
+            lst.append(i)
+    out = []
+    limit = max_points if max_points > 0 else 2 ** 31
+    for m in maps:
+        for vox in sorted(m, key=lambda v: (v[2], v[1], v[0])):
+            for i in m[vox]:
+                if len(out) > limit:
+                    break
+                out.append(i)
+    return out
+
+
+def test_adaptive_sampling_bands_and_first_k_per_voxel():
+    """AdaptiveSamplePointsInGrid (reference include/ct_icp/algorithm/sampling.h:55-110): band lookup by range, voxel size per
+    band, first num_points_per_voxel indices per voxel, the `size() > max` stop (max + 1 survive), points nearer than the first
+    distance or beyond the last dropped."""
+    rng = np.random.default_rng(17)
+    pts = rng.normal(size=(6000, 3)) * np.array([12.0, 12.0, 1.5])
+    pts[:50] *= 0.02                                           # inside the 0.5 m blind zone
+    pts[50:60] *= 40.0                                         # some beyond 200 m
+    bands = orc.ADAPTIVE_DEFAULT_BANDS
+    for k, mx in ((1, -1), (3, -1), (1, 250), (2, 1)):
+        got = orc.adaptive_sampling(pts, bands, k, mx)
+        want = _adaptive_python(pts, bands, k, mx)
+        assert got.tolist() == want
+        if mx > 0:
+            assert len(got) == mx + 1                          # the reference's off-by-one (:96-106)
+    idx = orc.adaptive_sampling(pts)
+    d = np.linalg.norm(pts[idx], axis=1)
+    assert 0 < len(idx) < len(pts) and d.min() >= 0.5 and d.max() < 200.0
+    # density falls with range: kept fraction of the far band is larger than that of a near band with many points per voxel
+    assert len(set(idx.tolist())) == len(idx)
+    custom = ((1.0, 0.5), (30.0, 2.0), (60.0, -1.0))
+    assert orc.adaptive_sampling(pts, custom, 2, -1).tolist() == _adaptive_python(pts, custom, 2, -1)
+    on_first = np.array([[0.5, 0.0, 0.0], [0.3, 0.4, 0.0], [1.0, 0.0, 0.0]])       # |p| == distance[0]: entry -1 in the reference
+    assert orc.adaptive_sampling(on_first).tolist() == [2]
+    with pytest.raises(ValueError):
+        orc.adaptive_sampling(pts, ((2.0, 0.1), (1.0, 0.2)))
+    assert len(orc.adaptive_sampling(np.zeros((0, 3)))) == 0
+
+
 def test_reference_shaped_variant_gives_the_same_system(street_case):
     """oracle/ref_shaped.cpp (node-based hash map, 80-byte records, std::priority_queue — the CPU baseline's "honest" variant)
     must produce exactly the oracle's packed system: same neighbour sets, same arithmetic after the search."""
