@@ -754,11 +754,15 @@ ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries, size_t 
     MapView mv;
     ctgn_status st = make_map_view(h, radius, &mv);
     if (st != CTGN_OK) return st;
-    double *dq = nullptr, *dout = nullptr;
-    int *dcnt = nullptr;
-    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dq), n * 3 * sizeof(double)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dout), n * (size_t) k * 3 * sizeof(double)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&dcnt), n * sizeof(int)));
+    struct DevBuf {                                   // freed on every exit path
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void) hipFree(p); }
+    } bq, bout, bcnt;
+    HIPCHK(h, hipMalloc(&bq.p, n * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(&bout.p, n * (size_t) k * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(&bcnt.p, n * sizeof(int)));
+    double *dq = static_cast<double *>(bq.p), *dout = static_cast<double *>(bout.p);
+    int *dcnt = static_cast<int *>(bcnt.p);
     HIPCHK(h, hipMemcpyAsync(dq, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(dout, 0, n * (size_t) k * 3 * sizeof(double), h->stream));
     hipLaunchKernelGGL(k_radius_search, dim3((unsigned) ((n + LANE_BLOCK - 1) / LANE_BLOCK)), dim3(LANE_BLOCK),
@@ -767,7 +771,6 @@ ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries, size_t 
     HIPCHK(h, hipMemcpyAsync(out_xyz, dout, n * (size_t) k * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(out_count, dcnt, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipFree(dq); hipFree(dout); hipFree(dcnt);
     return CTGN_OK;
 }
 
