@@ -54,6 +54,12 @@ struct ctgn_context {
     int update_mode = 0;                // 0: host mirror + delta upload, 1: device-resident maintenance (ctgn_devmap)
     std::vector<DevLevel> devlevels;
     DevMapScratch dm;
+    OrderScratch ord;                   // keypoint order of the neighbour-search kernel (sorted by home voxel), see order_keypoints
+    bool order_valid = false, order_stale = true;
+    int planned_iters = 0;              // iteration budget of the running solve (num_iters_icp)
+    int ordering_mode = -1;             // ctgn_set_ordering: -1 automatic, 0 never, 1 always
+    double *d_kp_sorted = nullptr;      // the 7 keypoint arrays in position order (working copy of the GN kernels when ordered)
+    size_t sorted_cap = 0;
 
     // keypoints: one device allocation holding 7 arrays [rx ry rz t wx wy wz] of kp_stride (= n rounded up to 64) doubles
     // back to back, so that one copy moves the whole set (and one copy brings the three world arrays back)
@@ -321,13 +327,73 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     return CTGN_OK;
 }
 
-KpView kp_view(ctgn_handle h) {
+// Should the GN kernels work through this upload in home-voxel order (sorted positions + position-ordered working copy)?
+//  * the searched level exceeds the caches: yes, it pays at once — neighbouring waves then share their voxels in L2 instead of
+//    each fetching them from HBM (config D, 1 M keypoints over a 0.4 GB level: 5.3 -> 3.6 ms per iteration for a 0.2 ms sort);
+//  * the level sits in the caches: the order still puts more rounds on the shared-home fast path and makes the residual
+//    kernel's gathers coherent, worth ~5e-5 us per keypoint and iteration (6-9 us at 132 k), against a sort + permute of
+//    ~60 us + 1.5e-4 us per keypoint (seven short launches). Ordered when the caller's iteration budget covers that — a
+//    132 k-keypoint scan from 13 iterations on; a loop that stops early on its threshold has then paid ~80 us for nothing.
+// Never below 32 k keypoints. ctgn_set_ordering (or CTGN_ORDER=0 / 1 in the environment, for whole test-suite runs) forces it
+// off / on.
+bool want_order(ctgn_handle h, uint64_t level_points) {
+    static const int env_forced = [] { const char *e = std::getenv("CTGN_ORDER"); return e ? std::atoi(e) : -1; }();
+    const int forced = h->ordering_mode >= 0 ? h->ordering_mode : env_forced;
+    if (forced >= 0) return forced != 0 && h->n_kp > 0;
+    if (h->n_kp < 32768) return false;
+    if (level_points * 24ull >= (128ull << 20)) return true;
+    const double n = (double) h->n_kp;
+    return (double) h->planned_iters * n * 5e-5 > 60.0 + 1.5e-4 * n;
+}
+
+// buffers of the ordered mode, sized for the current keypoint capacity; called at upload time for scans that may be ordered so
+// that no allocation lands inside a solve
+ctgn_status order_reserve(ctgn_handle h) {
+    DMCHK(h, order_scratch_reserve(h->ord, (size_t) h->n_kp));
+    if (h->sorted_cap < 7 * (size_t) h->kp_stride) {
+        if (h->d_kp_sorted) HIPCHK(h, hipFree(h->d_kp_sorted));
+        h->d_kp_sorted = nullptr; h->sorted_cap = 0;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp_sorted), 7 * (size_t) h->cap_kp * sizeof(double)));
+        h->sorted_cap = 7 * (size_t) h->cap_kp;
+    }
+    return CTGN_OK;
+}
+
+// first accumulate launch after an upload: sort the positions by home voxel at the search resolution, or decide not to
+ctgn_status order_keypoints(ctgn_handle h, const MapView &mv) {
+    h->order_stale = false;
+    h->order_valid = false;
+    int map_id, nb;
+    double res;
+    search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
+    const uint64_t level_points = h->update_mode == 1 ? h->devlevels[map_id].host.num_points : h->levels[map_id].num_points;
+    if (!want_order(h, level_points)) return CTGN_OK;
+    const size_t c = (size_t) h->kp_stride;
+    DMCHK(h, order_by_home_voxel(h->ord, h->d_kp + 4 * c, h->d_kp + 5 * c, h->d_kp + 6 * c, (size_t) h->n_kp, mv.resolution, h->stream));
+    ctgn_status rs = order_reserve(h);
+    if (rs != CTGN_OK) return rs;
+    hipLaunchKernelGGL(k_kp_permute, dim3(grid_for((size_t) h->n_kp)), dim3(256), 0, h->stream, h->d_kp, c, h->ord.order, h->n_kp,
+                       h->d_kp_sorted);
+    HIPCHK(h, hipGetLastError());
+    h->order_valid = true;
+    return CTGN_OK;
+}
+
+// `working`: the view the GN kernels iterate on. When the upload was ordered and nobody reads per-keypoint results by index
+// (debug capture, the robust route's kernels), that is the position-ordered copy with plain indexing — the hand-over records are
+// then indexed by position too; otherwise the caller-order arrays, through `order` if the upload was ordered.
+KpView kp_view(ctgn_handle h, bool working = false) {
     KpView v;
     const size_t c = (size_t) h->kp_stride;
-    v.rx = h->d_kp; v.ry = h->d_kp + c; v.rz = h->d_kp + 2 * c; v.t = h->d_kp + 3 * c;
-    v.wx = h->d_kp + 4 * c; v.wy = h->d_kp + 5 * c; v.wz = h->d_kp + 6 * c;
+    const bool sorted = working && h->order_valid && !h->debug;
+    double *base = sorted ? h->d_kp_sorted : h->d_kp;
+    v.rx = base; v.ry = base + c; v.rz = base + 2 * c; v.t = base + 3 * c;
+    v.wx = base + 4 * c; v.wy = base + 5 * c; v.wz = base + 6 * c;
     v.sel = h->d_res;
     v.n = h->n_kp;
+    v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
+    v.chunk = h->order_valid ? 2 : 1;
+    v.xcd_split = 0;                    // set per launch (needs the grid size)
     return v;
 }
 
@@ -375,7 +441,11 @@ int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
 }
 
 ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter, bool search_only = false) {
-    KpView kv = kp_view(h);
+    if (h->order_stale) {
+        ctgn_status os = order_keypoints(h, mv);
+        if (os != CTGN_OK) return os;
+    }
+    KpView kv = kp_view(h, !search_only);
     DebugView dv = dbg_view(h);
     EventPair *ev = nullptr;
     if (h->profiling) {
@@ -404,6 +474,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
+            static const bool xcd_off = [] { const char *e = std::getenv("CTGN_XCD"); return e && std::atoi(e) == 0; }();
+            kv.xcd_split = (h->order_valid && g1 >= 64 && !xcd_off) ? 1 : 0;
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
@@ -567,6 +639,8 @@ void ctgn_destroy(ctgn_handle h) {
         for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
         for (auto &d : h->devlevels) devmap_level_free(d);
         devmap_scratch_free(h->dm);
+        order_scratch_free(h->ord);
+        if (h->d_kp_sorted) hipFree(h->d_kp_sorted);
         if (h->d_kp) hipFree(h->d_kp);
         if (h->d_tp) hipFree(h->d_tp);
         if (h->h_tp) hipHostFree(h->h_tp);
@@ -796,7 +870,13 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         h->cap_kp = (int) cap;
     }
     h->n_kp = (int) n;
+    h->order_stale = true;
+    h->order_valid = false;
     h->kp_stride = (int) std::min<size_t>((n + 63) & ~(size_t) 63, (size_t) h->cap_kp);
+    if (n >= 32768 && h->ordering_mode != 0) {       // this upload may be ordered (want_order): have the buffers ready
+        ctgn_status rs = order_reserve(h);
+        if (rs != CTGN_OK) return rs;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));      // staging reuse
     const size_t c = (size_t) h->kp_stride;
     double tmin = INFINITY, tmax = -INFINITY;
@@ -897,6 +977,7 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
     h->launched_iters = 0;
+    h->planned_iters = opts->num_iters_icp;
     h->events_used = 0;
     h->gn_active = true;
     HIPCHK(h, hipEventRecord(h->ev_loop_start, h->stream));
@@ -1298,6 +1379,11 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     MapView mv;
     st = make_map_view(h, -1.0, &mv);
     if (st != CTGN_OK) return st;
+    h->planned_iters = 0;                            // the robust route caps its residuals at max_num_residuals: small sets
+    if (h->order_stale) {
+        st = order_keypoints(h, mv);
+        if (st != CTGN_OK) return st;
+    }
     const RobustBuf rb = robust_buf(h);
     const KpView kv = kp_view(h);
     const int n = h->n_kp;
@@ -1510,6 +1596,12 @@ ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, s
     const size_t n = std::min(max_waves, (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES);
     HIPCHK(h, hipMemcpy(out, h->d_prof + 16, 4 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *n_waves = n;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return CTGN_ERR_INVALID_ARGUMENT;
+    h->ordering_mode = mode;
     return CTGN_OK;
 }
 

@@ -204,6 +204,17 @@ __global__ void k_as_flags(const uint64_t *keys, size_t n, uint32_t k, uint8_t *
     flags[i] = (key != AS_INVALID && (i < k || keys[i - k] != key)) ? 1 : 0;
 }
 
+// home-voxel sort key of a keypoint's world point (see OrderScratch)
+__global__ void k_order_keys(const double *wx, const double *wy, const double *wz, size_t n, double resolution, uint32_t *keys,
+                             uint32_t *idx) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t vx = (uint32_t) voxel_coord(wx[i], resolution) & 4095u, vy = (uint32_t) voxel_coord(wy[i], resolution) & 4095u,
+                   vz = (uint32_t) voxel_coord(wz[i], resolution) & 255u;
+    keys[i] = (vx << 20) | (vy << 8) | vz;
+    idx[i] = (uint32_t) i;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static hipError_t read_counters(DevLevel &L, hipStream_t stream) {
     DM_CHK(hipMemcpyAsync(&L.host, L.counters, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
@@ -400,6 +411,41 @@ hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBa
     DM_CHK(hipStreamSynchronize(stream));
     *out_count = count;
     return hipSuccess;
+}
+
+hipError_t order_scratch_reserve(OrderScratch &S, size_t n) {
+    if (n > S.cap) {
+        order_scratch_free(S);
+        const size_t cap = n + n / 4 + 1024;
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.keys), cap * sizeof(uint32_t)));
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.keys_alt), cap * sizeof(uint32_t)));
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx), cap * sizeof(uint32_t)));
+        DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.order), cap * sizeof(uint32_t)));
+        size_t tmp = 0;
+        DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.order, (int) cap, 0, 32, (hipStream_t) 0));
+        DM_CHK(hipMalloc(&S.temp, tmp));
+        S.temp_bytes = tmp;
+        S.cap = cap;
+    }
+    return hipSuccess;
+}
+
+hipError_t order_by_home_voxel(OrderScratch &S, const double *wx, const double *wy, const double *wz, size_t n, double resolution,
+                               hipStream_t stream) {
+    DM_CHK(order_scratch_reserve(S, n));
+    hipLaunchKernelGGL(k_order_keys, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, wx, wy, wz, n, resolution, S.keys, S.idx);
+    DM_CHK(hipGetLastError());
+    size_t tmp = S.temp_bytes;
+    return hipcub::DeviceRadixSort::SortPairs(S.temp, tmp, S.keys, S.keys_alt, S.idx, S.order, (int) n, 0, 32, stream);
+}
+
+void order_scratch_free(OrderScratch &S) {
+    if (S.keys) (void) hipFree(S.keys);
+    if (S.keys_alt) (void) hipFree(S.keys_alt);
+    if (S.idx) (void) hipFree(S.idx);
+    if (S.order) (void) hipFree(S.order);
+    if (S.temp) (void) hipFree(S.temp);
+    S = OrderScratch{};
 }
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {

@@ -87,6 +87,18 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
 // indices when max_num_points > 0 (the reference stops on size() > max). The band list must be validated by the caller.
 hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBands &bands, int max_num_points, uint32_t *out_idx,
                                     size_t *out_count, hipStream_t stream);
+// Keypoint order for the neighbour-search kernel: indices sorted by the home voxel of their world point (12 / 12 / 8 bits of
+// x / y / z, wrapped — aliasing only interleaves far-apart regions). A permutation only: which wave works on which keypoint —
+// results do not depend on it. `order` stays valid until the next call.
+struct OrderScratch {
+    uint32_t *keys = nullptr, *keys_alt = nullptr, *idx = nullptr, *order = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0, cap = 0;
+};
+hipError_t order_scratch_reserve(OrderScratch &S, size_t n);       // allocations only (kept out of the solve)
+hipError_t order_by_home_voxel(OrderScratch &S, const double *wx, const double *wy, const double *wz, size_t n, double resolution,
+                               hipStream_t stream);
+void order_scratch_free(OrderScratch &S);
 hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream);
 
 }  // namespace ctgn

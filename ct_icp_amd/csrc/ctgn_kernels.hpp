@@ -51,7 +51,19 @@ struct KpView {
     double *wx, *wy, *wz;
     uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: count, then the byte offsets of the kept points
     int n;
+    const uint32_t *order;   // k_accumulate_rows works on keypoint order[s] at position s (positions sorted by home voxel); nullptr = identity
+    int chunk;               // rounds of a tile that take consecutive positions (>= 1)
+    int xcd_split;           // 1: the blocks of XCD x (blockIdx % 8) work inside the x-th eighth of the tiles (needs gridDim >= 8)
 };
+
+// working copy of the keypoint block in position order (ctgn_api.hip, order_keypoints): dst[a][pos] = src[a][order[pos]]
+__global__ void k_kp_permute(const double *src, size_t stride, const uint32_t *order, int n, double *dst) {
+    for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
+        const size_t i = order[pos];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) dst[a * stride + pos] = src[a * stride + i];
+    }
+}
 
 struct GnParams {
     int min_nb, max_nb;
@@ -451,6 +463,7 @@ template <int OCC>
 struct WaveScratch {
     double px[64], py[64], pz[64];     // world point of the tile's keypoints
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
+    int id[64];                        // its index in the caller's arrays; -1 = none
     union {
         struct {
             RowList list[4];
@@ -615,14 +628,35 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     }
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
-    for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
+    // Tile hand-out. Default: wave w of block b starts at tile 4 b + w and strides by the grid. With kp.xcd_split (sorted
+    // positions over a map larger than the caches) the tiles are cut into eight contiguous ranges and the blocks that land on
+    // XCD x (workgroups are dealt round-robin to the 8 XCDs) stay inside range x, so each XCD's L2 holds an eighth of the
+    // map region in flight instead of all eight holding the same lines.
+    int tile_first = blockIdx.x * ROW_WAVES + wave, tile_end = ntiles, tile_step = gridDim.x * ROW_WAVES;
+    if (kp.xcd_split) {
+        const int x = blockIdx.x & 7, per = (ntiles + 7) >> 3;
+        const int blocks_on_x = ((int) gridDim.x - x + 7) >> 3;
+        tile_first = x * per + (blockIdx.x >> 3) * ROW_WAVES + wave;
+        tile_end = min(ntiles, (x + 1) * per);
+        tile_step = blocks_on_x * ROW_WAVES;
+    }
+    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
         // ---------------- phase A: lane (row, sub < rounds) owns keypoint (sub * ntiles + tile) * 4 + row: round r of a
         // tile works on four CONSECUTIVE keypoints (neighbours in the scan usually share their home voxel), while the
         // rounds of one tile are spread over the whole scan with stride 4 * ntiles. Every tile is thereby a uniform
         // sample of the scan, which levels the per-wave work (dense and sparse regions differ ~4x in candidates per
         // keypoint; with contiguous tiles the slowest wave ran 1.8x the mean).
-        const int my_kp = (sub * ntiles + tile) * 4 + row;
-        const bool own = (sub < rounds) && (my_kp < kp.n);
+        // With kp.order (large scans over maps that exceed the caches, ctgn_api.hip) the positions are sorted by home voxel:
+        // the four of a round nearly always share it, neighbouring tiles work on neighbouring voxels at the same time (L2
+        // reuse), and kp.chunk consecutive rounds take consecutive positions, so the staged neighbourhood of one round
+        // usually serves the next; groups of kp.chunk rounds are still strided over the whole order.
+        int my_kp = -1;
+        if (sub < rounds) {
+            const int c = kp.chunk, g = sub / c, j = sub - g * c, cg = min(c, rounds - g * c);
+            const int pos = g * ntiles * 4 * c + tile * 4 * cg + j * 4 + row;
+            if (pos < kp.n) my_kp = kp.order ? (int) kp.order[pos] : pos;
+        }
+        const bool own = my_kp >= 0;
         {
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
@@ -642,6 +676,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         }
         W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
         W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
+        W.id[lane] = my_kp;
         }
         CTGN_TICK(0)
 
@@ -850,8 +885,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // first (the reference's neighbour order; the list is sorted nearest first), in a per-keypoint record. The covariance sums
             // are then taken by the owner lane in phase C — no cross-lane reductions and no point loads here.
             {
-                const int kp_r = (r * ntiles + tile) * 4 + row;
-                if (kp_r < kp.n && !(ablate & 4)) {
+                const int kp_r = W.id[src];
+                if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
                     if (sub == 0) o[0] = (uint32_t) n;
 #pragma unroll
@@ -913,7 +948,10 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
     int n_used_wave = 0;
     const int ntiles = (kp.n + RES_BLOCK - 1) / RES_BLOCK;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int my_kp = tile * RES_BLOCK + tid;
+        // position -> keypoint: with kp.order the lanes of a wave take keypoints of neighbouring voxels, so their gathers share
+        // cache lines (the sums then run in position order: still fixed, a different rounding than index order)
+        const int my_pos = tile * RES_BLOCK + tid;
+        const int my_kp = (kp.order && my_pos < kp.n) ? (int) kp.order[my_pos] : my_pos;
         double u[12], rr = 0.0;
         bool used = false;
         if (my_kp < kp.n) {

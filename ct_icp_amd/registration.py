@@ -354,6 +354,10 @@ class GnSolver:
     def set_ablation(self, mask: int):
         L.check(self._h, L.lib().ctgn_set_ablation(self._h, mask))
 
+    def set_ordering(self, mode: int):
+        """-1 automatic (default), 0 never, 1 always: home-voxel ordering of the GN kernels' work (include/ctgn.h)."""
+        L.check(self._h, L.lib().ctgn_set_ordering(self._h, int(mode)))
+
     def set_variant(self, v: int):
         L.check(self._h, L.lib().ctgn_set_variant(self._h, v))
 

@@ -364,6 +364,12 @@ ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
  * 3 normal/residual/Jacobian, 5 shared-home-voxel fast path). Results are INVALID while a mask is set; only timings
  * are meaningful (ablation profiling). */
 ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
+/* Keypoint ordering of the GN kernels: -1 = automatic (default), 0 = never, 1 = always. When ordered, the kernels work through
+ * the upload in home-voxel order (positions sorted once per upload on the device, the kernels iterate on a position-ordered
+ * working copy): same per-keypoint results, the packed sums then run in position order (a different, still fixed, rounding).
+ * Automatic = when the searched map level exceeds the caches, or when the caller's iteration budget covers the ~80 us the sort
+ * costs at 132 k keypoints; never below 32 k keypoints. Takes effect at the next ctgn_set_keypoints. */
+ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel

@@ -417,6 +417,58 @@ def test_config_c_nclt_profile_matches_oracle(nclt_case):
         assert gm.NumVoxels(li) == om.num_voxels(li)
 
 
+def test_home_voxel_ordering_changes_nothing_but_the_schedule(config_b_full, box_case):
+    """ctgn_set_ordering (include/ctgn.h): working through an upload in home-voxel order (positions sorted on the device, the
+    kernels iterate on a position-ordered working copy, XCD-split tile hand-out) is a scheduling decision. Per-keypoint
+    results — neighbour counts, normals, planarity, used flags — must be bit-identical (debug capture keeps the caller-order
+    arrays and goes through the order indirection), the packed system equal up to summation order, poses and world points
+    equal to rounding, on a full scan (132 k keypoints) and on a small frame; the automatic mode orders from 13 iterations on
+    at this size and must give the forced result bit for bit."""
+    gm, sc = config_b_full
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=4)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t, sc.raw)
+    s = cia.GnSolver(gm)
+    out = {}
+    for mode in (0, 1):
+        s.set_ordering(mode)
+        s.set_debug(True)
+        s.set_keypoints(sc.raw, world0, sc.t)
+        s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=1, threshold_orientation_norm=0.0))
+        dbg = s.get_debug()
+        s.set_debug(False)
+        s.set_keypoints(sc.raw, world0, sc.t)
+        pose, summ, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=4, threshold_orientation_norm=0.0))
+        out[mode] = (dbg, pose, summ, s.world_points(), s.get_system())
+    d0, p0, s0, w0, (A0, b0, n0) = out[0]
+    d1, p1, s1, w1, (A1, b1, n1) = out[1]
+    for key in d0:
+        assert np.array_equal(d0[key], d1[key]), key
+    assert s0.num_residuals_used == s1.num_residuals_used and n0 == n1 and s0.num_iters == s1.num_iters == 4
+    assert np.abs(A1 - A0).max() < 1e-12 * np.abs(A0).max() and np.abs(b1 - b0).max() < 1e-12 * np.abs(b0).max() + 1e-16
+    assert np.abs(p1 - p0).max() < 1e-12 and np.abs(w1 - w0).max() < 1e-10
+    s.set_ordering(-1)                                  # automatic: 16 iterations of 132 k keypoints cover the sort
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pa, _, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=16, threshold_orientation_norm=0.0))
+    s.set_ordering(1)
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pf, _, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=16, threshold_orientation_norm=0.0))
+    s.set_ordering(0)
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pn, _, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=16, threshold_orientation_norm=0.0))
+    assert np.array_equal(pa, pf) and not np.array_equal(pa, pn) and np.abs(pa - pn).max() < 1e-11
+    # a small frame (a few hundred keypoints, one block): forced ordering against the oracle
+    om, gb = build_maps(box_case, 4, with_gpu=True)
+    scb, raw, t, poseb, worldb = _keypoints(box_case, 4, 0.25)
+    sb = cia.GnSolver(gb)
+    sb.set_ordering(1)
+    sb.set_keypoints(raw, worldb, t)
+    pg, sg, _ = sb.solve(poseb, scb.t_begin_end, _opts())
+    po, _, so = orc.register_gn(om, raw, worldb.copy(), t, poseb, scb.t_begin_end, _oopts(_opts()), None, heap_mode=1)
+    assert sg.success and sg.num_residuals_used == so.num_residuals_used and sg.num_iters == so.num_iters
+    tr, rot = se3.pose_error(pg, po)
+    assert tr < 1e-7 and rot < 1e-7
+
+
 def test_full_scan_undistortion(config_b_full):
     """the continuous-time transform of a whole sweep (reference src/ct_icp/odometry.cpp:461-486) against
     the oracle's InterpolatePose * raw, on ~130 k points."""
