@@ -392,7 +392,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.sel = h->d_res;
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
-    v.chunk = h->order_valid ? 2 : 1;
+    v.chunk = h->order_valid ? 2 : 1;    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
     v.xcd_split = 0;                    // set per launch (needs the grid size)
     return v;
 }
@@ -474,8 +474,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
-            static const bool xcd_off = [] { const char *e = std::getenv("CTGN_XCD"); return e && std::atoi(e) == 0; }();
-            kv.xcd_split = (h->order_valid && g1 >= 64 && !xcd_off) ? 1 : 0;
+            kv.xcd_split = (h->order_valid && g1 >= 64) ? 1 : 0;      // D: 3.34 -> 3.15 ms per launch; B2 ordered: +1-2 %
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
