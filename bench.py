@@ -333,7 +333,7 @@ def main():
                                                   "(the reference's keypoint count; latency regime)",
                                             "D": "config D-like: dense analytic street, map {0.5 m, 40 pts} ~0.5 GB (> Infinity Cache), "
                                                  "1 M keypoints spread over the whole map, radius 0.8 (125 voxels), k=20"}[args.workload]
-        if args.workload == "B2" and world == 1 and not args.ablate and not args.inner:
+        if args.workload == "B2" and world == 1 and not args.ablate and not args.inner and args.variant != 1:   # variant 1 has no robust route
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["frame_stages"] = fs = measure_frame_stages(cia, inp, syn, se3, local_rank)
