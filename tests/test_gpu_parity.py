@@ -415,6 +415,16 @@ def test_config_c_nclt_profile_matches_oracle(nclt_case):
     # all three resolutions of the host mirror agree with the oracle map
     for li in range(3):
         assert gm.NumVoxels(li) == om.num_voxels(li)
+    # the 125-voxel instantiation in home-voxel order (position-ordered working copy, XCD-split hand-out at 94 blocks), with and
+    # without debug capture (the latter goes through the order indirection): same registration
+    for debug in (False, True):
+        s.set_ordering(1)
+        s.set_debug(debug)
+        s.set_keypoints(raw, world0, t)
+        pose2, summ2, _ = s.solve(pose0, sc.t_begin_end, o, mm)
+        assert summ2.num_iters == summ.num_iters and summ2.num_residuals_used == summ.num_residuals_used
+        assert np.abs(pose2 - pose1).max() < 1e-11 and np.abs(s.world_points() - world_o).max() < 1e-7
+    assert np.array_equal(s.get_debug()["n_neighbors"], nn)
 
 
 def test_home_voxel_ordering_changes_nothing_but_the_schedule(config_b_full, box_case):
