@@ -178,6 +178,10 @@ inline double read_elem(const void *base, size_t stride, ctgn_dtype dt, size_t i
     return dt == CTGN_F64 ? reinterpret_cast<const double *>(p)[c] : (double) reinterpret_cast<const float *>(p)[c];
 }
 
+// Stage n points of a host or device view as the device map's batch: SoA planes `S.stride` = n rounded up to 64 apart, so that a
+// host view travels in ONE copy (three separate copies cost more than the bytes they move).
+ctgn_status stage_batch(ctgn_handle h, const void *base, size_t stride, ctgn_dtype dt, size_t n);
+
 // A view / output pointer may address device memory (e.g. a torch CUDA tensor): then nothing is staged through the host.
 bool on_device(const void *p) {
     if (!p) return false;
@@ -202,6 +206,16 @@ ctgn_status scatter_device_view(ctgn_handle h, const double *src, size_t src_str
     hipLaunchKernelGGL(k_view_scatter, dim3(grid_for(n)), dim3(256), 0, h->stream, src, src_stride, ncomp, static_cast<char *>(base),
                        stride, dt == CTGN_F64 ? 1 : 0, (int) n);
     HIPCHK(h, hipGetLastError());
+    return CTGN_OK;
+}
+
+ctgn_status stage_batch(ctgn_handle h, const void *base, size_t stride, ctgn_dtype dt, size_t n) {
+    DevMapScratch &S = h->dm;
+    S.stride = std::min((n + 63) & ~(size_t) 63, S.cap);
+    if (on_device(base)) return gather_device_view(h, base, stride, dt, 3, S.pts, S.stride, n);
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) S.h_pts[a * S.stride + i] = read_elem(base, stride, dt, i, a);
+    HIPCHK(h, hipMemcpyAsync(S.pts, S.h_pts, (2 * S.stride + n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return CTGN_OK;
 }
 
@@ -690,14 +704,9 @@ static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t str
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
     DevMapScratch &S = h->dm;
-    if (on_device(xyz_base)) {
-        ctgn_status gs = gather_device_view(h, xyz_base, stride, dt, 3, S.pts, S.cap, n);
+    {
+        ctgn_status gs = stage_batch(h, xyz_base, stride, dt, n);
         if (gs != CTGN_OK) return gs;
-    } else {
-        for (size_t i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz_base, stride, dt, i, a);
-        for (int a = 0; a < 3; ++a)
-            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipMemsetAsync(S.inserted, 0, n, h->stream));
     bool range_error = false, overflow = false;
@@ -1125,14 +1134,9 @@ ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double vo
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
     DevMapScratch &S = h->dm;
-    if (on_device(xyz.base)) {
-        ctgn_status gs = gather_device_view(h, xyz.base, xyz.stride_bytes, xyz.dtype, 3, S.pts, S.cap, n);
+    {
+        ctgn_status gs = stage_batch(h, xyz.base, xyz.stride_bytes, xyz.dtype, n);
         if (gs != CTGN_OK) return gs;
-    } else {
-        for (size_t i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
-        for (int a = 0; a < 3; ++a)
-            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     DMCHK(h, devmap_grid_sampling(S, n, voxel_size, out_indices, out_count, h->stream));   // out_indices: host or device memory
     return CTGN_OK;
@@ -1170,14 +1174,9 @@ ctgn_status ctgn_adaptive_sampling(ctgn_handle h, ctgn_view xyz, size_t n, const
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
     DevMapScratch &S = h->dm;
-    if (on_device(xyz.base)) {
-        ctgn_status gs = gather_device_view(h, xyz.base, xyz.stride_bytes, xyz.dtype, 3, S.pts, S.cap, n);
+    {
+        ctgn_status gs = stage_batch(h, xyz.base, xyz.stride_bytes, xyz.dtype, n);
         if (gs != CTGN_OK) return gs;
-    } else {
-        for (size_t i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) S.h_pts[a * S.cap + i] = read_elem(xyz.base, xyz.stride_bytes, xyz.dtype, i, a);
-        for (int a = 0; a < 3; ++a)
-            HIPCHK(h, hipMemcpyAsync(S.pts + a * S.cap, S.h_pts + a * S.cap, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     DMCHK(h, devmap_adaptive_sampling(S, n, bands, opts->max_num_points, out_indices, out_count, h->stream));
     return CTGN_OK;
@@ -1194,12 +1193,14 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         if (h->d_tp) HIPCHK(h, hipFree(h->d_tp));
         if (h->h_tp) HIPCHK(h, hipHostFree(h->h_tp));
         h->d_tp = nullptr; h->h_tp = nullptr; h->tp_cap = 0;
-        const size_t cap = n + n / 4 + 1024;
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_tp), cap * 7 * sizeof(double)));      // x y z t | out x y z
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_tp), cap * 4 * sizeof(double), hipHostMallocDefault));
+        const size_t cap = ((n + n / 4 + 1024) + 63) & ~(size_t) 63;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_tp), (cap * 7 + 16) * sizeof(double)));      // x y z t | out x y z | pose
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_tp), (cap * 4 + 16) * sizeof(double), hipHostMallocDefault));
         h->tp_cap = cap;
     }
-    const size_t c = h->tp_cap;
+    // array stride: n rounded up to 64, so that the four input arrays + the pose travel in ONE copy and the three output arrays
+    // come back in one (seven separate copies cost more than the bytes they move)
+    const size_t c = std::min((n + 63) & ~(size_t) 63, h->tp_cap);
     const bool dev = on_device(raw.base);
     if (on_device(ts.base) != dev || on_device(out_base) != dev)
         return fail(h, CTGN_ERR_UNSUPPORTED, "the point, timestamp and output views must all be host memory or all be device memory");
@@ -1228,16 +1229,13 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         in_range = in_range && (tbe[0] <= t && t <= tbe[1]);
     }
     if (!in_range) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
-    for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
-    HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    for (int a = 0; a < 4; ++a)
-        HIPCHK(h, hipMemcpyAsync(h->d_tp + a * c, h->h_tp + a * c, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < 14; ++i) h->h_tp[4 * c + i] = pose[i];
+    HIPCHK(h, hipMemcpyAsync(h->d_tp, h->h_tp, (4 * c + 14) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    double *d_out = h->d_tp + 4 * c + 16;           // the pose sits between the inputs and the outputs
     const int grid = (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_transform_points, dim3(grid), dim3(256), 0, h->stream, h->d_tp, h->d_tp + 4 * c, (int) n, c, h->d_pose_in,
-                       tbe[0], tbe[1]);
+    hipLaunchKernelGGL(k_transform_points, dim3(grid), dim3(256), 0, h->stream, h->d_tp, d_out, (int) n, c, h->d_tp + 4 * c, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
-    for (int a = 0; a < 3; ++a)
-        HIPCHK(h, hipMemcpyAsync(h->h_tp + a * c, h->d_tp + (4 + a) * c, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_tp, d_out, 3 * c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < n; ++i) {
         char *p = static_cast<char *>(out_base) + i * out_stride;

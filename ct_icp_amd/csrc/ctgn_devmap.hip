@@ -352,12 +352,12 @@ hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStrea
     if (n == 0) return hipSuccess;
     DM_CHK(ensure_capacity(L, n, stream));
     const unsigned grid = (unsigned) ((n + 255) / 256);
-    hipLaunchKernelGGL(k_dm_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, L.resolution, S.keys, S.idx, L.counters);
+    hipLaunchKernelGGL(k_dm_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, L.resolution, S.keys, S.idx, L.counters);
     DM_CHK(hipGetLastError());
     size_t tmp = S.cub_temp_bytes;
     DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 64, stream));
     hipLaunchKernelGGL(k_dm_insert, dim3(grid), dim3(256), 0, stream, L.slots, (uint32_t) (L.slots_cap - 1), L.blocks, L.blk, L.nblocks_cap,
-                       L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.cap, L.min_distance * L.min_distance, S.inserted);
+                       L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.stride, L.min_distance * L.min_distance, S.inserted);
     DM_CHK(hipGetLastError());
     return read_counters(L, stream);
 }
@@ -372,7 +372,7 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
     if (tcap > S.gs_cap) return hipErrorInvalidValue;
     DM_CHK(hipMemsetAsync(S.gs_keys, 0xFF, tcap * sizeof(unsigned long long), stream));
     DM_CHK(hipMemsetAsync(S.gs_first, 0xFF, tcap * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, voxel_size, S.gs_keys, S.gs_first, (uint32_t) (tcap - 1),
+    hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, voxel_size, S.gs_keys, S.gs_first, (uint32_t) (tcap - 1),
                        S.idx);
     hipLaunchKernelGGL(k_gs_first_flags, dim3(grid), dim3(256), 0, stream, S.gs_first, S.idx, n, S.inserted);
     DM_CHK(hipGetLastError());
@@ -393,7 +393,7 @@ hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBa
     *out_count = 0;
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned) ((n + 255) / 256);
-    hipLaunchKernelGGL(k_as_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.cap, n, bands, S.keys, S.idx);
+    hipLaunchKernelGGL(k_as_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, bands, S.keys, S.idx);
     DM_CHK(hipGetLastError());
     size_t tmp = S.cub_temp_bytes;
     // stable sort on (band, z, y, x): indices stay ascending inside a voxel, so its first k positions are the k indices the

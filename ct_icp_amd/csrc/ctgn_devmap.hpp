@@ -48,6 +48,7 @@ struct DevMapScratch {                   // per handle, shared by the levels
     void *cub_temp = nullptr;
     size_t cub_temp_bytes = 0;
     size_t cap = 0;
+    size_t stride = 0;                   // distance between the x / y / z planes of the staged batch (<= cap; set by the stager)
     double *h_pts = nullptr;             // pinned
     uint8_t *h_inserted = nullptr;       // pinned
     // grid sampling: open-addressing table voxel key -> smallest point index (2 x cap slots, power of two)
