@@ -9,7 +9,7 @@ while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
   rm -rf gpurun_out/pmc$i
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $line --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 50 --warmup 0 --inner ${BENCH_ARGS:-}) > gpurun_out/pmc$i.log 2>&1
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $line --output-format csv -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/bench.py" --steps 200 --warmup 0 --inner ${BENCH_ARGS:-}) > gpurun_out/pmc$i.log 2>&1
   f=$(find gpurun_out/pmc$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python scripts/pmc_summary.py "$f" > gpurun_out/pmc_$i.txt; cat gpurun_out/pmc_$i.txt; else tail -5 gpurun_out/pmc$i.log; fi
   find gpurun_out/pmc$i -type f -size +1M -delete

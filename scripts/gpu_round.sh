@@ -10,11 +10,11 @@ timeout 900 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider >
 fi
 for v in ${VARIANTS:-0 2 1}; do
   extra="--no-cpu-baseline --no-pmc"; [ "$v" = "0" ] && [ "${SKIP_CPU:-0}" != "1" ] && extra=""
-  timeout 600 python bench.py --steps ${STEPS:-50} --warmup 10 --variant $v $extra > gpurun_out/bench_v$v.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench_v$v.log
+  timeout 600 python bench.py --steps ${STEPS:-200} --warmup 20 --variant $v $extra > gpurun_out/bench_v$v.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench_v$v.log
 done
 if [ "${PROFILE:-1}" = "1" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 50 --warmup 0 --inner) > gpurun_out/rocprof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- python "$OLDPWD/bench.py" --steps 200 --warmup 0 --inner) > gpurun_out/rocprof.log 2>&1
   find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r cat > gpurun_out/kernel_stats.csv
   find gpurun_out/prof -name "*kernel_trace.csv" -delete
   cut -c1-160 gpurun_out/kernel_stats.csv
