@@ -78,7 +78,10 @@ def run_sequence(seq, args, device: int):
         if j < args.init_frames:          # the first frames enter the map as they are (ground-truth poses here)
             pose = syn.frame_pose14(knots, j)
         else:
-            kp = np.sort(cia.grid_sampling(gm, raw, args.sample_voxel_size))         # odometry.cpp:538
+            if args.sampling == "ADAPTIVE":                                          # odometry.cpp:539-545 (the NCLT profile)
+                kp = np.sort(cia.AdaptiveSamplePointsInGrid(gm, raw, cia.AdaptiveGridSamplingOptions(max_num_points=args.max_num_keypoints)))
+            else:
+                kp = np.sort(cia.grid_sampling(gm, raw, args.sample_voxel_size))     # odometry.cpp:538
             t2 = time.perf_counter()
             stages["sample"] += t2 - t1
             # constant-velocity initial guess from the two previous optimised frames (odometry.cpp:276-330)
@@ -154,7 +157,11 @@ def run_sequence_device(seq, args, device: int):
         if j < args.init_frames:
             pose = syn.frame_pose14(knots, j)
         else:
-            kp = torch.sort(cia.grid_sampling(gm, raw, args.sample_voxel_size).long()).values
+            if args.sampling == "ADAPTIVE":
+                kp = torch.sort(cia.AdaptiveSamplePointsInGrid(gm, raw, cia.AdaptiveGridSamplingOptions(
+                    max_num_points=args.max_num_keypoints)).long()).values
+            else:
+                kp = torch.sort(cia.grid_sampling(gm, raw, args.sample_voxel_size).long()).values
             kraw, kt = raw[kp], t[kp]
             torch.cuda.synchronize()
             t3 = time.perf_counter()
@@ -198,6 +205,9 @@ def main():
     ap.add_argument("--solver", default="GN", choices=["GN", "CERES"])
     ap.add_argument("--voxel-size", type=float, default=0.5)
     ap.add_argument("--sample-voxel-size", type=float, default=1.5)
+    ap.add_argument("--sampling", default="GRID", choices=["GRID", "ADAPTIVE"],
+                    help="keypoint sampling (Odometry::TryRegister): grid of --sample-voxel-size, or the range-banded sampler of the NCLT profile")
+    ap.add_argument("--max-num-keypoints", type=int, default=1500, help="ADAPTIVE only (nclt_config.yaml: max_num_keypoints)")
     ap.add_argument("--max-distance", type=float, default=100.0)
     ap.add_argument("--init-frames", type=int, default=5)
     ap.add_argument("--gn-prior", action="store_true", help="pass the PreviousFrameMotionModel to the GN solver too")
@@ -242,7 +252,7 @@ def main():
         print(json.dumps({"metric": "frames/s, whole per-frame loop through libctgn", "value": frames / wall, "n_gpus": world,
                           "solver": args.solver, "sequences": len(results), "frames": frames, "wall_seconds": wall,
                           "map": "host mirror" if args.host_map else "device-resident",
-                          "views": "device memory" if args.device_views else "host memory", "per_sequence": results}))
+                          "views": "device memory" if args.device_views else "host memory", "keypoint_sampling": args.sampling, "per_sequence": results}))
 
 
 if __name__ == "__main__":
