@@ -406,7 +406,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.sel = h->d_res;
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
-    v.chunk = h->order_valid ? 2 : 1;    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
+    v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
     v.xcd_split = 0;                    // set per launch (needs the grid size)
     return v;
 }

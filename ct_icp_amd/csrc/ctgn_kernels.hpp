@@ -648,8 +648,9 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         // keypoint; with contiguous tiles the slowest wave ran 1.8x the mean).
         // With kp.order (large scans over maps that exceed the caches, ctgn_api.hip) the positions are sorted by home voxel:
         // the four of a round nearly always share it, neighbouring tiles work on neighbouring voxels at the same time (L2
-        // reuse), and kp.chunk consecutive rounds take consecutive positions, so the staged neighbourhood of one round
-        // usually serves the next; groups of kp.chunk rounds are still strided over the whole order.
+        // reuse). kp.chunk consecutive rounds take consecutive positions (the staged neighbourhood of one round then often
+        // serves the next) and groups of kp.chunk rounds are strided over the whole order; the library passes 1 — longer
+        // chunks unbalance the tiles by more than the reuse saves.
         int my_kp = -1;
         if (sub < rounds) {
             const int c = kp.chunk, g = sub / c, j = sub - g * c, cg = min(c, rounds - g * c);
