@@ -898,8 +898,11 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     snxt_round = r + 1;
                 }
             }
-            // B3: final selection -> list sorted ascending, [0..n)
-            if (!(ablate & 2)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
+            // B3: final selection -> list sorted ascending, [0..n). A row that ends with fewer than min_number_neighbors (or 5)
+            // candidates was never pruned (Ln < k throughout), so Ln already is its exact neighbour count, and the residual kernel
+            // drops it on that count alone: when no row of the wave can be used, skip the selection and hand over counts only.
+            const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr;
+            if (!(ablate & 2) && __any(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
             const int n = (ablate & 2) ? min(Ln, k) : Ln;
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const int e = sub + 16 * m;
-                        if (e < n) {
+                        if (e < n && row_needed) {
                             const uint32_t vis = R.vis[e];
                             const uint32_t bc = occ_tab[vis >> 6];
                             o[n - e] = (bc >> 7) * stride3 + (vis & 63u) * 8u;      // slot 1 = farthest kept ... slot n = nearest
@@ -985,6 +988,10 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                 rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
             }
             const int res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
+            // a keypoint with fewer than min_number_neighbors (or 5) neighbours is dropped by the gates below whatever its
+            // sums are (ct_icp.cpp:769, neighborhood.h:227): do not gather for it, unless debug capture wants its farthest
+            // neighbour. On a street scan that is every second keypoint that has neighbours at all.
+            const int gat_n = ((res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr) ? res_n : 0;
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
             // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240).
             // Gathers in groups of eight (24 independent loads in flight), sums strictly in order.
@@ -992,11 +999,11 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int g = 0; g < KMAX / GG; ++g) {
-                if (GG * g < res_n) {
+                if (GG * g < gat_n) {
                     double gx[GG], gy[GG], gz[GG];
 #pragma unroll
                     for (int q = 0; q < GG; ++q) {
-                        const uint32_t off = (GG * g + q < res_n) ? rec32[1 + GG * g + q] : 0u;
+                        const uint32_t off = (GG * g + q < gat_n) ? rec32[1 + GG * g + q] : 0u;
                         gx[q] = *reinterpret_cast<const double *>(pbase + off);
                         gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
                         gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                     if (g == 0) res_q = Vec3{gx[0], gy[0], gz[0]};      // points[0]: the farthest kept (ct_icp.cpp:791)
 #pragma unroll
                     for (int q = 0; q < GG; ++q) {
-                        if (GG * g + q < res_n) {
+                        if (GG * g + q < gat_n) {
                             const double x = gx[q], y = gy[q], z = gz[q];
                             res_S.x += x; res_S.y += y; res_S.z += z;
                             res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
             const uint4 v4 = in4[q];
             rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
         }
-        const int n = min((int) rec32[0], KMAX);
+        const int n_all = min((int) rec32[0], KMAX);
+        const int n = (n_all >= prm.min_nb && n_all >= 5) ? n_all : 0;          // invalid below (:566-567): nothing to gather, and the search kernel hands over no offsets
         Vec3 S{0, 0, 0}, q0{0, 0, 0};
         Sym3 SS{0, 0, 0, 0, 0, 0};
         // farthest-first, summed front to back like the GN route (neighborhood.h:236-240)
