@@ -404,6 +404,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.rx = base; v.ry = base + c; v.rz = base + 2 * c; v.t = base + 3 * c;
     v.wx = base + 4 * c; v.wy = base + 5 * c; v.wz = base + 6 * c;
     v.sel = h->d_res;
+    v.cnt = h->d_res + (size_t) h->cap_kp * SEL_STRIDE;
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
@@ -873,7 +874,7 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), (cap * 7 + KP_TAIL) * sizeof(double)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), cap * SEL_STRIDE * sizeof(uint32_t)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + cap) * sizeof(uint32_t)));   // records | counts
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }

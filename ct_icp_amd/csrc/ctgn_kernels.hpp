@@ -50,6 +50,7 @@ struct KpView {
     const double *rx, *ry, *rz, *t;
     double *wx, *wy, *wz;
     uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: count, then the byte offsets of the kept points
+    uint32_t *cnt;           // [n] the record's count again, dense: the residual kernel looks here first and only fetches the records it will use
     int n;
     const uint32_t *order;   // k_accumulate_rows works on keypoint order[s] at position s (positions sorted by home voxel); nullptr = identity
     int chunk;               // rounds of a tile that take consecutive positions (>= 1)
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 const int kp_r = W.id[src];
                 if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
-                    if (sub == 0) o[0] = (uint32_t) n;
+                    if (sub == 0) { o[0] = (uint32_t) n; kp.cnt[kp_r] = (uint32_t) n; }
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const int e = sub + 16 * m;
@@ -979,13 +980,19 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
         double u[12], rr = 0.0;
         bool used = false;
         if (my_kp < kp.n) {
-            // the whole 144-byte record in nine independent 16-byte loads
-            const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
+            // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
+            // record in nine independent 16-byte loads
+            const int cnt_n = min((int) kp.cnt[my_kp], KMAX);
+            const bool fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
             uint32_t rec32[SEL_STRIDE];
+            rec32[0] = (uint32_t) cnt_n;
+            if (fetch_rec) {
+                const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
 #pragma unroll
-            for (int q = 0; q < SEL_STRIDE / 4; ++q) {
-                const uint4 v4 = in4[q];
-                rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
+                for (int q = 0; q < SEL_STRIDE / 4; ++q) {
+                    const uint4 v4 = in4[q];
+                    rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
+                }
             }
             const int res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
             // a keypoint with fewer than min_number_neighbors (or 5) neighbours is dropped by the gates below whatever its
