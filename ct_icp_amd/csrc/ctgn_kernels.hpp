@@ -1027,12 +1027,14 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                     }
                 }
             }
-            const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
-            const Vec3 p{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};       // written (or taken as given) by phase A
-            const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
-            if (!(ablate & 8)) used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
+            if (fetch_rec && !(ablate & 8)) {
+                const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+                const Vec3 p{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};       // written (or taken as given) by phase A
+                const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+                used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
+            }
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;
                 dbg.normal[3 * my_kp] = nrm.x; dbg.normal[3 * my_kp + 1] = nrm.y; dbg.normal[3 * my_kp + 2] = nrm.z;
@@ -1047,10 +1049,12 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
         // four doubles per lane and keypoint and was bound by LDS bandwidth). Accumulation order is fixed: deterministic.
         double *rec = s_rec[wave];
         double *my = rec + lane * 13;
+        const unsigned long long used_lanes = __ballot(used);
+        n_used_wave += __popcll(used_lanes);
+        if (used_lanes == 0ull) continue;            // a wave of dropped keypoints adds exact zeros: nothing to stage, nothing to multiply
 #pragma unroll
         for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
         my[12] = used ? rr : 0.0;
-        n_used_wave += __popcll(__ballot(used));
         if (!(ablate & 128)) {
             const int comp = lane & 15;
 #pragma unroll 4
