@@ -368,7 +368,8 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * the upload in home-voxel order (positions sorted once per upload on the device, the kernels iterate on a position-ordered
  * working copy): same per-keypoint results, the packed sums then run in position order (a different, still fixed, rounding).
  * Automatic = when the searched map level exceeds the caches, or when the caller's iteration budget covers the ~80 us the sort
- * costs at 132 k keypoints; never below 32 k keypoints. Takes effect at the next ctgn_set_keypoints. */
+ * costs at 132 k keypoints (num_iters_icp >= 13 there); never below 32 k keypoints. Takes effect at the
+ * next ctgn_set_keypoints. Debug capture and the robust route keep caller-order records and read through the order instead. */
 ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
