@@ -19,6 +19,11 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_frame_steps():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "frame_steps_small.npz")))
+
+
+@pytest.fixture(scope="session")
 def golden_robust():
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "robust_small.npz")))
 

@@ -589,6 +589,28 @@ def test_adaptive_sampling_on_device(config_b_full):
             cia.AdaptiveSamplePointsInGrid(gm, raw[:100], cia.AdaptiveGridSamplingOptions(distance_voxel_size=bad))
 
 
+def test_golden_frame_steps_through_the_gpu(golden_frame_steps):
+    """SURVEY 8f rows 1-3 against the committed golden vectors (tests/golden/frame_steps_small.npz, plain-Python restatements of
+    the reference): both samplers (same indices, same order), the undistortion loop, and the device-resident map's insert
+    decisions / eviction / point sets."""
+    g = golden_frame_steps
+    raw, t, world = g["raw"], g["t"], g["world"]
+    res, min_d, cap = g["map_params"]
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(float(res), float(min_d), int(cap))],
+                                                default_radius=0.75, device_updates=True))
+    for size in (0.5, 1.5):
+        assert np.array_equal(cia.grid_sampling(gm, raw, size), g[f"grid_{size}"])
+    assert np.array_equal(cia.AdaptiveSamplePointsInGrid(gm, raw), g["adaptive_default"])
+    o = cia.AdaptiveGridSamplingOptions(num_points_per_voxel=2, max_num_points=300)
+    assert np.array_equal(cia.AdaptiveSamplePointsInGrid(gm, raw, o), g["adaptive_k2_max300"])
+    assert np.abs(cia.transform_points(gm, raw, t, g["pose"], g["tbe"]) - world).max() < 1e-11
+    assert np.array_equal(np.asarray(gm.InsertPointCloud(world[:2500]), dtype=bool), g["insert_kept_1"])
+    gm.RemoveElementsFarFromLocation(g["remove_loc"], float(g["remove_distance"]))
+    assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(g["points_after_remove"]))
+    assert np.array_equal(np.asarray(gm.InsertPointCloud(world[2500:]), dtype=bool), g["insert_kept_2"])
+    assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(g["points_final"]))
+
+
 def test_sequence_of_frames_end_to_end(street_case):
     """The per-frame loop of Odometry::DoRegister (reference src/ct_icp/odometry.cpp:386-501) with every data-parallel step on
     the GPU — frame grid sampling, keypoint grid sampling, GN registration with the previous-frame motion model, full-scan

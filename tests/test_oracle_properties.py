@@ -12,6 +12,7 @@ from scipy.spatial.transform import Rotation, Slerp
 
 from oracle import oracle as orc
 from oracle import numpy_check as npc
+import ct_icp_amd as cia
 from ct_icp_amd import se3, synthetic as syn
 from conftest import build_maps
 
@@ -369,6 +370,36 @@ def test_adaptive_sampling_bands_and_first_k_per_voxel():
     with pytest.raises(ValueError):
         orc.adaptive_sampling(pts, ((2.0, 0.1), (1.0, 0.2)))
     assert len(orc.adaptive_sampling(np.zeros((0, 3)))) == 0
+
+
+def _sorted_rows(a):
+    a = np.asarray(a).reshape(-1, 3)
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def test_golden_frame_steps(golden_frame_steps):
+    """tests/golden/frame_steps_small.npz (plain-Python restatements of sub_sample_frame, AdaptiveSamplePointsInGrid, the
+    undistortion loop and the map insert / eviction rules, tests/golden/make_golden_frame_steps.py) against the C oracle and
+    against the product's host-side map mirror."""
+    g = golden_frame_steps
+    raw, t = g["raw"], g["t"]
+    for size in (0.5, 1.5):
+        assert np.array_equal(orc.grid_sampling(raw, size), g[f"grid_{size}"])
+    assert np.array_equal(orc.adaptive_sampling(raw), g["adaptive_default"])
+    assert np.array_equal(orc.adaptive_sampling(raw, orc.ADAPTIVE_DEFAULT_BANDS, 2, 300), g["adaptive_k2_max300"])
+    assert np.abs(orc.transform_points(g["pose"], g["tbe"], t, raw) - g["world"]).max() < 1e-12
+    res, min_d, cap = g["map_params"]
+    om = orc.Map(resolutions=[(float(res), float(min_d), int(cap))], default_radius=0.75)
+    hm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(float(res), float(min_d), int(cap))],
+                                                default_radius=0.75, device=-1))
+    world = g["world"]
+    for m_insert, m_remove, m_export in ((om.insert, om.remove_far, lambda: om.export(0)),
+                                         (hm.InsertPointCloud, hm.RemoveElementsFarFromLocation, lambda: hm.MapAsPointCloud(0))):
+        assert np.array_equal(np.asarray(m_insert(world[:2500]), dtype=bool), g["insert_kept_1"])
+        m_remove(g["remove_loc"], float(g["remove_distance"]))
+        assert np.array_equal(_sorted_rows(m_export()), _sorted_rows(g["points_after_remove"]))
+        assert np.array_equal(np.asarray(m_insert(world[2500:]), dtype=bool), g["insert_kept_2"])
+        assert np.array_equal(_sorted_rows(m_export()), _sorted_rows(g["points_final"]))
 
 
 def test_reference_shaped_variant_gives_the_same_system(street_case):
