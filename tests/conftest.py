@@ -100,3 +100,28 @@ def build_maps(case, n_map_frames, with_gpu=False, device=0, subsample=None):
         if gm is not None:
             gm.InsertPointCloud(pts)
     return om, gm
+
+
+def load_frame_steps_module():
+    """tests/golden/make_golden_frame_steps.py as a module (its DictMap is the plain-Python model of the map rules)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_frame_steps", os.path.join(ROOT, "tests", "golden", "make_golden_frame_steps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+MAP_FUZZ_LEVELS = ((0.5, 0.05, 4), (1.0, 0.2, 20), (0.3, 0.0, 2))
+
+
+def map_fuzz_steps(seed, min_d, steps=12):
+    """Random insert batches (clustered: full voxels, near-duplicates below the minimum distance, sign flips across the axis
+    planes) with an eviction centre every third step."""
+    rng = np.random.default_rng(100 + seed)
+    centre = np.zeros(3)
+    for step in range(steps):
+        centre = centre + rng.normal(0, 1.5, 3)
+        pts = centre + rng.normal(0, 2.0, (300, 3)) * np.array([1.0, 1.0, 0.3])
+        pts[::7] = pts[1::7][:len(pts[::7])] + rng.normal(0, 0.3 * max(min_d, 0.01), (len(pts[::7]), 3))
+        pts[::11, rng.integers(0, 3)] *= -1.0
+        yield pts, (centre.copy() if step % 3 == 2 else None)

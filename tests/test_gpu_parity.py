@@ -611,6 +611,25 @@ def test_golden_frame_steps_through_the_gpu(golden_frame_steps):
     assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(g["points_final"]))
 
 
+def test_device_map_fuzz_against_a_dict_model():
+    """The fuzz of tests/test_oracle_properties.py::test_map_maintenance_fuzz_against_a_dict_model on the DEVICE-resident map:
+    insert decisions, evictions and point sets against the plain-Python dict-of-lists model of map.h:261-293,305-322."""
+    from conftest import MAP_FUZZ_LEVELS, load_frame_steps_module, map_fuzz_steps
+    mk = load_frame_steps_module()
+    for seed, (res, min_d, cap) in enumerate(MAP_FUZZ_LEVELS):
+        model = mk.DictMap(res, min_d, cap)
+        gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(res, min_d, cap)], default_radius=0.75,
+                                                    device_updates=True))
+        for step, (pts, evict) in enumerate(map_fuzz_steps(seed, min_d)):
+            assert np.array_equal(np.asarray(gm.InsertPointCloud(pts), dtype=bool), model.insert(pts)), (seed, step)
+            if evict is not None:
+                model.remove_far(evict, 4.0)
+                gm.RemoveElementsFarFromLocation(evict, 4.0)
+            want_pts = _sorted_rows(model.points())
+            assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), want_pts), (seed, step)
+            assert gm.NumPoints() == len(want_pts)
+
+
 def test_sequence_of_frames_end_to_end(street_case):
     """The per-frame loop of Odometry::DoRegister (reference src/ct_icp/odometry.cpp:386-501) with every data-parallel step on
     the GPU — frame grid sampling, keypoint grid sampling, GN registration with the previous-frame motion model, full-scan

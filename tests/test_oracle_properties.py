@@ -6,6 +6,8 @@ test/unit/ct_icp/test_ct_icp.cxx:10-12), so the oracle is pinned by
   (2) golden vectors from an independent NumPy/SciPy derivation (tests/golden/make_golden.py),
   (3) recovery of a known ground-truth pose on noise-free planes.
 """
+import os
+
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation, Slerp
@@ -400,6 +402,30 @@ def test_golden_frame_steps(golden_frame_steps):
         assert np.array_equal(_sorted_rows(m_export()), _sorted_rows(g["points_after_remove"]))
         assert np.array_equal(np.asarray(m_insert(world[2500:]), dtype=bool), g["insert_kept_2"])
         assert np.array_equal(_sorted_rows(m_export()), _sorted_rows(g["points_final"]))
+
+
+def test_map_maintenance_fuzz_against_a_dict_model():
+    """Random insert / evict sequences (clustered points: full voxels, near-duplicates below the minimum distance, negative and
+    axis-plane coordinates, evictions that empty and refill voxels) on the C oracle's map and on the product's host mirror against
+    the plain-Python dict-of-lists model of include/ct_icp/map.h:261-293,305-322 (tests/golden/make_golden_frame_steps.py)."""
+    from conftest import MAP_FUZZ_LEVELS, load_frame_steps_module, map_fuzz_steps
+    mk = load_frame_steps_module()
+    for seed, (res, min_d, cap) in enumerate(MAP_FUZZ_LEVELS):
+        model = mk.DictMap(res, min_d, cap)
+        om = orc.Map(resolutions=[(res, min_d, cap)], default_radius=0.75)
+        hm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(res, min_d, cap)], default_radius=0.75, device=-1))
+        for step, (pts, evict) in enumerate(map_fuzz_steps(seed, min_d)):
+            want = model.insert(pts)
+            assert np.array_equal(np.asarray(om.insert(pts), dtype=bool), want), (seed, step)
+            assert np.array_equal(np.asarray(hm.InsertPointCloud(pts), dtype=bool), want), (seed, step)
+            if evict is not None:
+                model.remove_far(evict, 4.0)
+                om.remove_far(evict, 4.0)
+                hm.RemoveElementsFarFromLocation(evict, 4.0)
+            want_pts = _sorted_rows(model.points())
+            assert np.array_equal(_sorted_rows(om.export(0)), want_pts), (seed, step)
+            assert np.array_equal(_sorted_rows(hm.MapAsPointCloud(0)), want_pts), (seed, step)
+            assert hm.NumPoints() == len(want_pts) == om.num_points()
 
 
 def test_reference_shaped_variant_gives_the_same_system(street_case):
