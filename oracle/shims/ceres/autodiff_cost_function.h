@@ -1,0 +1,2 @@
+// oracle/_ref shim: see ceres.h
+#include "ceres.h"
