@@ -141,5 +141,12 @@ def pose_error(pose_a, pose_b):
     a = np.asarray(pose_a, dtype=np.float64).ravel()
     b = np.asarray(pose_b, dtype=np.float64).ravel()
     tr = max(np.linalg.norm(a[4:7] - b[4:7]), np.linalg.norm(a[11:14] - b[11:14]))
-    rot = max(np.radians(angular_distance_deg(a[0:4], b[0:4])), np.radians(angular_distance_deg(a[7:11], b[7:11])))
+    # angle of the relative rotation from the vector part of conj(qa) * qb: 2 atan2(|v|, |w|) -- accurate down to 1e-16, where the
+    # acos((trace - 1) / 2) of AngularDistance (types.h:141-150) stops resolving at sqrt(eps) ~ 1.5e-8
+    def _angle(qa, qb):
+        qa, qb = quat_normalize(qa), quat_normalize(qb)
+        w = float(np.dot(qa, qb))
+        v = qa[3] * qb[0:3] - qb[3] * qa[0:3] - np.cross(qa[0:3], qb[0:3])
+        return 2.0 * np.arctan2(np.linalg.norm(v), abs(w))
+    rot = max(_angle(a[0:4], b[0:4]), _angle(a[7:11], b[7:11]))
     return float(tr), float(rot)

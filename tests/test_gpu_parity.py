@@ -374,20 +374,6 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
             dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def nclt_case():
-    """Config-C-like (BASELINE.json configs[2]): HDL-32E pattern, jittery Segway-like motion, the NCLT profile's three-resolution
-    map (0.5 / 1 / 2 m x 30 pts; default radius 0.8 => the 0.5 m level, 125 voxels per query), min_number_neighbors 10,
-    20 iterations, <= 1500 keypoints (reference config/odometry/nclt_config.yaml:19-104)."""
-    scene = syn.street_scene(150.0, seed=2, half_width=(7.0, 9.0))
-    dirs, rel_t = syn.lidar_pattern("hdl32", azimuth_steps=900)
-    knots = syn.driving_trajectory(10, dt=0.1, speed=2.0, yaw_rate=0.3, height=1.0, jitter=0.02, seed=2, start_x=20.0)
-    scans = [syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), max_range=60.0, noise=0.02,
-                               seed=200 + j) for j in range(9)]
-    return dict(scene=scene, knots=knots, scans=scans, resolutions=[(0.5, 0.08, 30), (1.0, 0.08, 30), (2.0, 0.08, 30)],
-                default_radius=0.8)
-
-
 def test_config_c_nclt_profile_matches_oracle(nclt_case):
     case = nclt_case
     om, gm = build_maps(case, 8, with_gpu=True)

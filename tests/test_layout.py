@@ -15,7 +15,8 @@ def _files(sub, exts):
 
 def test_product_never_touches_the_oracle():
     # comments may MENTION the oracle; includes, imports, links and paths may not exist
-    pat = re.compile(r"#include[^\n]*oracle|import[^\n]*oracle|from\s+oracle|libctgn_oracle|ctgn_oracle\.|oracle/|orc_[a-z_]+\(|numpy_check")
+    pat = re.compile(r"#include[^\n]*oracle|import[^\n]*oracle|from\s+oracle|libctgn_oracle|libctgn_ref|ctgn_oracle\.|oracle/|orc_[a-z_]+\(|ref_[a-z_]+\("
+                     r"|numpy_check|mini_eigen|shims/")
     for path in _files("ct_icp_amd", (".py", ".hpp", ".hip", ".cpp", ".h", "Makefile")):
         txt = open(path, errors="ignore").read()
         assert not pat.search(txt), f"{path} references the oracle"
