@@ -92,7 +92,7 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
             double sq_min = 1.7976931348623157e308;
             for (uint32_t q = 0; q < count; ++q) {
                 const double dx = bx[q] - px, dy = by[q] - py, dz = bz[q] - pz;
-                const double sq = dx * dx + dy * dy + dz * dz;
+                const double sq = sq_norm3(dx, dy, dz);
                 if (sq < sq_min) sq_min = sq;
             }
             take = sq_min > min_dist_sq;
@@ -117,7 +117,7 @@ __global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *bloc
         if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
         const double *bx = blocks + (size_t) s.block * 3 * blk;
         const double dx = bx[0] - lx, dy = bx[blk] - ly, dz = bx[2 * blk] - lz;
-        if (sqrt(dx * dx + dy * dy + dz * dz) > distance) {
+        if (sqrt(sq_norm3(dx, dy, dz)) > distance) {
             slots[i] = Slot{KEY_TOMB, 0u, 0u};
             const int t = atomicAdd(&cnt->free_top, 1);
             free_list[t] = s.block;

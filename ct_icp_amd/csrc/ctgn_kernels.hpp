@@ -234,7 +234,7 @@ __device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, doub
                 const double *bx = m.blocks + (size_t) block * 3 * m.blk;
                 for (uint32_t i = 0; i < count; ++i) {
                     double dx = bx[i] - p.x, dy = bx[m.blk + i] - p.y, dz = bx[2 * m.blk + i] - p.z;
-                    double d2 = dx * dx + dy * dy + dz * dz;
+                    double d2 = sq_norm3(dx, dy, dz);
                     if (d2 > m.r2thr) continue;                       // map.h:491-493
                     int pos;
                     if (n < k) pos = n++;                             // map.h:494-500
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 };
                 auto test = [&](const Cand &cnd) {
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const double d2 = sq_norm3(dx, dy, dz);
                     // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
                     // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
                     const bool pass = cnd.valid && d2 <= kth_d2;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 };
                 auto test = [&](const Cand &cnd) {
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    const double d2 = sq_norm3(dx, dy, dz);
                     const bool pass = cnd.valid && d2 <= kth_d2;
                     const uint32_t pm = row_bits(__ballot(pass), row);
                     if (pass) {

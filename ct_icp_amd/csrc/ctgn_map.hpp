@@ -19,6 +19,8 @@
 #include <cstring>
 #include <vector>
 
+#include "ctgn_math.hpp"      // sq_norm3: the reference build's rounding of a squared distance
+
 namespace ctgn {
 
 struct Slot {
@@ -172,7 +174,7 @@ struct VoxelLevel {
                 double sq_min = 1.7976931348623157e308;
                 for (uint32_t k = 0; k < s.count; ++k) {
                     double dx = x[k] - px, dy = y[k] - py, dz = z[k] - pz;
-                    double sq = dx * dx + dy * dy + dz * dz;
+                    double sq = sq_norm3(dx, dy, dz);
                     if (sq < sq_min) sq_min = sq;
                 }
                 if (sq_min > min_distance * min_distance) {
@@ -216,7 +218,7 @@ struct VoxelLevel {
             if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
             const double *x = bx(s.block);
             double dx = x[0] - loc[0], dy = x[blk] - loc[1], dz = x[2 * blk] - loc[2];
-            if (std::sqrt(dx * dx + dy * dy + dz * dz) > distance) {
+            if (std::sqrt(sq_norm3(dx, dy, dz)) > distance) {
                 num_points -= s.count;
                 num_voxels--;
                 num_tombs++;

@@ -24,6 +24,14 @@ CTGN_HD Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z
 CTGN_HD Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 CTGN_HD Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
 CTGN_HD double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// |d|^2 exactly as the reference's stock build evaluates (p - q).squaredNorm() / .norm() of a Vector3d (map.h:279-286,313,491):
+// Eigen's completely unrolled redux associates c0 + (c1 + c2) (Core/Redux.h), and a build without -march cannot fuse multiply-adds.
+// This value feeds discrete decisions (radius test, k-th best, minimum-distance insert, eviction), so it is kept bit-identical.
+CTGN_HD double sq_norm3(double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return xx + (yy + zz);
+}
 CTGN_HD Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 struct Quat {

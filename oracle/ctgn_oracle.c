@@ -41,6 +41,12 @@ struct orc_map {
     orc_level levels[ORC_MAX_RESOLUTIONS];
 };
 
+/* Eigen's association order for a 3-vector reduction (squaredNorm / norm / dot of Vector3d): the completely unrolled scalar redux
+ * splits [0, 3) into [0, 1) and [1, 3) (Eigen/src/Core/Redux.h, redux_novec_unroller), i.e. c0 + (c1 + c2) -- NOT (c0 + c1) + c2.
+ * With the reference's stock build flags (no -march, so no FMA) this is the rounding that decides `distance > radius`
+ * (map.h:491-493), the heap comparisons (:494-500), the min-distance insert test (:279-286) and the eviction test (:313). */
+static inline double sq_norm3(double dx, double dy, double dz) { return dx * dx + (dy * dy + dz * dz); }
+
 static inline uint64_t orc_hash3(int x, int y, int z) {
     /* any hash works: bucket order is not observable through the queries.
      * (the reference's is x*73856093 + y*19349669 + z*83492791, types.h:610-623) */
@@ -142,7 +148,7 @@ static int level_insert_point(orc_level *L, const double p[3]) {
         double sq_dist_min = DBL_MAX;
         for (int i = 0; i < v->count; ++i) {
             double dx = v->pts[3 * i] - p[0], dy = v->pts[3 * i + 1] - p[1], dz = v->pts[3 * i + 2] - p[2];
-            double sq = dx * dx + dy * dy + dz * dz;
+            double sq = sq_norm3(dx, dy, dz);
             if (sq < sq_dist_min) sq_dist_min = sq;
         }
         if (sq_dist_min > min_dist * min_dist) {
@@ -173,7 +179,7 @@ void orc_map_remove_far(orc_map *m, const double location[3], double distance) {
         for (size_t v = 0; v < L->num_voxels; ++v) {
             orc_voxel *vx = &L->voxels[v];
             double dx = vx->pts[0] - location[0], dy = vx->pts[1] - location[1], dz = vx->pts[2] - location[2];
-            double d = sqrt(dx * dx + dy * dy + dz * dz);
+            double d = sqrt(sq_norm3(dx, dy, dz));
             if (d > distance) {
                 L->num_points -= (uint64_t) vx->count;
                 free(vx->pts);
@@ -308,7 +314,7 @@ int orc_map_radius_search(const orc_map *m, const double query[3], double radius
                 for (int i = 0; i < vb->count; ++i, ++visit) {
                     double dx = vb->pts[3 * i] - query[0], dy = vb->pts[3 * i + 1] - query[1],
                            dz = vb->pts[3 * i + 2] - query[2];
-                    double sq = dx * dx + dy * dy + dz * dz;
+                    double sq = sq_norm3(dx, dy, dz);
                     double distance = sqrt(sq);                       /* map.h:491 (.norm()) */
                     if (distance > radius) continue;                  /* map.h:492 */
                     heap_item it;
@@ -594,7 +600,7 @@ static int gn_keypoint(const orc_map *m, const double raw[3], const double world
     if (!orc_neighborhood(nb, n, normal, &a2d)) return 0;              /* :778 (invalid below 5 points:
         the reference would then read an uninitialised normal; defined here as "skip") */
     const double *tb = pose + 4;
-    if (normal[0] * (tb[0] - world[0]) + normal[1] * (tb[1] - world[1]) + normal[2] * (tb[2] - world[2]) < 0) {
+    if (normal[0] * (tb[0] - world[0]) + (normal[1] * (tb[1] - world[1]) + normal[2] * (tb[2] - world[2])) < 0) {   /* Eigen dot: c0 + (c1 + c2) */
         normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2];   /* :782-784 */
     }
     if (normal_out) { normal_out[0] = normal[0]; normal_out[1] = normal[1]; normal_out[2] = normal[2]; }

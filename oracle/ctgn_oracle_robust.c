@@ -478,7 +478,7 @@ size_t orc_robust_build(const orc_map *m, const double *raw_xyz, const double *w
         /* :570-573: normal . (BeginTr - BeginTr) < 0 never holds: the normal keeps the eigen-solver's sign */
         double weight = pow(a2d, o->power_planarity);                           /* :574 */
         const double dx = nb[0] - world[0], dy = nb[1] - world[1], dz = nb[2] - world[2];
-        weight = lw * weight + ln * exp(-sqrt(dx * dx + dy * dy + dz * dz) /
+        weight = lw * weight + ln * exp(-sqrt(dx * dx + (dy * dy + dz * dz)) /
                                         (o->max_dist_to_plane_ct_icp * o->min_number_neighbors));   /* :576-579 */
         const double alpha = orc_alpha_timestamp(t[k], tbe[0], tbe[1]);        /* :592 */
         for (int i = 0; i < o->num_closest_neighbors; ++i) {                    /* :585-595 */

@@ -67,7 +67,7 @@ std::vector<Vec3> radius_search(const RefMap &m, const double q[3], double radiu
                 for (size_t i = 0; i < blk.points.size(); ++i) {
                     neighbor = blk.points[i];                                   // 80-byte copy, as map.h:481
                     const double dx = neighbor.xyz.x - q[0], dy = neighbor.xyz.y - q[1], dz = neighbor.xyz.z - q[2];
-                    const double distance = std::sqrt(dx * dx + dy * dy + dz * dz);
+                    const double distance = std::sqrt(dx * dx + (dy * dy + dz * dz));
                     if (distance > radius) continue;
                     if ((int) pq.size() == max_num_neighbors) {
                         if (distance < std::get<0>(pq.top())) {

@@ -7,8 +7,13 @@
 //
 // What is restated here (arithmetic of the third-party library, Eigen 3.3/3.4 -- unpinned by the reference, see
 // SURVEY.md section 8c) and what is not:
-//   * dense fixed/dynamic matrices are evaluated eagerly (no expression templates); every operation is the plain
-//     textbook loop in the same association order Eigen's unvectorised path uses;
+//   * dense fixed/dynamic matrices are evaluated eagerly (no expression templates); element-wise operations are the plain
+//     loops; REDUCTIONS (sum, squaredNorm, norm, dot, trace-free redux) of fixed-size objects follow Eigen's association
+//     order, because it decides discrete results (`(p - q).norm() > radius`, map.h:491-493): the completely unrolled
+//     scalar redux splits a range [s, s+n) into halves of n/2 and n - n/2 (Core/Redux.h, redux_novec_unroller) -- for a
+//     3-vector that is c0 + (c1 + c2) -- and even-sized double vectors go through 2-wide packets (stock x86-64 build,
+//     SSE2: redux_vec_unroller over packets, then predux = p[0] + p[1]) -- for a 4-vector (c0 + c2) + (c1 + c3);
+//     dynamic-size reductions are summed left to right;
 //   * Quaternion: product, conjugate, inverse, normalize(d), _transformVector (v + w*uv + qv x uv with uv = 2 qv x v),
 //     toRotationMatrix, the matrix -> quaternion branches (trace / largest diagonal), slerp with the
 //     |d| >= 1 - eps linear fallback: restated from Eigen/src/Geometry/Quaternion.h as documented;
@@ -263,25 +268,48 @@ namespace Eigen {
         template<typename OD> CommaInitializer<D> operator<<(const MatrixBase<OD> &o) { return CommaInitializer<D>(derived(), o); }
 
         // ---- reductions
-        Scalar squaredNorm() const {
-            // Eigen's unvectorised redux: coefficients in storage (column-major) order, left to right
-            Scalar s = internal::abs2(coeff(0, 0));
-            bool first = true;
-            for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) {
-                if (first) { first = false; continue; }
-                s = s + internal::abs2(coeff(i, j));
+        // Eigen's redux association order (see the header): completely unrolled halving tree for fixed sizes, through
+        // 2-wide packets when the scalar is double and the size is even; left to right for dynamic sizes
+        template<typename F> Scalar redux_(F coeff_at) const {
+            const Index n = size();
+            if (n == 0) return Scalar(0);
+            if (SizeAtCompileTime == Dynamic) {
+                Scalar s = coeff_at(0);
+                for (Index i = 1; i < n; ++i) s = s + coeff_at(i);
+                return s;
             }
-            return s;
+            if (std::is_same<Scalar, double>::value && n % 2 == 0 && n >= 2) {
+                struct P { Scalar a, b; };
+                struct T {
+                    static P run(F &f, Index start, Index len) {          // start, len in packets
+                        if (len == 1) return P{f(2 * start), f(2 * start + 1)};
+                        const Index half = len / 2;
+                        P l = run(f, start, half), r = run(f, start + half, len - half);
+                        return P{l.a + r.a, l.b + r.b};
+                    }
+                };
+                P p = T::run(coeff_at, 0, n / 2);
+                return p.a + p.b;
+            }
+            struct T {
+                static Scalar run(F &f, Index start, Index len) {
+                    if (len == 1) return f(start);
+                    const Index half = len / 2;
+                    Scalar l = run(f, start, half);
+                    Scalar r = run(f, start + half, len - half);
+                    return l + r;
+                }
+            };
+            return T::run(coeff_at, 0, n);
+        }
+        Scalar squaredNorm() const {
+            auto f = [this](Index i) { return internal::abs2(this->coeff(i)); };
+            return redux_(f);
         }
         Scalar norm() const { using std::sqrt; return sqrt(squaredNorm()); }
         Scalar sum() const {
-            if (size() == 0) return Scalar(0);
-            Scalar s = coeff(0, 0); bool first = true;
-            for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) {
-                if (first) { first = false; continue; }
-                s = s + coeff(i, j);
-            }
-            return s;
+            auto f = [this](Index i) { return this->coeff(i); };
+            return redux_(f);
         }
         Scalar mean() const { return sum() / Scalar(size()); }
         Scalar prod() const { Scalar s(1); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) s = s * coeff(i, j); return s; }
@@ -302,9 +330,8 @@ namespace Eigen {
         bool allFinite() const { using std::isfinite; for (Index i = 0; i < size(); ++i) if (!isfinite(coeff(i))) return false; return true; }
         template<typename OD> Scalar dot(const MatrixBase<OD> &o) const {
             assert(size() == o.size());
-            Scalar s = coeff(0) * o.coeff(0);
-            for (Index i = 1; i < size(); ++i) s = s + coeff(i) * o.coeff(i);
-            return s;
+            auto f = [this, &o](Index i) { return this->coeff(i) * o.coeff(i); };
+            return redux_(f);
         }
         template<typename OD> Matrix<Scalar, 3, 1> cross(const MatrixBase<OD> &o) const {
             Matrix<Scalar, 3, 1> r;
