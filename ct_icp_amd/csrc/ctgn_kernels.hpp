@@ -956,11 +956,18 @@ inline size_t rows_kernel_smem() {
 // Splitting it off keeps the neighbour-search kernel free of the eigen-solver's registers and runs this part with
 // all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
 // ================================================================================================
+// neighbourhood sums handed over by k_search_dense (ctgn_dense.hpp), indexed by POSITION
+struct NbSums {
+    double *v;                    // [12][stride]: S.x S.y S.z | SS.xx xy xz yy yz zz | q.x q.y q.z
+    uint32_t *cnt;                // [n] neighbour count
+    size_t stride;
+};
+
 constexpr int RES_BLOCK = 256;
 constexpr int GG = 8;                // neighbours gathered per group: 3 x GG independent loads in flight per lane
 
 __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                                 double *partials, DebugView dbg, int ablate) {
+                                                                 double *partials, DebugView dbg, int ablate, NbSums sums) {
     __shared__ double s_rec[RES_BLOCK / 64][64 * 13];
     __shared__ double s_comb[RES_BLOCK / 64][SYS_N];
     if (st->done) return;
@@ -980,10 +987,26 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
         double u[12], rr = 0.0;
         bool used = false;
         if (my_kp < kp.n) {
+            int res_n;
+            bool fetch_rec;
+            Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
+            Sym3 res_SS{0, 0, 0, 0, 0, 0};
+            if (sums.v) {
+                // k_search_dense left the neighbour count and, for a keypoint the gates can keep, the finished sums (by position)
+                res_n = min((int) sums.cnt[my_pos], KMAX);
+                fetch_rec = (res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr;
+                if (fetch_rec) {
+                    const double *sv = sums.v + my_pos;
+                    const size_t ss = sums.stride;
+                    res_S = Vec3{sv[0], sv[ss], sv[2 * ss]};
+                    res_SS = Sym3{sv[3 * ss], sv[4 * ss], sv[5 * ss], sv[6 * ss], sv[7 * ss], sv[8 * ss]};
+                    res_q = Vec3{sv[9 * ss], sv[10 * ss], sv[11 * ss]};
+                }
+            } else {
             // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
             // record in nine independent 16-byte loads
             const int cnt_n = min((int) kp.cnt[my_kp], KMAX);
-            const bool fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
+            fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
             uint32_t rec32[SEL_STRIDE];
             rec32[0] = (uint32_t) cnt_n;
             if (fetch_rec) {
@@ -994,7 +1017,7 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                     rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
                 }
             }
-            const int res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
+            res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
             // a keypoint with fewer than min_number_neighbors (or 5) neighbours is dropped by the gates below whatever its
             // sums are (ct_icp.cpp:769, neighborhood.h:227): do not gather for it, unless debug capture wants its farthest
             // neighbour. On a street scan that is every second keypoint that has neighbours at all.
@@ -1002,8 +1025,6 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
             // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240).
             // Gathers in groups of eight (24 independent loads in flight), sums strictly in order.
-            Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
-            Sym3 res_SS{0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int g = 0; g < KMAX / GG; ++g) {
                 if (GG * g < gat_n) {
@@ -1026,6 +1047,7 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                         }
                     }
                 }
+            }
             }
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;

@@ -276,11 +276,17 @@ def config_b_full():
     dirs, rel_t = syn.lidar_pattern("hdl64")
     knots = syn.driving_trajectory(12, seed=0, start_x=20.0)
     gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75))
+    om = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
     for j in range(10):
         sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=100 + j)
-        gm.InsertPointCloud(sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)])
+        pts = sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)]
+        assert np.array_equal(gm.InsertPointCloud(pts), om.insert(pts))
     sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 10), 1.0, 1.1, noise=0.02, seed=110)
+    _B2_ORACLE_MAP["om"] = om
     return gm, sc
+
+
+_B2_ORACLE_MAP = {}
 
 
 def test_full_size_properties(config_b_full):
@@ -773,3 +779,204 @@ def test_config_a_reference_scene_gpu_vs_oracle(config_a_case):
     pose_ro, _, sro = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, oro, None, heap_mode=1)
     tr, rot = se3.pose_error(frame_r.pose14(), pose_ro)
     assert summ_r.success and sro.success and tr < 2e-3 and rot < 2e-4, (tr, rot)
+
+
+# ------------------------------------------------------------------------------------------------- BASELINE sizes vs the oracle
+@pytest.mark.parametrize("search_kernel", ["rows", "rows_ordered", "dense"])
+def test_full_size_b2_sweep_matches_oracle(config_b_full, search_kernel):
+    """BASELINE.json configs[1] at its full size (the workload bench.py times): every return of the 64-beam sweep (~132 k
+    keypoints) against the oracle running OpenMP over keypoints — one accumulation: neighbour counts, farthest neighbours and
+    gate decisions identical, packed system <= 1e-10 relative; five iterations: pose <= 1e-7 (stated bar 1e-4). For the row
+    kernel in caller order, in home-voxel order, and for the dense (home-voxel run) kernel."""
+    import os
+    gm, sc = config_b_full
+    om = _B2_ORACLE_MAP["om"]
+    n = len(sc.t)
+    assert n > 100_000
+    threads = max(1, min(16, os.cpu_count() or 1))
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=4)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t, sc.raw)
+    o1 = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_ordering(0 if search_kernel == "rows" else 1)
+    s.set_search_kernel(1 if search_kernel == "dense" else 0)
+    s.set_debug(True)
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o1)
+    dbg = s.get_debug()
+    A, b, n_used = s.get_system()
+    Ao, bo, no, info = orc.gn_accumulate(om, sc.raw, world0, sc.t, pose0, sc.t_begin_end, _oopts(o1), heap_mode=0, num_threads=threads, debug=True)
+    assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
+    has = info["n_neighbors"] >= 20
+    assert has.sum() > 50_000
+    assert np.array_equal(dbg["farthest"][has], info["farthest"][has])
+    assert np.array_equal(dbg["used"], info["used"]) and n_used == no == summ.num_residuals_used > 20_000
+    assert np.abs(dbg["a2d"][has] - info["a2d"][has]).max() < 1e-9
+    scale = np.abs(Ao).max()
+    assert np.abs(A - Ao).max() < 1e-10 * scale and np.abs(b - bo).max() < 1e-10 * np.abs(bo).max() + 1e-14
+    # five iterations without debug capture (the path bench.py times), with the motion prior
+    k = syn.driving_trajectory(12, seed=0, start_x=20.0)
+    mm = cia.PreviousFrameMotionModel()
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([k[9], k[10]]), 0.0, 0.0)
+    op = orc.MotionPrior(previous_begin_tr=k[9, 4:7], previous_end_tr=k[10, 4:7])
+    o5 = _opts(num_iters_icp=5, threshold_orientation_norm=0.0)
+    s.set_debug(False)
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pose5, summ5, _ = s.solve(pose0, sc.t_begin_end, o5, mm)
+    pose_o, world_o, so = orc.register_gn(om, sc.raw, world0, sc.t, pose0, sc.t_begin_end, _oopts(o5), op, heap_mode=0, num_threads=threads)
+    assert summ5.success and so.success and summ5.num_iters == so.num_iters == 5
+    assert summ5.num_residuals_used == so.num_residuals_used
+    tr, rot = se3.pose_error(pose5, pose_o)
+    assert tr < 1e-7 and rot < 1e-7, (tr, rot)
+    assert np.abs(s.world_points() - world_o).max() < 1e-7
+
+
+def test_dense_search_kernel_small_and_sparse_inputs(box_case, nclt_case):
+    """k_search_dense forced on inputs it is not meant for (few keypoints, one or two per home voxel; the 125-voxel sweep; fewer than k
+    neighbours; min_number_neighbors < k): same neighbour counts, farthest neighbours, gate decisions and poses as the oracle."""
+    for case, frames, voxel, kw in ((box_case, 5, 0.3, {}), (nclt_case, 8, 0.8, dict(min_number_neighbors=10))):
+        om, gm = build_maps(case, frames, with_gpu=True)
+        sc, raw, t, pose0, world0 = _keypoints(case, frames, voxel)
+        o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0, **kw)
+        s = cia.GnSolver(gm)
+        s.set_ordering(1)
+        s.set_search_kernel(1)
+        s.set_debug(True)
+        s.set_keypoints(raw, world0, t)
+        pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
+        dbg = s.get_debug()
+        A, b, n_used = s.get_system()
+        Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
+        assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
+        has = info["n_neighbors"] >= max(o.min_number_neighbors, 5)
+        assert has.sum() > 300
+        assert np.array_equal(dbg["farthest"][has], info["farthest"][has]) and np.array_equal(dbg["used"], info["used"])
+        assert n_used == no
+        assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max()
+        o = _opts(num_iters_icp=6, threshold_orientation_norm=1e-5, **kw)
+        s.set_debug(False)
+        s.set_keypoints(raw, world0, t)
+        pose6, summ6, _ = s.solve(pose0, sc.t_begin_end, o)
+        pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
+        assert summ6.num_iters == so.num_iters and summ6.num_residuals_used == so.num_residuals_used
+        tr, rot = se3.pose_error(pose6, pose_o)
+        assert tr < 1e-7 and rot < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_exact_distance_ties_on_a_lattice_map(mode):
+    """map.h:491-500 keeps candidates in a std::priority_queue keyed by distance only: which of two EQUAL distances survives is
+    decided by libstdc++'s heap. The GPU uses the total order (d2, visit index). On a lattice (dozens of candidates at exactly
+    equal distances) the kept SET can differ between the two where a tie straddles the k-th place, but the count, the farthest
+    kept DISTANCE and every strictly-closer neighbour cannot; the total-order restatement of the oracle (heap_mode 1) must match
+    bit for bit. The dense kernel meets its crowded-pivot-bin fallback here."""
+    g = np.arange(-8, 9) * 0.25
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
+    res = [(0.5, 0.01, 40)]
+    om = orc.Map(resolutions=res, default_radius=0.8)
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=0.8))
+    assert np.array_equal(om.insert(lattice), gm.InsertPointCloud(lattice))
+    rng = np.random.default_rng(6)
+    core = lattice[np.abs(lattice).max(axis=1) <= 1.0]
+    qs = np.concatenate([core[:150], core[:150] + 0.125, core[150:300] + [0.125, 0.0, 0.0], core[:100] + rng.normal(0, 1e-3, (100, 3))])
+    # batched RadiusSearch (lane kernel, total order)
+    for k in (20, 8):
+        got = gm.ComputeNeighborhoods(qs, k)
+        for q, gq in zip(qs, got):
+            want = om.radius_search(q, 0.0, k, heap_mode=1)
+            assert np.array_equal(gq, want)
+            ref_heap = om.radius_search(q, 0.0, k, heap_mode=0)
+            assert len(ref_heap) == len(want)
+            d_w, d_h = np.linalg.norm(want - q, axis=1), np.linalg.norm(ref_heap - q, axis=1)
+            assert np.array_equal(np.sort(d_w), np.sort(d_h))          # same multiset of distances either way
+    # the GN kernels on the same queries as keypoints (identity pose, raw = world)
+    n = len(qs)
+    pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], float)
+    tt = np.linspace(0.0, 1.0, n)
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_ordering(1 if mode == "dense" else 0)
+    s.set_search_kernel(1 if mode == "dense" else 0)
+    s.set_debug(True)
+    s.set_keypoints(qs, qs, tt)
+    s.solve(pose, (0.0, 1.0), o)
+    dbg = s.get_debug()
+    Ao, bo, no, info = orc.gn_accumulate(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o), heap_mode=1, debug=True)
+    assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"]) and (info["n_neighbors"] == 20).all()
+    assert np.array_equal(dbg["farthest"], info["farthest"])
+    assert np.array_equal(dbg["used"], info["used"])
+    A, b, n_used = s.get_system()
+    assert n_used == no and np.abs(A - Ao).max() <= 1e-10 * max(np.abs(Ao).max(), 1e-300)
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_km_scale_world_coordinates(street_case, mode):
+    """SURVEY section 7 'Precision': the same scene 5 km from the origin (absolute FP64 coordinates, as the reference stores them).
+    Discrete results stay identical to the oracle; the covariance C = SS / n - mu mu^T loses ~|p|^2 / sigma^2 * eps of relative
+    accuracy in ANY summation order (the reference's included), so a2D / normals / system are compared at the bar that conditioning
+    allows, the pose at 1e-6 (stated tolerance 1e-4)."""
+    shift = np.array([5000.0, -3000.0, 120.0])
+    case = street_case
+    res = case["resolutions"]
+    om = orc.Map(resolutions=res, default_radius=case["default_radius"])
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=case["default_radius"]))
+    for j in range(6):
+        pts = case["scans"][j].world_gt + shift
+        assert np.array_equal(om.insert(pts), gm.InsertPointCloud(pts))
+    sc, raw, t, pose0, _ = _keypoints(case, 6, 0.6)
+    pose0 = pose0.copy(); pose0[4:7] += shift; pose0[11:14] += shift
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_ordering(1 if mode == "dense" else 0)
+    s.set_search_kernel(1 if mode == "dense" else 0)
+    s.set_debug(True)
+    s.set_keypoints(raw, world0, t)
+    s.solve(pose0, sc.t_begin_end, o)
+    dbg = s.get_debug()
+    A, b, n_used = s.get_system()
+    Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
+    assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
+    has = info["n_neighbors"] >= 20
+    assert has.sum() > 500 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
+    assert (dbg["used"] != info["used"]).sum() <= 2 and abs(n_used - no) <= 2      # |d| < 0.3 gate on a value conditioned ~1e-7
+    assert np.abs(dbg["a2d"][has] - info["a2d"][has]).max() < 1e-4
+    assert np.abs(A - Ao).max() < 1e-4 * np.abs(Ao).max()
+    o = _opts(num_iters_icp=6, threshold_orientation_norm=0.0)
+    s.set_debug(False)
+    s.set_keypoints(raw, world0, t)
+    pose6, summ6, _ = s.solve(pose0, sc.t_begin_end, o)
+    pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
+    tr, rot = se3.pose_error(pose6, pose_o)
+    assert tr < 1e-6 and rot < 1e-6, (tr, rot)
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_k32_neighbours_and_64_point_voxels(box_case, mode):
+    """The kernels' limits: max_number_neighbors = 32 (CTGN_MAX_NEIGHBORS) and max_num_points = 64 per voxel."""
+    case = dict(box_case, resolutions=[(0.5, 0.02, 64)])
+    om, gm = build_maps(case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, 0.4)
+    for k, min_nb in ((32, 32), (32, 12), (7, 5)):
+        o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0, max_number_neighbors=k, min_number_neighbors=min_nb)
+        s = cia.GnSolver(gm)
+        s.set_ordering(1 if mode == "dense" else 0)
+        s.set_search_kernel(1 if mode == "dense" else 0)
+        s.set_debug(True)
+        s.set_keypoints(raw, world0, t)
+        pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
+        dbg = s.get_debug()
+        A, b, n_used = s.get_system()
+        Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
+        assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"]) and info["n_neighbors"].max() == k
+        has = info["n_neighbors"] >= max(min_nb, 5)
+        assert has.sum() > 1000 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
+        assert np.array_equal(dbg["used"], info["used"]) and n_used == no
+        assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max()
+        pose_o, _, _ = orc.gn_solve_update(Ao, bo, no, None, pose0)
+        tr, rot = se3.pose_error(pose1, pose_o)
+        assert tr < TIGHT and rot < TIGHT
+    got = gm.ComputeNeighborhoods(world0[:300], 32)
+    for q, gq in zip(world0[:300], got):
+        assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=1))
