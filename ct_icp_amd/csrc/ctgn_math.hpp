@@ -230,6 +230,109 @@ __device__ __forceinline__ void sym3_normal_a2d(Sym3 c, Vec3 &normal, double &a2
     a2d = (sqrt(smid) - sqrt(smin)) / sqrt(smax);
 }
 
+// Eigen::JacobiSVD<Matrix3d>(C, ComputeFullV) of the reference's ComputeNeighborhoodInfo (include/SlamCore/experimental/
+// neighborhood.h:293) restated operation for operation (Eigen/src/SVD/JacobiSVD.h two-sided Jacobi over (p, q) = (1,0), (2,0), (2,1)
+// with real_2x2_jacobi_svd and JacobiRotation::makeJacobi from Eigen/src/Jacobi/Jacobi.h; threshold 2 eps max|diag|; singular
+// values = |diag| * scale, sorted decreasing together with the columns of V), with correctly rounded division and square root and
+// no fused multiply-add — i.e. the arithmetic of a stock x86-64 build. The fast cyclic Jacobi above agrees with it to rounding
+// wherever the normal is defined; on a rank-deficient covariance (collinear neighbours) the third singular vector is decided by
+// the roundings themselves, and the robust route gives such neighbourhoods a non-zero weight (ct_icp.cpp:574-579), so that route
+// uses this one. C row-major full symmetric matrix; sv descending; V row-major.
+CTGN_HD void jacobi_svd3_exact(const double Cin[9], double sv[3], double V[9]) {
+#pragma clang fp contract(off)
+    double W[3][3], Vm[3][3];
+    double scale = 0.0;
+    for (int i = 0; i < 9; ++i) if (fabs(Cin[i]) > scale) scale = fabs(Cin[i]);
+    if (scale == 0.0) scale = 1.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { W[i][j] = Cin[3 * i + j] / scale; Vm[i][j] = (i == j) ? 1.0 : 0.0; }
+    const double precision = 2.0 * DBL_EPSILON, tiny = DBL_MIN;
+    double max_diag = 0.0;
+    for (int i = 0; i < 3; ++i) if (fabs(W[i][i]) > max_diag) max_diag = fabs(W[i][i]);
+    bool finished = false;
+    while (!finished) {
+        finished = true;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 0 ? 1 : 2, q = pq == 2 ? 1 : 0;
+            double thr = precision * max_diag;
+            if (thr < tiny) thr = tiny;
+            if (!(fabs(W[p][q]) > thr || fabs(W[q][p]) > thr)) continue;
+            finished = false;
+            const double m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+            double r1c, r1s;
+            const double t = m00 + m11, d = m10 - m01;
+            if (fabs(d) < tiny) { r1s = 0.0; r1c = 1.0; }
+            else { const double u = t / d; const double tmp = sqrt(1.0 + u * u); r1s = 1.0 / tmp; r1c = u / tmp; }
+            const double n00 = r1c * m00 + r1s * m10, n01 = r1c * m01 + r1s * m11, n11 = -r1s * m01 + r1c * m11;
+            double jc, js;
+            const double deno = 2.0 * fabs(n01);
+            if (deno < tiny) { jc = 1.0; js = 0.0; }
+            else {
+                const double tau = (n00 - n11) / deno, w = sqrt(tau * tau + 1.0);
+                const double t2 = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+                const double sign_t = t2 > 0.0 ? 1.0 : -1.0;
+                const double n = 1.0 / sqrt(t2 * t2 + 1.0);
+                js = -sign_t * (n01 / fabs(n01)) * fabs(t2) * n;
+                jc = n;
+            }
+            const double lc = r1c * jc - r1s * (-js), ls = r1c * (-js) + r1s * jc;
+            if (!(lc == 1.0 && ls == 0.0)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double xi = W[p][k], yi = W[q][k];
+                    W[p][k] = lc * xi + ls * yi;
+                    W[q][k] = -ls * xi + lc * yi;
+                }
+            }
+            const double tc = jc, ts = -js;
+            if (!(tc == 1.0 && ts == 0.0)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double xi = W[k][p], yi = W[k][q];
+                    W[k][p] = tc * xi + ts * yi;
+                    W[k][q] = -ts * xi + tc * yi;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double xi = Vm[k][p], yi = Vm[k][q];
+                    Vm[k][p] = tc * xi + ts * yi;
+                    Vm[k][q] = -ts * xi + tc * yi;
+                }
+            }
+            const double md = fabs(W[p][p]) > fabs(W[q][q]) ? fabs(W[p][p]) : fabs(W[q][q]);
+            if (md > max_diag) max_diag = md;
+        }
+    }
+    for (int i = 0; i < 3; ++i) sv[i] = fabs(W[i][i]) * scale;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int pos = 0;
+        double mx = sv[i];
+        for (int k = i + 1; k < 3; ++k) if (sv[k] > mx) { mx = sv[k]; pos = k - i; }
+        if (mx == 0.0) break;
+        if (pos) {
+            pos += i;
+            const double ts = sv[i]; sv[i] = sv[pos]; sv[pos] = ts;
+            for (int k = 0; k < 3; ++k) { const double tv = Vm[k][pos]; Vm[k][pos] = Vm[k][i]; Vm[k][i] = tv; }
+        }
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[3 * i + j] = Vm[i][j];
+}
+
+// mean / covariance / JacobiSVD of ComputeNeighborhood (neighborhood.h:236-244,293-311) from the running sums, in the reference
+// build's arithmetic (no fused multiply-add): normal = V[:, 2], a2D = (sqrt s1 - sqrt s2) / sqrt s0
+CTGN_HD void normal_a2d_exact(int n, Vec3 S, const double SS9[9], Vec3 &normal, double &a2d) {
+#pragma clang fp contract(off)
+    const double dn = (double) n;
+    const double b[3] = {S.x / dn, S.y / dn, S.z / dn};
+    double C[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { const double m = SS9[3 * r + c] / dn; C[3 * r + c] = m - b[r] * b[c]; }
+    double sv[3], V[9];
+    jacobi_svd3_exact(C, sv, V);
+    normal = Vec3{V[2], V[5], V[8]};
+    a2d = (sqrt(fabs(sv[1])) - sqrt(fabs(sv[2]))) / sqrt(fabs(sv[0]));
+}
+
 // Diagonally pivoted LDL^T solve of a symmetric 12x12 system (Eigen LDLT::compute + solve, ct_icp.cpp:914).
 // m is the full matrix, row-major, destroyed.
 CTGN_HD void ldlt_solve12(double *m, const double *b, double *x) {

@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
         const int n_all = min((int) rec32[0], KMAX);
         const int n = (n_all >= prm.min_nb && n_all >= 5) ? n_all : 0;          // invalid below (:566-567): nothing to gather, and the search kernel hands over no offsets
         Vec3 S{0, 0, 0}, q0{0, 0, 0};
-        Sym3 SS{0, 0, 0, 0, 0, 0};
-        // farthest-first, summed front to back like the GN route (neighborhood.h:236-240)
+        double SS9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // farthest-first, summed front to back (neighborhood.h:236-240), WITHOUT fused multiply-adds: this route weighs
+        // rank-deficient neighbourhoods too (:574-579), whose "normal" is decided by the roundings (jacobi_svd3_exact)
 #pragma unroll
         for (int g = 0; g < KMAX / 8; ++g) {
             if (8 * g < n) {
@@ -211,9 +212,11 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (8 * g + q < n) {
+#pragma clang fp contract(off)
                         const double x = gx[q], y = gy[q], z = gz[q];
                         S.x += x; S.y += y; S.z += z;
-                        SS.xx += x * x; SS.xy += x * y; SS.xz += x * z; SS.yy += y * y; SS.yz += y * z; SS.zz += z * z;
+                        const double xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+                        SS9[0] += xx; SS9[1] += xy; SS9[2] += xz; SS9[3] += xy; SS9[4] += yy; SS9[5] += yz; SS9[6] += xz; SS9[7] += yz; SS9[8] += zz;
                         if (8 * g + q < prm.num_closest) {                    // neighborhood.points[i], :585-595
                             const size_t at = (size_t) (8 * g + q) * rb.cap + k;
                             rb.ref[at] = x;
@@ -228,13 +231,8 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
         Vec3 nrm{0, 0, 0};
         double weight = 0.0;
         if (valid) {
-            const double dn = (double) n;
-            const Vec3 mu{S.x / dn, S.y / dn, S.z / dn};
-            Sym3 C;
-            C.xx = SS.xx / dn - mu.x * mu.x; C.xy = SS.xy / dn - mu.x * mu.y; C.xz = SS.xz / dn - mu.x * mu.z;
-            C.yy = SS.yy / dn - mu.y * mu.y; C.yz = SS.yz / dn - mu.y * mu.z; C.zz = SS.zz / dn - mu.z * mu.z;
             double a2d;
-            sym3_normal_a2d(C, nrm, a2d);       // :570-573 never flips: normal . (BeginTr - BeginTr) = 0
+            normal_a2d_exact(n, S, SS9, nrm, a2d);      // :570-573 never flips: normal . (BeginTr - BeginTr) = 0
             const Vec3 p{kp.wx[k], kp.wy[k], kp.wz[k]};
             const Vec3 d = q0 - p;
             weight = prm.lambda_w * pow(a2d, prm.power) + prm.lambda_n * exp(-sqrt(dot(d, d)) / prm.nbr_scale);   // :574-579

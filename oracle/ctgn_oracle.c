@@ -506,6 +506,90 @@ void orc_sym_eigen3(const double C[9], double evals[3], double V[9]) {
     }
 }
 
+/* Eigen::JacobiSVD<Matrix3d>(C, ComputeFullV) restated operation for operation (Eigen/src/SVD/JacobiSVD.h: two-sided Jacobi, sweeps
+ * over (p, q) = (1,0), (2,0), (2,1), threshold 2 eps * max|diag|, real_2x2_jacobi_svd + JacobiRotation::makeJacobi from
+ * Eigen/src/Jacobi/Jacobi.h, singular values |diag| * scale sorted in decreasing order with the columns of V). The same statement
+ * as oracle/shims/mini_eigen.h (which oracle/_ref runs under the reference's own ComputeNeighborhoodInfo, neighborhood.h:285-316)
+ * and as jacobi_svd3_exact of the product: on a rank-deficient covariance (collinear neighbours: a pole) the "normal" is decided by
+ * these very roundings, so the three agree bit for bit only if they perform the same operations. sv descending, V row-major. */
+void orc_jacobi_svd3(const double Cin[9], double sv[3], double V[9]) {
+    double W[3][3], Vm[3][3];
+    double scale = 0.0;
+    for (int i = 0; i < 9; ++i) if (fabs(Cin[i]) > scale) scale = fabs(Cin[i]);
+    if (scale == 0.0) scale = 1.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { W[i][j] = Cin[3 * i + j] / scale; Vm[i][j] = (i == j) ? 1.0 : 0.0; }
+    const double precision = 2.0 * DBL_EPSILON, tiny = DBL_MIN;
+    double max_diag = 0.0;
+    for (int i = 0; i < 3; ++i) if (fabs(W[i][i]) > max_diag) max_diag = fabs(W[i][i]);
+    int finished = 0;
+    while (!finished) {
+        finished = 1;
+        for (int p = 1; p < 3; ++p)
+            for (int q = 0; q < p; ++q) {
+                double thr = precision * max_diag;
+                if (thr < tiny) thr = tiny;
+                if (!(fabs(W[p][q]) > thr || fabs(W[q][p]) > thr)) continue;
+                finished = 0;
+                /* real_2x2_jacobi_svd */
+                const double m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+                double r1c, r1s;
+                const double t = m00 + m11, d = m10 - m01;
+                if (fabs(d) < tiny) { r1s = 0.0; r1c = 1.0; }
+                else { const double u = t / d; const double tmp = sqrt(1.0 + u * u); r1s = 1.0 / tmp; r1c = u / tmp; }
+                const double n00 = r1c * m00 + r1s * m10, n01 = r1c * m01 + r1s * m11, n11 = -r1s * m01 + r1c * m11;
+                /* JacobiRotation::makeJacobi(n00, n01, n11) */
+                double jc, js;
+                const double deno = 2.0 * fabs(n01);
+                if (deno < tiny) { jc = 1.0; js = 0.0; }
+                else {
+                    const double tau = (n00 - n11) / deno, w = sqrt(tau * tau + 1.0);
+                    const double t2 = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+                    const double sign_t = t2 > 0.0 ? 1.0 : -1.0;
+                    const double n = 1.0 / sqrt(t2 * t2 + 1.0);
+                    js = -sign_t * (n01 / fabs(n01)) * fabs(t2) * n;
+                    jc = n;
+                }
+                /* j_left = rot1 * j_right^T */
+                const double lc = r1c * jc - r1s * (-js), ls = r1c * (-js) + r1s * jc;
+                if (!(lc == 1.0 && ls == 0.0))
+                    for (int k = 0; k < 3; ++k) {
+                        const double xi = W[p][k], yi = W[q][k];
+                        W[p][k] = lc * xi + ls * yi;
+                        W[q][k] = -ls * xi + lc * yi;
+                    }
+                /* applyOnTheRight(p, q, j_right): columns rotated by j_right^T = (jc, -js) */
+                const double tc = jc, ts = -js;
+                if (!(tc == 1.0 && ts == 0.0)) {
+                    for (int k = 0; k < 3; ++k) {
+                        const double xi = W[k][p], yi = W[k][q];
+                        W[k][p] = tc * xi + ts * yi;
+                        W[k][q] = -ts * xi + tc * yi;
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        const double xi = Vm[k][p], yi = Vm[k][q];
+                        Vm[k][p] = tc * xi + ts * yi;
+                        Vm[k][q] = -ts * xi + tc * yi;
+                    }
+                }
+                double md = fabs(W[p][p]) > fabs(W[q][q]) ? fabs(W[p][p]) : fabs(W[q][q]);
+                if (md > max_diag) max_diag = md;
+            }
+    }
+    for (int i = 0; i < 3; ++i) sv[i] = fabs(W[i][i]) * scale;
+    for (int i = 0; i < 3; ++i) {
+        int pos = 0;
+        double mx = sv[i];
+        for (int k = i + 1; k < 3; ++k) if (sv[k] > mx) { mx = sv[k]; pos = k - i; }
+        if (mx == 0.0) break;
+        if (pos) {
+            pos += i;
+            double ts = sv[i]; sv[i] = sv[pos]; sv[pos] = ts;
+            for (int k = 0; k < 3; ++k) { double tv = Vm[k][pos]; Vm[k][pos] = Vm[k][i]; Vm[k][i] = tv; }
+        }
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[3 * i + j] = Vm[i][j];
+}
+
 /* TNeighborhood::ComputeNeighborhood(A2D | NORMAL) — include/SlamCore/experimental/neighborhood.h:225-257
  * then ComputeNeighborhoodInfo :285-316. */
 int orc_neighborhood(const double *pts, int n, double normal[3], double *a2d) {
@@ -523,7 +607,7 @@ int orc_neighborhood(const double *pts, int n, double normal[3], double *a2d) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) cov[3 * r + c] -= bary[r] * bary[c];   /* :243 */
     double ev[3], V[9];
-    orc_sym_eigen3(cov, ev, V);                              /* :293 */
+    orc_jacobi_svd3(cov, ev, V);                             /* :293 Eigen::JacobiSVD<Mat3>(covariance, ComputeFullV) */
     normal[0] = V[2]; normal[1] = V[5]; normal[2] = V[8];    /* V.block<3,1>(0,2) :300-303 */
     double s0 = fabs(ev[0]), s1 = fabs(ev[1]), s2 = fabs(ev[2]);   /* singularValues().cwiseAbs() :304 */
     *a2d = (sqrt(s1) - sqrt(s2)) / sqrt(s0);                 /* :309-311 */

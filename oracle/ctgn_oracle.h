@@ -103,6 +103,7 @@ void orc_transform_points(const double pose[14], const double t_begin_end[2], co
 /* TNeighborhood::ComputeNeighborhood(A2D|NORMAL) (neighborhood.h:225-257,285-316). Returns 0 if <5 pts. */
 int orc_neighborhood(const double *pts_xyz, int n, double normal[3], double *a2d);
 /* symmetric 3x3 eigen-decomposition, eigenvalues descending, V columns = eigenvectors (row-major 3x3) */
+void orc_jacobi_svd3(const double C[9], double sv[3], double V[9]);
 void orc_sym_eigen3(const double C[9], double evals[3], double V[9]);
 /* pivoted LDL^T solve of a 12x12 symmetric system (Eigen A.ldlt().solve(b), ct_icp.cpp:914) */
 void orc_ldlt_solve12(const double A[144], const double b[12], double x[12]);
