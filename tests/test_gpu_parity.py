@@ -982,3 +982,46 @@ def test_k32_neighbours_and_64_point_voxels(box_case, mode):
     got = gm.ComputeNeighborhoods(world0[:300], 32)
     for q, gq in zip(world0[:300], got):
         assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=1))
+
+
+def test_config_d_dense_scan_one_iteration_matches_oracle():
+    """BASELINE.json configs[3] (dense scan, sharded across GPUs in production; here the single-GPU kernel instantiation it uses):
+    the 125-voxel sweep (0.5 m x 40-point map, radius 0.8) on >= 1 M keypoints, one accumulation against the oracle running OpenMP
+    over keypoints — neighbour counts, farthest neighbours and gate decisions identical, packed system <= 1e-10 relative, pose of
+    the following solve <= 1e-8. Same generator as `bench.py --workload D`, on a 600 m stretch (4.4 M map points) so that the CPU
+    side finishes in about a minute."""
+    import os
+    import bench
+    inp = bench.make_inputs_dense(0, length=600.0)
+    res = [(0.5, 0.03, 40)]
+    om = orc.Map(resolutions=res, default_radius=0.8)
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*res[0])], default_radius=0.8))
+    pts = inp["map_points"]
+    for s0 in range(0, len(pts), 2_000_000):
+        kept = gm.InsertPointCloud(pts[s0:s0 + 2_000_000])
+        assert np.array_equal(kept, om.insert(pts[s0:s0 + 2_000_000]))
+    assert gm.SearchParamsFromRadiusSearch() == (0, 0.5, 2)
+    raw, t = inp["raw"], inp["t"]
+    n = len(t)
+    assert n >= 1_000_000
+    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.02, seed=5)
+    world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, inp["tbe"], _oopts(o), heap_mode=0, num_threads=threads, debug=True)
+    pose_o, _, _ = orc.gn_solve_update(Ao, bo, no, None, pose0)
+    for ordering in (0, 1):                                        # caller order; home-voxel order (what the library picks for this size)
+        s = cia.GnSolver(gm)
+        s.set_ordering(ordering)
+        s.set_debug(True)
+        s.set_keypoints(raw, world0, t)
+        pose1, summ, _ = s.solve(pose0, inp["tbe"], o)
+        dbg = s.get_debug()
+        A, b, n_used = s.get_system()
+        assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
+        has = info["n_neighbors"] >= 20
+        assert has.sum() > 700_000 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
+        assert np.array_equal(dbg["used"], info["used"]) and n_used == no == summ.num_residuals_used
+        assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max() and np.abs(b - bo).max() < 1e-10 * np.abs(bo).max() + 1e-14
+        tr, rot = se3.pose_error(pose1, pose_o)
+        assert tr < TIGHT and rot < TIGHT, (tr, rot)
