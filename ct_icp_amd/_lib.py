@@ -109,6 +109,10 @@ SYMBOLS = {
     "ctgn_map_radius_search": (C.c_int, [_H, _dp, C.c_size_t, C.c_double, C.c_int32, _dp, C.POINTER(C.c_int32)]),
     "ctgn_set_keypoints": (C.c_int, [_H, View, View, View, C.c_size_t]),
     "ctgn_solve": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_solve_sharded": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_dist_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "ctgn_dist_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "ctgn_dist_shutdown": (C.c_int, [_H]),
     "ctgn_get_world_points": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
     "ctgn_grid_sampling": (C.c_int, [_H, View, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_adaptive_sampling_options_default": (None, [C.POINTER(AdaptiveSamplingOptions)]),
@@ -142,6 +146,7 @@ SYMBOLS = {
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_search_kernel": (C.c_int, [_H, C.c_int32]),
+    "ctgn_traffic_counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_phase_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
 }

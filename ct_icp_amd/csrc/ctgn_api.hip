@@ -4,6 +4,8 @@
 #include "../../include/ctgn.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is bound at run time (dlopen), see rccl_api()
 
 #include <algorithm>
 #include <chrono>
@@ -124,6 +126,10 @@ struct ctgn_context {
     RobustParams rprm{};
     ctgn_robust_options r_opts{};
 
+    // keypoint-sharded mode (ctgn_dist_init): this rank's RCCL communicator
+    ncclComm_t comm = nullptr;
+    int dist_rank = 0, dist_world = 1;
+
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
@@ -132,6 +138,34 @@ struct ctgn_context {
 };
 
 namespace {
+
+// RCCL entry points, bound on first use with dlopen("librccl.so.1"): a process that already holds RCCL (torch.distributed's
+// "nccl" backend ships a librccl with the same SONAME) shares that instance, a plain C++ host gets the ROCm one; and libctgn.so
+// keeps loading on a box without RCCL as long as nobody asks for the sharded mode.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi &rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
 
 const char *status_str(ctgn_status s) {
     switch (s) {
@@ -544,6 +578,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         } else {
             const size_t sm = rows_kernel_smem<2>();
             if (h->variant == 2) launch(k_accumulate_rows<2, false, false, 3>, sm, nullptr);
+            else if (h->variant == 3) launch(k_accumulate_rows<2, true, true, 3>, sm, h->d_prof);
             else launch(k_accumulate_rows<2, true, false, 3>, sm, nullptr);
         }
     }
@@ -683,6 +718,7 @@ void ctgn_destroy(ctgn_handle h) {
     if (h->device >= 0) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
+        if (h->comm && rccl_api().ok) { rccl_api().CommDestroy(h->comm); h->comm = nullptr; }
         for (auto &d : h->dlevels) { if (d.slots) hipFree(d.slots); if (d.blocks) hipFree(d.blocks); }
         for (auto &d : h->devlevels) devmap_level_free(d);
         devmap_scratch_free(h->dm);
@@ -1159,6 +1195,69 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
     return ctgn_gn_end(h, pose_io, summary);
 }
 
+/* -------------------------------------------------------------------------------------------------
+ * Keypoint-sharded mode: the collective is issued from here, on the handle's stream
+ * ---------------------------------------------------------------------------------------------- */
+ctgn_status ctgn_dist_unique_id(uint8_t out[CTGN_DIST_ID_BYTES]) {
+    static_assert(CTGN_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ctgn.h mirrors ncclUniqueId");
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!rccl_api().ok) return CTGN_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (rccl_api().GetUniqueId(&id) != ncclSuccess) return CTGN_ERR_HIP;
+    std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_dist_init(ctgn_handle h, int32_t rank, int32_t world_size, const uint8_t id_bytes[CTGN_DIST_ID_BYTES]) {
+    NEED_DEVICE(h);
+    if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "bad rank / world size / id");
+    if (!rccl_api().ok) return fail(h, CTGN_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    if (h->comm) { rccl_api().CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+    const ncclResult_t r = rccl_api().CommInitRank(&h->comm, world_size, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclCommInitRank: ") + rccl_api().GetErrorString(r)); }
+    h->dist_rank = rank;
+    h->dist_world = world_size;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_dist_shutdown(ctgn_handle h) {
+    NEED_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->comm && rccl_api().ok) rccl_api().CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->dist_rank = 0; h->dist_world = 1;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                               const ctgn_motion_prior *prior, ctgn_summary *summary) {
+    NEED_DEVICE(h);
+    if (!h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
+    ctgn_status st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
+    MapView mv;
+    if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
+    for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {
+        st = launch_accumulate(h, mv, it == 0);                    // this rank's shard -> per-block partials
+        if (st != CTGN_OK) break;
+        h->launched_iters++;
+        st = launch_reduce_solve(h, 1);                             // -> packed system (96 doubles) in d_sys
+        if (st != CTGN_OK) break;
+        // the one exchange of the path: 78 J^T J | 12 J^T r | count | pad, summed over the ranks, in place, on this stream
+        const ncclResult_t r = rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) { st = fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclAllReduce: ") + rccl_api().GetErrorString(r)); break; }
+        st = launch_reduce_solve(h, 2);                             // identical input on every rank -> identical pose, no broadcast
+    }
+    if (st != CTGN_OK) {
+        h->gn_active = false;
+        hipStreamSynchronize(h->stream);
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", ctgn_last_error(h)); }
+        return st;
+    }
+    return ctgn_gn_end(h, pose_io, summary);
+}
+
 ctgn_status ctgn_grid_sampling(ctgn_handle h, ctgn_view xyz, size_t n, double voxel_size, uint32_t *out_indices, size_t *out_count) {
     NEED_DEVICE(h);
     if (!out_count || !(voxel_size > 0) || (n && (!xyz.base || !out_indices))) return CTGN_ERR_INVALID_ARGUMENT;
@@ -1617,6 +1716,15 @@ ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->d_prof, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));      // [12] (dense: runs) stays on the device
     if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 12 * sizeof(unsigned long long)));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_traffic_counters(ctgn_handle h, uint64_t out[2], int32_t reset) {
+    NEED_DEVICE(h);
+    if (!out) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d_prof + 12, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d_prof + 12, 0, 2 * sizeof(unsigned long long)));
     return CTGN_OK;
 }
 

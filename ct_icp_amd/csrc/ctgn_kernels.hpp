@@ -617,7 +617,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     const uint32_t blk8 = (uint32_t) blk * 8u, stride3 = 3u * blk8;
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;      // uniform bases: scalar-base + 32-bit lane offset loads
 
-    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds, 10: hash probes issued, 11: map points streamed
     unsigned long long tprev = 0;
     if (PROF) tprev = __builtin_readcyclecounter();
     const unsigned long long t_wave_start = tprev;
@@ -709,6 +709,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     // probe the 27 sweep voxels once for the wave (lane v < 27 takes sweep voxel v)
                     if (snxt_round != r)
                         snxt = probe_issue(map, lane < 27 && !(ablate & 16), kx + lane / 9 - 1, ky + (lane / 3) % 3 - 1, kz + lane % 3 - 1);
+                    if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(snxt.active));
                     const uint32_t bc = probe_resolve(map, snxt);
                     const int cnt = (int) (bc & 127u);
                     const int inc = row_scan_i32(cnt);                       // inclusive prefix within each DPP row
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     o.z = *reinterpret_cast<const double *>(pbase_z + off);
                 };
                 auto test = [&](const Cand &cnd) {
+                    if (PROF) pc[11] += (unsigned long long) __popcll(__ballot(cnd.valid));
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
                     const double d2 = sq_norm3(dx, dy, dz);
                     // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate);
                     nxt_round = r + 1;
                 }
+                if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(cur.active));
                 const uint32_t bc = probe_resolve(map, cur);
                 if (bc) RP.occ[cur_v] = bc;
                 // Once the row holds k candidates and knows its k-th best distance, a voxel that lies entirely farther away cannot
@@ -853,6 +856,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     o.vis = (ch.y >> 8) + (uint32_t) sub;
                 };
                 auto test = [&](const Cand &cnd) {
+                    if (PROF) pc[11] += (unsigned long long) __popcll(__ballot(cnd.valid));
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
                     const double d2 = sq_norm3(dx, dy, dz);
                     const bool pass = cnd.valid && d2 <= kth_d2;
@@ -934,6 +938,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
         atomicMax(&prof[10], tot_);            // slowest wave
         atomicAdd(&prof[11], 1ull);            // waves
+        atomicAdd(&prof[12], pc[10]);          // hash probes issued (voxels not culled; the shared-home path probes once per wave)
+        atomicAdd(&prof[13], pc[11]);          // map points streamed (16-point chunk slots that held a point)
         // per-wave timeline of the LAST launch: start and end clock, fast-path rounds, rounds (prof + 16, 4 per wave)
         unsigned long long *wrec = prof + 16 + 4 * (size_t) (blockIdx.x * ROW_WAVES + wave);
         wrec[0] = t_wave_start; wrec[1] = __builtin_readcyclecounter(); wrec[2] = pc[8]; wrec[3] = pc[9];

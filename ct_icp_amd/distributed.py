@@ -20,6 +20,14 @@ def shard_bounds(n: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def home_voxel_order(world_points: np.ndarray, resolution: float) -> np.ndarray:
+    """Permutation that sorts keypoints by the home voxel of their world point (x, then y, then z voxel index; stable). Sharding the
+    SORTED sequence into contiguous chunks (shard_bounds) gives every GPU a compact region of the replicated map to touch
+    ("keypoints split into G contiguous chunks after the voxel-key sort")."""
+    v = np.trunc(np.asarray(world_points, dtype=np.float64) / resolution).astype(np.int64)
+    return np.lexsort((v[:, 2], v[:, 1], v[:, 0]))
+
+
 def pack_system(A: np.ndarray, b: np.ndarray, n_used: int) -> np.ndarray:
     """Host packing of (A, b, count) in the device layout — used by the CPU (gloo) tests of the exchange."""
     s = np.zeros(SYSTEM_DOUBLES)
@@ -45,23 +53,39 @@ def allreduce_system(system_tensor, group=None):
 
 
 class ShardedGnSolver:
-    """Runs the stepwise C-ABI loop (ctgn_gn_begin / accumulate / solve_update / end) with the all-reduce in between.
-    The library's kernels are enqueued on torch's current stream so that NCCL's stream dependencies order them."""
+    """The keypoint-sharded GN loop of one rank. Default: the whole loop runs inside libctgn (ctgn_solve_sharded) with ONE
+    ncclAllReduce of the packed system per iteration issued from C on the handle's stream — no Python between the launches;
+    torch.distributed is only used to hand rank 0's RCCL unique id to the other ranks. `library_collective=False` keeps the
+    earlier variant (stepwise C-ABI calls with torch.distributed.all_reduce in between) for comparison."""
 
-    def __init__(self, voxel_map, group=None):
+    def __init__(self, voxel_map, group=None, library_collective: bool = True):
         import torch
+        import torch.distributed as dist
         from .registration import GnSolver
         self.torch = torch
         self.group = group
+        self.library_collective = library_collective
         self.solver = GnSolver(voxel_map)
-        self.system = torch.zeros(SYSTEM_DOUBLES, dtype=torch.float64, device="cuda")
-        self.solver.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.solver.gn_set_system_buffer(self.system.data_ptr())
+        self.system = None
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if library_collective:
+            box = [GnSolver.dist_unique_id() if rank == 0 else None]
+            if dist.is_initialized() and world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            self.solver.dist_init(rank, world, box[0])
+        else:
+            self.system = torch.zeros(SYSTEM_DOUBLES, dtype=torch.float64, device="cuda")
+            self.solver.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.solver.gn_set_system_buffer(self.system.data_ptr())
 
     def close(self):
-        """Give the library its own packed-system buffer back (the tensor may be freed afterwards)."""
+        """Release the communicator / give the library its own packed-system buffer back (the tensor may be freed afterwards)."""
         if self.solver is not None:
-            self.solver.gn_set_system_buffer(None)
+            if self.library_collective:
+                self.solver.dist_shutdown()
+            else:
+                self.solver.gn_set_system_buffer(None)
             self.solver = None
 
     def __del__(self):
@@ -75,6 +99,8 @@ class ShardedGnSolver:
 
     def solve(self, pose14, t_begin_end, options, motion_model=None):
         s = self.solver
+        if self.library_collective:
+            return s.solve_sharded(pose14, t_begin_end, options, motion_model)
         s.gn_begin(pose14, t_begin_end, options, motion_model)
         for _ in range(options.num_iters_icp):
             s.gn_accumulate()                      # local shard -> packed system in self.system

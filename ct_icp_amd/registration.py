@@ -228,6 +228,33 @@ class GnSolver:
         L.check(self._h, st)
         return pose, _summary(s), s
 
+    # ---- keypoint-sharded mode: the collective is issued by the library (ctgn_solve_sharded), RCCL bound at run time
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        out = (C.c_uint8 * 128)()
+        st = L.lib().ctgn_dist_unique_id(out)
+        if st != 0:
+            raise L.CtgnError(st, "ctgn_dist_unique_id failed (is librccl.so.1 loadable?)")
+        return bytes(out)
+
+    def dist_init(self, rank: int, world_size: int, unique_id: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        L.check(self._h, L.lib().ctgn_dist_init(self._h, int(rank), int(world_size), buf))
+
+    def dist_shutdown(self):
+        L.check(self._h, L.lib().ctgn_dist_shutdown(self._h))
+
+    def solve_sharded(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
+        """The sharded GN loop on this rank's resident keypoints; one ncclAllReduce of the packed system per iteration, issued in C."""
+        pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        opts, prior, s = _c_options(options), _c_prior(motion_model), L.Summary()
+        dp = C.POINTER(C.c_double)
+        st = L.lib().ctgn_solve_sharded(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
+                                        C.byref(prior) if prior is not None else None, C.byref(s))
+        L.check(self._h, st)
+        return pose, _summary(s), s
+
     def solve_robust(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
         """DoRegisterCeres on the resident keypoints (their world coordinates are ignored and rewritten)."""
         pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
@@ -342,6 +369,12 @@ class GnSolver:
         out = (C.c_uint64 * 12)()
         L.check(self._h, L.lib().ctgn_phase_cycles(self._h, out, int(reset)))
         return [int(x) for x in out]
+
+    def traffic_counters(self, reset=False):
+        """(hash probes issued, map points streamed) by the instrumented row kernel (variant 3) since the last reset."""
+        out = (C.c_uint64 * 2)()
+        L.check(self._h, L.lib().ctgn_traffic_counters(self._h, out, int(reset)))
+        return int(out[0]), int(out[1])
 
     def wave_timeline(self, max_waves: int = 8192) -> np.ndarray:
         """(waves, 4) uint64: start clock, end clock, fast-path rounds, rounds of the last variant-3 launch."""

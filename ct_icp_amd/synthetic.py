@@ -141,6 +141,90 @@ def street_scene(length: float = 400.0, seed: int = 1, half_width=(10.0, 12.0), 
                  np.zeros((0, 4)))
 
 
+
+def suburb_scene(seed: int = 7, x_range=(-140.0, 190.0), half_extent: float = 125.0, n_buildings: int = 150, n_trees: int = 1700) -> Scene:
+    """An open residential block around a road along +x: ground, scattered box buildings, box cars, poles and many trees (sphere crown on
+    a cylinder trunk). Unlike the street canyon of config B's small workload, a 64-beam sweep sees structure in every direction out to
+    its 100 m range, and the volumetric clutter fills voxels in 3-D — the regime in which a steady-state driving-profile map (0.8 m
+    voxels, 100 m eviction radius) reaches the ~3 x 10^5 voxels DESIGN.md section 2 estimates for a KITTI scene."""
+    rng = np.random.default_rng(seed)
+    planes = [[0, 0, 1, 0.0]]
+    bounds = [_inf_bounds()]
+    boxes, cyl, sph = [], [], []
+    x0, x1 = x_range
+    for _ in range(n_buildings):
+        w, d, h = rng.uniform(8, 22), rng.uniform(8, 18), rng.uniform(4, 14)
+        cx = rng.uniform(x0, x1)
+        cy = rng.choice([-1, 1]) * rng.uniform(9.0 + d / 2, half_extent)
+        boxes.append([cx - w / 2, cy - d / 2, 0.0, cx + w / 2, cy + d / 2, h])
+    x = x0
+    while x < x1:                   # parked cars
+        side = 1 if rng.random() < 0.5 else -1
+        y = side * rng.uniform(3.0, 5.5)
+        boxes.append([x, y - 0.9, 0.0, x + rng.uniform(3.8, 4.8), y + 0.9, rng.uniform(1.3, 1.7)])
+        x += rng.uniform(6.0, 15.0)
+    x = x0
+    while x < x1:                   # poles
+        for side in (1, -1):
+            cyl.append([x + rng.uniform(-1, 1), side * rng.uniform(6.5, 8.0), 0.2, 0.0, rng.uniform(4.0, 8.0)])
+        x += 15.0
+    for _ in range(n_trees):
+        cx = rng.uniform(x0, x1)
+        cy = rng.choice([-1, 1]) * rng.uniform(7.5, half_extent)
+        r = rng.uniform(1.5, 3.6)
+        hz = rng.uniform(2.5, 7.0) + r
+        cyl.append([cx, cy, rng.uniform(0.12, 0.3), 0.0, hz - 0.6 * r])
+        sph.append([cx, cy, hz, r])
+    return Scene(np.array(planes, float), np.array(bounds, float), np.array(boxes, float), np.array(cyl, float), np.array(sph, float))
+
+
+def sample_scene_surfaces(scene: Scene, center, radius: float = 100.0, density: float = 70.0, noise: float = 0.02, seed: int = 0) -> np.ndarray:
+    """World points spread uniformly over the scene's surfaces within `radius` of `center` (density in points / m^2, Gaussian range-like
+    noise): what a local map has accumulated after a few hundred sweeps from many viewpoints, without ray-casting those sweeps. The
+    points then go through the map's own insert rule (minimum distance, capacity per voxel)."""
+    rng = np.random.default_rng(seed)
+    c = np.asarray(center, float)
+    out = []
+    # ground: the disc of the first plane (z = const)
+    n = int(np.pi * radius * radius * density)
+    rr, th = radius * np.sqrt(rng.random(n)), rng.uniform(0, 2 * np.pi, n)
+    z0 = -scene.planes[0, 3] / scene.planes[0, 2]
+    out.append(np.stack([c[0] + rr * np.cos(th), c[1] + rr * np.sin(th), np.full(n, z0)], 1))
+    for bx in scene.boxes:
+        lo, hi = bx[:3], bx[3:]
+        if np.linalg.norm(np.clip(c, lo, hi) - c) > radius:
+            continue
+        w, d, h = hi - lo
+        for axis, area in ((0, d * h), (1, w * h)):                 # the two pairs of vertical faces
+            for val in (lo[axis], hi[axis]):
+                m = int(area * density)
+                p = lo + rng.random((m, 3)) * (hi - lo)
+                p[:, axis] = val
+                out.append(p)
+        m = int(w * d * density)                                    # roof
+        p = lo + rng.random((m, 3)) * (hi - lo)
+        p[:, 2] = hi[2]
+        out.append(p)
+    for cx, cy, r, za, zb in scene.cylinders:
+        if np.hypot(cx - c[0], cy - c[1]) > radius + r:
+            continue
+        m = int(2 * np.pi * r * (zb - za) * density)
+        th = rng.uniform(0, 2 * np.pi, m)
+        out.append(np.stack([cx + r * np.cos(th), cy + r * np.sin(th), rng.uniform(za, zb, m)], 1))
+    for cx, cy, cz, r in scene.spheres:
+        if np.hypot(cx - c[0], cy - c[1]) > radius + r:
+            continue
+        m = int(4 * np.pi * r * r * density)
+        v = rng.normal(size=(m, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        out.append(np.array([cx, cy, cz]) + r * v)
+    pts = np.concatenate(out)
+    pts = pts[np.linalg.norm(pts - c, axis=1) <= radius]
+    if noise > 0:
+        pts = pts + rng.normal(0.0, noise, pts.shape)
+    return pts[rng.permutation(len(pts))]
+
+
 def box_scene(half: float = 10.0, n_spheres: int = 4, seed: int = 20240901) -> Scene:
     """Closed 6-plane box (reference test/integration/testint_utils.h:39-96) with a few spheres and pillars inside
     (courtyard-like)."""

@@ -329,6 +329,21 @@ ctgn_status ctgn_gn_set_system_buffer(ctgn_handle h, void *device_ptr);
 ctgn_status ctgn_gn_solve_update(ctgn_handle h);
 /* Synchronise, re-transform the world points with the final pose, return pose + summary. */
 ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summary);
+
+/* The keypoint-sharded loop with the collective issued by the library (no host code between the launches of an iteration):
+ * map replicated on every rank, each rank uploads ITS contiguous shard of the keypoints (ctgn_set_keypoints), then per iteration
+ * accumulate -> ncclAllReduce(sum, CTGN_SYSTEM_DOUBLES doubles, in place, on the handle's stream) -> solve / update on every rank
+ * (identical reduced input => identical poses, no broadcast). RCCL is bound at run time (dlopen "librccl.so.1"; shared with
+ * torch.distributed's instance when that is loaded). Bootstrap: rank 0 calls ctgn_dist_unique_id and ships the 128 bytes to the
+ * other ranks by whatever means the host has (the reference has no launcher to mirror: it is a single process), every rank
+ * then calls ctgn_dist_init (collective). Replaces nothing in the reference: ct_icp.cpp:843-850 sums over ALL keypoints and
+ * :877-882 needs the global count — this is that sum across GPUs. */
+#define CTGN_DIST_ID_BYTES 128
+ctgn_status ctgn_dist_unique_id(uint8_t out[CTGN_DIST_ID_BYTES]);
+ctgn_status ctgn_dist_init(ctgn_handle h, int32_t rank, int32_t world_size, const uint8_t id[CTGN_DIST_ID_BYTES]);
+ctgn_status ctgn_dist_shutdown(ctgn_handle h);
+ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double t_begin_end[2], const ctgn_options *opts,
+                               const ctgn_motion_prior *prior, ctgn_summary *summary);
 /* Non-blocking query of the device-side stop flag of the running GN loop (synchronises the stream). */
 ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done);
 
@@ -384,6 +399,11 @@ ctgn_status ctgn_set_search_kernel(ctgn_handle h, int32_t mode);
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel
  * fast path, 9 = rounds (counts, per wave), 10 = clocks of the slowest wave (max), 11 = waves. */
 ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset);
+/* What the instrumented row kernel (variant 3) actually requested from the memory system since the last reset: out[0] = hash probes
+ * issued (sweep voxels NOT culled against the radius / the k-th best distance; the shared-home-voxel path probes its 27 voxels once
+ * per wave), out[1] = map points streamed. bench.py prices the kernel's algorithmic bytes with these instead of
+ * charging every point of all 27 / 125 sweep voxels. Measurement hook. */
+ctgn_status ctgn_traffic_counters(ctgn_handle h, uint64_t out[2], int32_t reset);
 /* Per-wave timeline of the last variant-3 launch: 4 words per wave slot (start clock, end clock, fast-path rounds,
  * rounds); slots of waves that did not run keep their previous content (zero initially). */
 ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves);

@@ -366,15 +366,18 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
         created = True
     try:
-        sh = ShardedGnSolver(gm)
-        sh.set_keypoints(raw, world0, t)
-        pose_s, summ_s, _ = sh.solve(pose0, sc.t_begin_end, o)
-        torch.cuda.synchronize()
-        assert np.array_equal(pose_f, pose_s) and summ_s.num_iters == 4
-        assert np.array_equal(w_f, sh.solver.world_points())
-        A, b, n = sh.solver.get_system()
-        assert n == summ_s.num_residuals_used
-        sh.close()
+        # both flavours: the collective issued by the library (ncclAllReduce from C, ctgn_solve_sharded) and the stepwise loop with
+        # torch.distributed.all_reduce in between
+        for library_collective in (True, False):
+            sh = ShardedGnSolver(gm, library_collective=library_collective)
+            sh.set_keypoints(raw, world0, t)
+            pose_s, summ_s, _ = sh.solve(pose0, sc.t_begin_end, o)
+            torch.cuda.synchronize()
+            assert np.array_equal(pose_f, pose_s) and summ_s.num_iters == 4
+            assert np.array_equal(w_f, sh.solver.world_points())
+            A, b, n = sh.solver.get_system()
+            assert n == summ_s.num_residuals_used
+            sh.close()
     finally:
         if created:
             dist.destroy_process_group()
@@ -1025,3 +1028,91 @@ def test_config_d_dense_scan_one_iteration_matches_oracle():
         assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max() and np.abs(b - bo).max() < 1e-10 * np.abs(bo).max() + 1e-14
         tr, rot = se3.pose_error(pose1, pose_o)
         assert tr < TIGHT and rot < TIGHT, (tr, rot)
+
+
+# ------------------------------------------------------------------------------------------------- two GPUs (skipped on a 1-GPU box)
+def _two_gpus():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+def _sharded_worker(rank, world, port, tmpdir):
+    import os, sys
+    sys.path.insert(0, ROOT_DIR); sys.path.insert(0, os.path.join(ROOT_DIR, "tests"))
+    import torch
+    import torch.distributed as dist
+    import conftest
+    from ct_icp_amd.distributed import ShardedGnSolver, home_voxel_order, shard_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    case = conftest.street_case.__wrapped__()
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in case["resolutions"]],
+                                                default_radius=case["default_radius"], device=rank))
+    for j in range(6):
+        gm.InsertPointCloud(case["scans"][j].world_gt)                 # the map is replicated
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, 0.3)
+    order = home_voxel_order(world0, case["resolutions"][0][0])        # global home-voxel sort, then contiguous chunks
+    lo, hi = shard_bounds(len(t), world, rank)
+    idx = order[lo:hi]
+    sh = ShardedGnSolver(gm)
+    sh.set_keypoints(raw[idx], world0[idx], t[idx])
+    pose, summ, _ = sh.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=5, threshold_orientation_norm=0.0))
+    np.save(os.path.join(tmpdir, f"pose_{rank}.npy"), np.concatenate([pose, [summ.num_residuals_used, summ.num_iters]]))
+    sh.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_two_gpu_shard_systems_sum_to_the_single_gpu_system(street_case):
+    """SURVEY.md section 8e on hardware: the packed systems of two GPU shards (contiguous chunks of the home-voxel-sorted keypoints,
+    map replicated on both devices) add up to the single-GPU system (<= 1e-12 relative; same count)."""
+    from ct_icp_amd.distributed import home_voxel_order, shard_bounds
+    case = street_case
+    maps = []
+    for dev in (0, 1):
+        gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in case["resolutions"]],
+                                                    default_radius=case["default_radius"], device=dev))
+        for j in range(6):
+            gm.InsertPointCloud(case["scans"][j].world_gt)
+        maps.append(gm)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, 0.3)
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    order = home_voxel_order(world0, case["resolutions"][0][0])
+    s = cia.GnSolver(maps[0])
+    s.set_keypoints(raw[order], world0[order], t[order])
+    s.solve(pose0, sc.t_begin_end, o)
+    A, b, n = s.get_system()
+    As, bs, ns = np.zeros_like(A), np.zeros_like(b), 0
+    for dev in (0, 1):
+        lo, hi = shard_bounds(len(t), 2, dev)
+        idx = order[lo:hi]
+        sd = cia.GnSolver(maps[dev])
+        sd.set_keypoints(raw[idx], world0[idx], t[idx])
+        sd.gn_begin(pose0, sc.t_begin_end, o, None)
+        sd.gn_accumulate()
+        Ad, bd, nd = sd.get_system()
+        sd.gn_solve_update(); sd.gn_end()
+        As += Ad * 1.0; bs += bd; ns += nd
+    assert ns == n and np.abs(As - A).max() < 1e-12 * np.abs(A).max() and np.abs(bs - b).max() < 1e-12 * np.abs(b).max() + 1e-18
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_two_rank_sharded_registration_over_rccl(street_case, tmp_path):
+    """Two processes, one GPU each, ncclAllReduce issued by the library: both ranks end on the identical pose, equal (<= 1e-12) to the
+    single-GPU registration of the whole keypoint set."""
+    import torch.multiprocessing as mp
+    mp.spawn(_sharded_worker, args=(2, 29541, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "pose_0.npy"), np.load(tmp_path / "pose_1.npy")
+    assert np.array_equal(p0, p1)
+    om, gm = build_maps(street_case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(street_case, 6, 0.3)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    pose, summ, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=5, threshold_orientation_norm=0.0))
+    assert int(p0[14]) == summ.num_residuals_used and int(p0[15]) == summ.num_iters
+    assert np.abs(p0[:14] - pose).max() < 1e-12
