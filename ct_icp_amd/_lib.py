@@ -113,6 +113,7 @@ SYMBOLS = {
     "ctgn_dist_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "ctgn_dist_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "ctgn_dist_shutdown": (C.c_int, [_H]),
+    "ctgn_gn_iterate": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "ctgn_get_world_points": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
     "ctgn_grid_sampling": (C.c_int, [_H, View, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_adaptive_sampling_options_default": (None, [C.POINTER(AdaptiveSamplingOptions)]),

@@ -59,6 +59,8 @@ struct ctgn_context {
     DevMapScratch dm;
     OrderScratch ord;                   // keypoint order of the neighbour-search kernel (sorted by home voxel), see order_keypoints
     bool order_valid = false, order_stale = true;
+    bool kp_coherent = false;           // the upload's own order is spatially coherent (scan order): consecutive keypoints mostly share or
+                                        // neighbour their home voxel; an incoherent one (shuffled, config D) is what ordering is for
     bool dense_ok = false;              // the ordered positions crowd their home voxels: k_search_dense instead of k_accumulate_rows
     int dense_mode = -1;                // -1 automatic (by the run count of the order), 0 never, 1 whenever the upload is ordered
     int planned_iters = 0;              // iteration budget of the running solve (num_iters_icp)
@@ -392,7 +394,9 @@ bool want_order(ctgn_handle h, uint64_t level_points) {
     const int forced = h->ordering_mode >= 0 ? h->ordering_mode : env_forced;
     if (forced >= 0) return forced != 0 && h->n_kp > 0;
     if (h->n_kp < 32768) return false;
-    if (level_points * 24ull >= (128ull << 20)) return true;
+    // a level that exceeds the caches: order an upload whose own order has no locality (config D: 3.35 -> 2.57 ms per launch); a
+    // sweep in firing order already walks the map coherently and gains nothing (B2 over the 270 MB map: 0.144 vs 0.145 ms)
+    if (level_points * 24ull >= (128ull << 20) && !h->kp_coherent) return true;
     const double n = (double) h->n_kp;
     return (double) h->planned_iters * n * 5e-5 > 60.0 + 1.5e-4 * n;
 }
@@ -556,7 +560,10 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
-            kv.xcd_split = (h->order_valid && g1 >= 64) ? 1 : 0;      // D: 3.34 -> 3.15 ms per launch; B2 ordered: +1-2 %
+            static const int env_xcd = [] { const char *e = std::getenv("CTGN_XCD_SPLIT"); return e ? std::atoi(e) : -1; }();     // measurement hook
+            // one contiguous eighth of the tiles per XCD: +4 % on config D (uniformly spread keypoints), -50 % on a sweep whose density
+            // varies along the sort key (the eighths then differ in work: B2 over the 270 MB map 0.145 -> 0.215 ms) -> incoherent uploads only
+            kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : (h->order_valid && !h->kp_coherent)) && g1 >= 64 ? 1 : 0;
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
@@ -980,6 +987,26 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     }
     h->t_min = tmin; h->t_max = tmax;
     h->pose_on_device = false;
+    h->kp_coherent = false;
+    if (n >= 32768) {
+        // spatial coherence of the caller's order, probed on ~4 k consecutive pairs of the staged world points at the search
+        // resolution: a LiDAR sweep in firing order is coherent (>90 % of consecutive returns fall into the same or a neighbouring
+        // voxel), a shuffled cloud is not. Only an incoherent upload is ordered for the sake of the caches (want_order).
+        int map_id, nb;
+        double res;
+        search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
+        const size_t step = std::max<size_t>(1, (n - 1) / 4096);
+        size_t pairs = 0, near = 0;
+        for (size_t i = 0; i + 1 < n; i += step, ++pairs) {
+            bool ok = true;
+            for (int a = 0; a < 3 && ok; ++a) {
+                const int v0 = voxel_coord(h->h_kp[(4 + a) * c + i], res), v1 = voxel_coord(h->h_kp[(4 + a) * c + i + 1], res);
+                ok = std::abs(v0 - v1) <= 1;
+            }
+            near += ok ? 1 : 0;
+        }
+        h->kp_coherent = pairs > 0 && 2 * near >= pairs;
+    }
     size_t words = 7 * c;
     if (n && h->pose_with_kp) {                    // ctgn_register: the pose shares the upload
         for (int i = 0; i < 14; ++i) h->h_kp[7 * c + i] = h->pose_with_kp[i];
@@ -1072,6 +1099,28 @@ ctgn_status ctgn_gn_accumulate(ctgn_handle h) {
     if (st != CTGN_OK) return st;
     h->launched_iters++;
     return launch_reduce_solve(h, 1);
+}
+
+// `iterations` whole GN iterations enqueued behind ctgn_gn_begin: the fused sequence ctgn_solve runs (search -> residual/reduce ->
+// reduce + solve), or with `sharded` the sequence of ctgn_solve_sharded (... -> reduce -> ncclAllReduce -> solve). No synchronisation.
+ctgn_status ctgn_gn_iterate(ctgn_handle h, int32_t iterations, int32_t sharded) {
+    NEED_DEVICE(h);
+    if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
+    if (sharded && !h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
+    MapView mv;
+    ctgn_status st = make_map_view(h, -1.0, &mv);
+    for (int it = 0; st == CTGN_OK && it < iterations; ++it) {
+        st = launch_accumulate(h, mv, h->launched_iters == 0);
+        if (st != CTGN_OK) break;
+        h->launched_iters++;
+        if (!sharded) { st = launch_reduce_solve(h, 0); continue; }
+        st = launch_reduce_solve(h, 1);
+        if (st != CTGN_OK) break;
+        const ncclResult_t r = rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) { st = fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclAllReduce: ") + rccl_api().GetErrorString(r)); break; }
+        st = launch_reduce_solve(h, 2);
+    }
+    return st;
 }
 
 ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out) {

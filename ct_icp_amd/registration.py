@@ -303,6 +303,10 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_gn_begin(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(opts),
                                               C.byref(prior) if prior is not None else None))
 
+    def gn_iterate(self, iterations: int, sharded: bool = False):
+        """Enqueue whole GN iterations behind gn_begin (no synchronisation); see ctgn_gn_iterate."""
+        L.check(self._h, L.lib().ctgn_gn_iterate(self._h, int(iterations), int(bool(sharded))))
+
     def gn_accumulate(self):
         L.check(self._h, L.lib().ctgn_gn_accumulate(self._h))
 

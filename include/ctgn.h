@@ -320,6 +320,10 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double t_b
 /* Enqueue neighbour search + residual/Jacobian + reduction for the current pose; the packed system
  * (CTGN_SYSTEM_DOUBLES doubles: 78 JtJ upper | 12 Jtr | count | pad) is left in device memory. */
 ctgn_status ctgn_gn_accumulate(ctgn_handle h);
+/* Enqueue `iterations` whole GN iterations behind ctgn_gn_begin without synchronising: the fused launch sequence of ctgn_solve, or
+ * (sharded != 0, after ctgn_dist_init) the one of ctgn_solve_sharded with its ncclAllReduce. ctgn_solve == begin + iterate(num_iters_icp)
+ * + end. Lets a caller (bench.py) bracket exactly K iterations of an already running loop with its own timers. */
+ctgn_status ctgn_gn_iterate(ctgn_handle h, int32_t iterations, int32_t sharded);
 /* Device address of the packed system (valid for the life of the handle, or until ctgn_gn_set_system_buffer). */
 ctgn_status ctgn_gn_system_device_ptr(ctgn_handle h, void **out_device_ptr);
 /* Make the library keep the packed system in a caller-owned device buffer of CTGN_SYSTEM_DOUBLES doubles (e.g. a
