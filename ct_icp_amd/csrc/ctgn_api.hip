@@ -506,6 +506,22 @@ int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
     return per_cu * h->num_cus;
 }
 
+// k_residual_reduce: 256-thread blocks for throughput, 64-thread blocks for small frames (the scattered gathers are bound by the
+// per-CU texture path, so a small frame wants MORE CUs, not fuller ones). Returns the grid = number of per-block partials.
+int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const DebugView &dv, const NbSums &sums) {
+    static const int env_small = [] { const char *e = std::getenv("CTGN_RES_SMALL"); return e ? std::atoi(e) : -1; }();      // measurement hook
+    const bool small = env_small >= 0 ? env_small != 0 : h->n_kp <= 8192;
+    if (small) {
+        const int grid = std::max(1, std::min((h->n_kp + 63) / 64, h->res_grid_cap));
+        hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate, sums);
+        return grid;
+    }
+    const int grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
+    hipLaunchKernelGGL(k_residual_reduce<RES_BLOCK>, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
+                       h->ablate, sums);
+    return grid;
+}
+
 ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter, bool search_only = false) {
     if (h->order_stale) {
         ctgn_status os = order_keypoints(h, mv);
@@ -545,9 +561,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                                ntiles, h->debug ? 1 : 0, nullptr, h->ablate);
         if (ev) (void) hipEventRecord(ev->stop, h->stream);
         ev = nullptr;
-        grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
-        hipLaunchKernelGGL(k_residual_reduce, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
-                           h->ablate, sums);
+        grid = launch_residual(h, mv, kv, dv, sums);
     } else if (h->variant == 1 || !rows_ok) {
         const int ntiles = (h->n_kp + LANE_BLOCK - 1) / LANE_BLOCK;
         grid = std::max(1, std::min(ntiles, MAX_PARTIAL_BLOCKS));
@@ -570,9 +584,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             ev = nullptr;
             if (search_only) { grid = g1; return; }
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
-            grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
-            hipLaunchKernelGGL(k_residual_reduce, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm,
-                               h->d_partials, dv, h->ablate, NbSums{nullptr, nullptr, 0});
+            grid = launch_residual(h, mv, kv, dv, NbSums{nullptr, nullptr, 0});
         };
         if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();

@@ -972,23 +972,17 @@ struct NbSums {
 constexpr int RES_BLOCK = 256;
 constexpr int GG = 8;                // neighbours gathered per group: 3 x GG independent loads in flight per lane
 
-__global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                                 double *partials, DebugView dbg, int ablate, NbSums sums) {
-    __shared__ double s_rec[RES_BLOCK / 64][64 * 13];
-    __shared__ double s_comb[RES_BLOCK / 64][SYS_N];
-    if (st->done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// One wave, one keypoint per lane (position my_pos): neighbour set -> sums -> normal, gates, residual, u -> the wave's 13 x 13 product
+// U^T U added to accm (FP64 MFMA, fixed order). `rec` is this wave's 64 x 13 LDS staging area.
+__device__ __forceinline__ void residual_tile(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
+                                              int ablate, const NbSums &sums, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave) {
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
     const uint32_t blk8 = (uint32_t) map.blk * 8u;
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
-    typedef double d4_t __attribute__((ext_vector_type(4)));
-    d4_t accm = {0.0, 0.0, 0.0, 0.0};
-    int n_used_wave = 0;
-    const int ntiles = (kp.n + RES_BLOCK - 1) / RES_BLOCK;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // position -> keypoint: with kp.order the lanes of a wave take keypoints of neighbouring voxels, so their gathers share
         // cache lines (the sums then run in position order: still fixed, a different rounding than index order)
-        const int my_pos = tile * RES_BLOCK + tid;
         const int my_kp = (kp.order && my_pos < kp.n) ? (int) kp.order[my_pos] : my_pos;
         double u[12], rr = 0.0;
         bool used = false;
@@ -1075,11 +1069,10 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
         // U^T U: sixteen v_mfma_f64_16x16x4_f64 per tile, K = 4 keypoints each; lane l feeds U[k0 + (l >> 4)][l & 15] as both
         // A[i = l & 15][k] and B[k][j = l & 15] (one LDS read per lane and step — the lane-per-entry loop this replaces read
         // four doubles per lane and keypoint and was bound by LDS bandwidth). Accumulation order is fixed: deterministic.
-        double *rec = s_rec[wave];
         double *my = rec + lane * 13;
         const unsigned long long used_lanes = __ballot(used);
         n_used_wave += __popcll(used_lanes);
-        if (used_lanes == 0ull) continue;            // a wave of dropped keypoints adds exact zeros: nothing to stage, nothing to multiply
+        if (used_lanes == 0ull) return;              // a wave of dropped keypoints adds exact zeros: nothing to stage, nothing to multiply
 #pragma unroll
         for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
         my[12] = used ? rr : 0.0;
@@ -1091,25 +1084,42 @@ __global__ __launch_bounds__(RES_BLOCK, 3) void k_residual_reduce(MapView map, K
                 accm = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accm, 0, 0, 0);
             }
         }
-    }
-    // block combine: lane l holds (U^T U)[row = (l >> 4) + 4 m][col = l & 15], m = 0..3 (the f64 MFMA's C/D layout); the upper
-    // triangle goes to the packed entries, column 12 (sum u_i r) to -J^T r; fixed order over the waves
-    if (lane < SYS_N - SYS_USED) s_comb[wave][SYS_USED + lane] = 0.0;
-    {
-        const int col = lane & 15;
+}
+
+// lane l holds (U^T U)[row = (l >> 4) + 4 m][col = l & 15], m = 0..3 (the f64 MFMA's C/D layout); the upper triangle goes to the
+// packed entries, column 12 (sum u_i r) to -J^T r, the wave's keypoint count to entry 90
+__device__ __forceinline__ void unpack_wave_sums(int lane, const d4_t &accm, int n_used_wave, double *comb) {
+    if (lane < SYS_N - SYS_USED) comb[SYS_USED + lane] = 0.0;
+    const int col = lane & 15;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int row = (lane >> 4) + 4 * m;
-            if (row < 12 && col >= row && col < 12) s_comb[wave][row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
-            if (row < 12 && col == 12) s_comb[wave][78 + row] = -accm[m];
-        }
-        if (lane == 0) s_comb[wave][90] = (double) n_used_wave;
+    for (int m = 0; m < 4; ++m) {
+        const int row = (lane >> 4) + 4 * m;
+        if (row < 12 && col >= row && col < 12) comb[row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
+        if (row < 12 && col == 12) comb[78 + row] = -accm[m];
     }
+    if (lane == 0) comb[90] = (double) n_used_wave;
+}
+
+// BLK = 256 (throughput: 4 waves share a CU's texture path) or 64 (small frames: the 60 scattered gathers per keypoint are bound by the
+// per-CU texture path — ~1 line per clock — so a 1 k-keypoint frame is spread over 16 CUs instead of 4)
+template <int BLK>
+__global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                            double *partials, DebugView dbg, int ablate, NbSums sums) {
+    __shared__ double s_rec[BLK / 64][64 * 13];
+    __shared__ double s_comb[BLK / 64][SYS_N];
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    d4_t accm = {0.0, 0.0, 0.0, 0.0};
+    int n_used_wave = 0;
+    const int ntiles = (kp.n + BLK - 1) / BLK;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+        residual_tile(map, kp, st, prm, dbg, ablate, sums, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave);
+    unpack_wave_sums(lane, accm, n_used_wave, s_comb[wave]);
     __syncthreads();
-    if (tid < SYS_N) {
+    for (int e = tid; e < SYS_N; e += BLK) {
         double s = 0.0;
-        for (int w = 0; w < RES_BLOCK / 64; ++w) s += s_comb[w][tid];
-        partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
+        for (int w = 0; w < BLK / 64; ++w) s += s_comb[w][e];
+        partials[(size_t) e * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
     }
 }
 
@@ -1129,60 +1139,53 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
 }
 
 #define WSYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
-__global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
-                                                              GnParams prm, int mode, int min_used) {
-    __shared__ double s_sys[SYS_N];
-    __shared__ double s_m[144];
-    __shared__ double s_temp[12];
-    __shared__ double s_x[12];
-    __shared__ double s_b[12];
-    __shared__ int s_perm[12];
-    __shared__ double s_sc[12];
-    __shared__ double s_q[8];
-    if (st->done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long tc0 = __builtin_readcyclecounter();
-    if (mode != 2) {
-        // wave w owns entries w, w+16, ..., w+80: six independent lane-strided sums (loads of all six in flight
-        // together), then six fixed shuffle trees
-        constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 3;
-        double acc[EPW];
-#pragma unroll
-        for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
-        // 16-byte loads: a lane takes blocks 2*lane and 2*lane + 1 of each 128-block span; with <= 640 blocks (the
-        // usual case) all 5 x 6 loads of a lane are in flight at once, so the reduction costs one memory round trip
-        for (int b0 = 0; b0 < nblocks; b0 += 128 * RU) {
-            double2 v[RU][EPW];
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int b = b0 + 128 * u + 2 * lane;
-                const int bb = b < nblocks ? b : 0;
-#pragma unroll
-                for (int q = 0; q < EPW; ++q)
-                    v[u][q] = *reinterpret_cast<const double2 *>(partials + (size_t) (wave + 16 * q) * MAX_PARTIAL_BLOCKS + bb);
-            }
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int b = b0 + 128 * u + 2 * lane;
-#pragma unroll
-                for (int q = 0; q < EPW; ++q) {
-                    acc[q] += (b < nblocks) ? v[u][q].x : 0.0;
-                    acc[q] += (b + 1 < nblocks) ? v[u][q].y : 0.0;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < EPW; ++q) {
-            const double s = wave_sum_fixed(acc[q]);
-            if (lane == 0) { sys[wave + 16 * q] = s; s_sys[wave + 16 * q] = s; }
-        }
-    } else {
-        if (tid < SYS_N) s_sys[tid] = sys[tid];
-    }
-    __syncthreads();
-    if (mode == 1 || wave != 0) return;
 
-    // ---- wave 0 only from here
+struct SolveScratch {                 // LDS of the 12 x 12 solve (wave 0)
+    double sys[SYS_N];
+    double m[144], temp[12], x[12], b[12], sc[12], q[8];
+    int perm[12];
+};
+
+// Sum of the per-block partials of the packed system, 16 waves: wave w owns entries w, w+16, ..., w+80 — six independent
+// lane-strided sums (a lane takes blocks 2 lane and 2 lane + 1 of each 128-block span; 16-byte loads, all in flight together), then
+// six fixed shuffle trees. `load2(entry, b)` returns the partials of blocks b and b + 1 (b even). Deterministic.
+template <typename Load2>
+__device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wave, int lane, double *sys_global, double *s_sys) {
+    constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 3;
+    double acc[EPW];
+#pragma unroll
+    for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 128 * RU) {
+        double2 v[RU][EPW];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int b = b0 + 128 * u + 2 * lane;
+            const int bb = b < nblocks ? b : 0;
+#pragma unroll
+            for (int q = 0; q < EPW; ++q) v[u][q] = load2(wave + 16 * q, bb);
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int b = b0 + 128 * u + 2 * lane;
+#pragma unroll
+            for (int q = 0; q < EPW; ++q) {
+                acc[q] += (b < nblocks) ? v[u][q].x : 0.0;
+                acc[q] += (b + 1 < nblocks) ? v[u][q].y : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EPW; ++q) {
+        const double s = wave_sum_fixed(acc[q]);
+        if (lane == 0) { sys_global[wave + 16 * q] = s; s_sys[wave + 16 * q] = s; }
+    }
+}
+
+// normalise, motion prior, LDL^T, pose update, stop test (ct_icp.cpp:860-962, :978-980) by ONE wave on the packed system in S.sys
+__device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const GnParams &prm, int min_used, int lane,
+                                            unsigned long long tc0) {
+    double *s_sys = S.sys, *s_m = S.m, *s_temp = S.temp, *s_x = S.x, *s_b = S.b, *s_sc = S.sc, *s_q = S.q;
+    int *s_perm = S.perm;
     const unsigned long long tc1 = __builtin_readcyclecounter();
     const int n_used = (int) (s_sys[90] + 0.5);
     if (n_used < min_used) {              // ct_icp.cpp:860-871 — soft failure, pose untouched
@@ -1356,6 +1359,23 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     if (nrm < prm.thr_norm) st->done = 1;                           // :978-980
     st->solve_cycles[0] = tc1 - tc0; st->solve_cycles[1] = tc2 - tc1; st->solve_cycles[2] = tc3 - tc2;
     st->solve_cycles[3] = __builtin_readcyclecounter() - tc3;
+}
+
+__global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
+                                                              GnParams prm, int mode, int min_used) {
+    __shared__ SolveScratch S;
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    if (mode != 2) {
+        reduce_partials([&](int e, int b) { return *reinterpret_cast<const double2 *>(partials + (size_t) e * MAX_PARTIAL_BLOCKS + b); },
+                        nblocks, wave, lane, sys, S.sys);
+    } else {
+        if (tid < SYS_N) S.sys[tid] = sys[tid];
+    }
+    __syncthreads();
+    if (mode == 1 || wave != 0) return;
+    solve_wave0(S, st, prm, min_used, lane, tc0);
 }
 
 #undef WSYNC

@@ -265,6 +265,24 @@ def test_stepwise_api_equals_fused_loop(box_case):
     pose_s, summ_s, _ = s.gn_end()
     assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, s.world_points())       # deterministic reductions
     assert summ_s.num_iters == summ_f.num_iters == 4
+    # small frames take 64-thread residual blocks (more CUs for the scattered gathers), large ones 256-thread blocks; either way the
+    # fused loop and the stepwise entry points give identical bits — odd block counts, ragged last groups, soft failure (< 100 used)
+    for n in (2048, 2047, 1300, 1025, 1024, 777, 256, 65, 64, 40):
+        idx = np.arange(n) % len(t)
+        for prior in (None, _prior(box_case, 5)[0]):
+            s.set_keypoints(raw[idx], world0[idx], t[idx])
+            pose_f, summ_f, _ = s.solve(pose0, sc.t_begin_end, o, prior)
+            w_f, sys_f = s.world_points(), s.get_system()
+            s.set_keypoints(raw[idx], world0[idx], t[idx])
+            s.gn_begin(pose0, sc.t_begin_end, o, prior)
+            for _ in range(4):
+                s.gn_accumulate()
+                s.gn_solve_update()
+            pose_s, summ_s, _ = s.gn_end()
+            assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, s.world_points()), n
+            assert summ_s.success == summ_f.success and summ_s.num_iters == summ_f.num_iters and summ_s.num_residuals_used == summ_f.num_residuals_used
+            sys_s = s.get_system()
+            assert np.array_equal(sys_f[0], sys_s[0]) and np.array_equal(sys_f[1], sys_s[1]) and sys_f[2] == sys_s[2]
 
 
 # ------------------------------------------------------------------------------------------------- full-size properties
