@@ -51,7 +51,8 @@ class MotionPrior(C.Structure):
 class Summary(C.Structure):
     _fields_ = [("success", C.c_int32), ("num_residuals_used", C.c_int32), ("num_iters", C.c_int32),
                 ("_pad", C.c_int32), ("duration_total_ms", C.c_double), ("duration_device_ms", C.c_double),
-                ("last_step_norm", C.c_double), ("error_log", C.c_char * 256)]
+                ("last_step_norm", C.c_double), ("duration_init_ms", C.c_double), ("avg_duration_neighborhood_ms", C.c_double),
+                ("avg_duration_solve_ms", C.c_double), ("avg_duration_iter_ms", C.c_double), ("error_log", C.c_char * 256)]
 
 
 class RobustOptions(C.Structure):

@@ -48,10 +48,10 @@ int main() {
         reg.Options().debug_print = false;
         ICPSummary s = reg.Register(map, kps, frame, nullptr);
         double err = 0;
-        for (int c = 0; c < 3; ++c) err = std::fmax(err, std::fabs(frame.end_pose.tr[c] - shift[c]));
+        for (int c = 0; c < 3; ++c) err = std::fmax(err, std::fabs(frame.end_pose.pose.tr[c] - shift[c]));
         std::printf("adapter %s n_used=%d iters=%d tr=%.6f %.6f %.6f err=%.2e map_points=%zu\n",
-                    (s.success && err < 1e-6) ? "ok" : "FAIL", s.num_residuals_used, s.num_iters, frame.end_pose.tr[0],
-                    frame.end_pose.tr[1], frame.end_pose.tr[2], err, map.NumPoints());
+                    (s.success && err < 1e-6) ? "ok" : "FAIL", s.num_residuals_used, s.num_iters, frame.end_pose.pose.tr[0],
+                    frame.end_pose.pose.tr[1], frame.end_pose.pose.tr[2], err, map.NumPoints());
         // raw-points insertion with poses + the in-place query spellings
         {
             std::vector<WPoint3D> extra(kps.begin(), kps.begin() + 500);
@@ -74,8 +74,8 @@ int main() {
             TransformFrame(map, copy, frame);
             double dmax = 0;
             for (const WPoint3D &p : copy)
-                for (int c = 0; c < 3; ++c) dmax = std::fmax(dmax, std::fabs(p.world_point[c] - p.raw_point[c] - (1.0 - p.timestamp) * frame.begin_pose.tr[c] -
-                                                     p.timestamp * frame.end_pose.tr[c]));
+                for (int c = 0; c < 3; ++c) dmax = std::fmax(dmax, std::fabs(p.world_point[c] - p.raw_point[c] - (1.0 - p.timestamp) * frame.begin_pose.pose.tr[c] -
+                                                     p.timestamp * frame.end_pose.pose.tr[c]));
             side_ok = side_ok && dmax < 1e-5;                     // the optimised rotations are the identity to ~1e-7
             std::printf("adapter-sampling %s grid=%zu adaptive=%zu undistort-err=%.1e\n", side_ok ? "ok" : "FAIL", sampled.size(),
                         adaptive.size(), dmax);
@@ -90,7 +90,7 @@ int main() {
         reg.Options().threshold_translation_norm = 1e-8;
         ICPSummary s2 = reg.Register(map, kps, frame2, nullptr);
         double err2 = 0;
-        for (int c = 0; c < 3; ++c) err2 = std::fmax(err2, std::fabs(frame2.end_pose.tr[c] - shift[c]));
+        for (int c = 0; c < 3; ++c) err2 = std::fmax(err2, std::fabs(frame2.end_pose.pose.tr[c] - shift[c]));
         std::printf("adapter-ceres %s n_res=%d iters=%d err=%.2e\n", (s2.success && err2 < 1e-5) ? "ok" : "FAIL",
                     s2.num_residuals_used, s2.num_iters, err2);
         return (s.success && err < 1e-6 && s2.success && err2 < 1e-5 && side_ok) ? 0 : 1;

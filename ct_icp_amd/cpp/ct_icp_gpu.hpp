@@ -16,6 +16,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstddef>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -35,22 +36,31 @@ struct WPoint3D {
 };
 static_assert(sizeof(WPoint3D) == 64, "WPoint3D must keep the reference's 64-byte layout");
 
-// slam::Pose (include/SlamCore/types.h:161-274): quaternion coeffs (x, y, z, w), translation, destination timestamp.
-struct Pose {
+// slam::TSE3<double> (include/SlamCore/types.h:104-138): Eigen::Quaterniond (coeffs x, y, z, w; 16-byte aligned) + Eigen::Vector3d.
+struct alignas(16) SE3 {
     double quat[4] = {0, 0, 0, 1};
     double tr[3] = {0, 0, 0};
-    double dest_timestamp = -1.0;
-    double ref_timestamp = 0.0;
-    int64_t dest_frame_id = -1, ref_frame_id = 0;
 };
+// slam::TPose<double> (types.h:161-167), the reference's member ORDER: pose, ref_timestamp, dest_timestamp, ref_frame_id, dest_frame_id
+// (frame_id_t = unsigned int, types.h:19). Same size and offsets as the reference's struct as compiled (oracle/_ref: ref_layout()).
+struct Pose {
+    SE3 pose;
+    double ref_timestamp = 0.0;
+    double dest_timestamp = -1.0;
+    unsigned int ref_frame_id = 0;
+    unsigned int dest_frame_id = (unsigned int) -1;
+};
+static_assert(sizeof(SE3) == 64 && offsetof(SE3, tr) == 32, "slam::SE3 layout");
+static_assert(sizeof(Pose) == 96 && offsetof(Pose, ref_timestamp) == 64 && offsetof(Pose, dest_timestamp) == 72 &&
+              offsetof(Pose, ref_frame_id) == 80 && offsetof(Pose, dest_frame_id) == 84, "slam::Pose layout");
 
 // ct_icp::TrajectoryFrame (include/ct_icp/types.h:31-61)
 struct TrajectoryFrame {
     Pose begin_pose, end_pose;
-    const double *BeginTr() const { return begin_pose.tr; }
-    const double *EndTr() const { return end_pose.tr; }
-    const double *BeginQuat() const { return begin_pose.quat; }
-    const double *EndQuat() const { return end_pose.quat; }
+    const double *BeginTr() const { return begin_pose.pose.tr; }
+    const double *EndTr() const { return end_pose.pose.tr; }
+    const double *BeginQuat() const { return begin_pose.pose.quat; }
+    const double *EndQuat() const { return end_pose.pose.quat; }
 };
 
 enum CT_ICP_SOLVER { GN, CERES, ROBUST };                    // include/ct_icp/ct_icp.h:35-39
@@ -195,8 +205,8 @@ public:
     void InsertPointCloud(std::vector<WPoint3D> &frame, const Pose &begin_pose, const Pose &end_pose, std::vector<size_t> &out_selected_points) {
         if (!frame.empty()) {
             double pose[14];
-            std::memcpy(pose, begin_pose.quat, 32); std::memcpy(pose + 4, begin_pose.tr, 24);
-            std::memcpy(pose + 7, end_pose.quat, 32); std::memcpy(pose + 11, end_pose.tr, 24);
+            std::memcpy(pose, begin_pose.pose.quat, 32); std::memcpy(pose + 4, begin_pose.pose.tr, 24);
+            std::memcpy(pose + 7, end_pose.pose.quat, 32); std::memcpy(pose + 11, end_pose.pose.tr, 24);
             const double tbe[2] = {begin_pose.dest_timestamp, end_pose.dest_timestamp};
             ctgn_view raw{frame[0].raw_point, sizeof(WPoint3D), CTGN_F64, 0};
             ctgn_view ts{&frame[0].timestamp, sizeof(WPoint3D), CTGN_F64, 0};
@@ -245,10 +255,10 @@ public:
             pp = &prior;
         }
         double pose[14];
-        std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
-        std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
-        std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
-        std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+        std::memcpy(pose, trajectory_frame.begin_pose.pose.quat, 32);
+        std::memcpy(pose + 4, trajectory_frame.begin_pose.pose.tr, 24);
+        std::memcpy(pose + 7, trajectory_frame.end_pose.pose.quat, 32);
+        std::memcpy(pose + 11, trajectory_frame.end_pose.pose.tr, 24);
         const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
         const size_t n = keypoints.size();
         WPoint3D dummy{};
@@ -264,16 +274,19 @@ public:
             out.error_log = ctgn_last_error(voxel_map.handle());
             return out;
         }
-        std::memcpy(trajectory_frame.begin_pose.quat, pose, 32);
-        std::memcpy(trajectory_frame.begin_pose.tr, pose + 4, 24);
-        std::memcpy(trajectory_frame.end_pose.quat, pose + 7, 32);
-        std::memcpy(trajectory_frame.end_pose.tr, pose + 11, 24);
+        std::memcpy(trajectory_frame.begin_pose.pose.quat, pose, 32);
+        std::memcpy(trajectory_frame.begin_pose.pose.tr, pose + 4, 24);
+        std::memcpy(trajectory_frame.end_pose.pose.quat, pose + 7, 32);
+        std::memcpy(trajectory_frame.end_pose.pose.tr, pose + 11, 24);
         out.success = s.success != 0;
         out.num_residuals_used = s.num_residuals_used;
         out.num_iters = s.num_iters;
         out.error_log = s.error_log;
-        out.duration_total = s.duration_total_ms * 1e-3;
-        out.avg_duration_iter = s.num_iters ? s.duration_device_ms * 1e-3 / s.num_iters : 0.0;
+        out.duration_total = s.duration_total_ms;                       // milliseconds, as the reference's duration_ms (ct_icp.cpp:24-27)
+        out.duration_init = s.duration_init_ms;
+        out.avg_duration_iter = s.avg_duration_iter_ms;
+        out.avg_duration_neighborhood = s.avg_duration_neighborhood_ms;
+        out.avg_duration_solve = s.avg_duration_solve_ms;
         return out;
     }
 
@@ -311,10 +324,10 @@ private:
             pp = &prior;
         }
         double pose[14];
-        std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
-        std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
-        std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
-        std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+        std::memcpy(pose, trajectory_frame.begin_pose.pose.quat, 32);
+        std::memcpy(pose + 4, trajectory_frame.begin_pose.pose.tr, 24);
+        std::memcpy(pose + 7, trajectory_frame.end_pose.pose.quat, 32);
+        std::memcpy(pose + 11, trajectory_frame.end_pose.pose.tr, 24);
         const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
         const size_t n = keypoints.size();
         WPoint3D dummy{};
@@ -331,16 +344,19 @@ private:
             out.error_log = ctgn_last_error(voxel_map.handle());
             return out;
         }
-        std::memcpy(trajectory_frame.begin_pose.quat, pose, 32);
-        std::memcpy(trajectory_frame.begin_pose.tr, pose + 4, 24);
-        std::memcpy(trajectory_frame.end_pose.quat, pose + 7, 32);
-        std::memcpy(trajectory_frame.end_pose.tr, pose + 11, 24);
+        std::memcpy(trajectory_frame.begin_pose.pose.quat, pose, 32);
+        std::memcpy(trajectory_frame.begin_pose.pose.tr, pose + 4, 24);
+        std::memcpy(trajectory_frame.end_pose.pose.quat, pose + 7, 32);
+        std::memcpy(trajectory_frame.end_pose.pose.tr, pose + 11, 24);
         out.success = s.success != 0;
         out.num_residuals_used = s.num_residuals_used;
         out.num_iters = s.num_iters;
         out.error_log = s.error_log;
-        out.duration_total = s.duration_total_ms * 1e-3;
-        out.avg_duration_iter = s.num_iters ? s.duration_device_ms * 1e-3 / s.num_iters : 0.0;
+        out.duration_total = s.duration_total_ms;                       // milliseconds, as the reference's duration_ms (ct_icp.cpp:24-27)
+        out.duration_init = s.duration_init_ms;
+        out.avg_duration_iter = s.avg_duration_iter_ms;
+        out.avg_duration_neighborhood = s.avg_duration_neighborhood_ms;
+        out.avg_duration_solve = s.avg_duration_solve_ms;
         return out;
     }
 
@@ -403,10 +419,10 @@ inline std::vector<size_t> AdaptiveSamplePointsInGrid(GpuVoxelMap &voxel_map, co
 inline void TransformFrame(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &frame, const TrajectoryFrame &trajectory_frame) {
     if (frame.empty()) return;
     double pose[14];
-    std::memcpy(pose, trajectory_frame.begin_pose.quat, 32);
-    std::memcpy(pose + 4, trajectory_frame.begin_pose.tr, 24);
-    std::memcpy(pose + 7, trajectory_frame.end_pose.quat, 32);
-    std::memcpy(pose + 11, trajectory_frame.end_pose.tr, 24);
+    std::memcpy(pose, trajectory_frame.begin_pose.pose.quat, 32);
+    std::memcpy(pose + 4, trajectory_frame.begin_pose.pose.tr, 24);
+    std::memcpy(pose + 7, trajectory_frame.end_pose.pose.quat, 32);
+    std::memcpy(pose + 11, trajectory_frame.end_pose.pose.tr, 24);
     const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
     ctgn_view raw{frame[0].raw_point, sizeof(WPoint3D), CTGN_F64, 0};
     ctgn_view ts{&frame[0].timestamp, sizeof(WPoint3D), CTGN_F64, 0};

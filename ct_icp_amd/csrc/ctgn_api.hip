@@ -97,6 +97,7 @@ struct ctgn_context {
     int last_grid = 0;
     bool gn_active = false;
     std::chrono::steady_clock::time_point gn_t0;
+    double init_ms = 0.0;               // host time from the call to the first launch (ICPSummary::duration_init)
     hipEvent_t ev_loop_start = nullptr, ev_loop_stop = nullptr;
 
     // debug / introspection
@@ -460,6 +461,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
     v.xcd_split = 0;                    // set per launch (needs the grid size)
+    v.clk_iter_start = nullptr;         // set by launch_accumulate for the launch that opens an iteration
     return v;
 }
 
@@ -528,6 +530,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (os != CTGN_OK) return os;
     }
     KpView kv = kp_view(h, !search_only);
+    if (!search_only) kv.clk_iter_start = &h->d_state->clk_iter_start;
     DebugView dv = dbg_view(h);
     EventPair *ev = nullptr;
     if (h->profiling) {
@@ -1094,6 +1097,7 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
     h->launched_iters = 0;
+    h->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
     h->planned_iters = opts->num_iters_icp;
     h->events_used = 0;
     h->gn_active = true;
@@ -1200,6 +1204,12 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
         float ms = 0.f;
         hipEventElapsedTime(&ms, h->ev_loop_start, h->ev_loop_stop);
         summary->duration_device_ms = ms;
+        // ICPSummary's timing fields (ct_icp.h:164-168), from the device's 100 MHz wall clock stamped by the kernels themselves
+        const double per_iter = s.iter > 0 ? 1e-5 / (double) s.iter : 0.0;                 // 10 ns ticks -> ms, averaged
+        summary->avg_duration_neighborhood_ms = (double) s.ticks_neighborhood * per_iter;
+        summary->avg_duration_solve_ms = (double) s.ticks_solve * per_iter;
+        summary->avg_duration_iter_ms = (double) s.ticks_iter * per_iter;
+        summary->duration_init_ms = h->init_ms;
         summary->duration_total_ms =
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
         if (s.failed) {
@@ -1624,6 +1634,12 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
         float ms = 0.f;
         hipEventElapsedTime(&ms, h->ev_loop_start, h->ev_loop_stop);
         summary->duration_device_ms = ms;
+        // ICPSummary's timing fields (ct_icp.h:164-168), from the device's 100 MHz wall clock stamped by the kernels themselves
+        const double per_iter = s.iter > 0 ? 1e-5 / (double) s.iter : 0.0;                 // 10 ns ticks -> ms, averaged
+        summary->avg_duration_neighborhood_ms = (double) s.ticks_neighborhood * per_iter;
+        summary->avg_duration_solve_ms = (double) s.ticks_solve * per_iter;
+        summary->avg_duration_iter_ms = (double) s.ticks_iter * per_iter;
+        summary->duration_init_ms = h->init_ms;
         summary->duration_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (s.failed) {
             std::snprintf(summary->error_log, sizeof(summary->error_log),

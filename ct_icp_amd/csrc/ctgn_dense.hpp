@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64) void k_search_dense(MapView map, KpView kp, con
     constexpr int S = 2 * NB + 1, V = S * S * S;
     __shared__ DenseScratch<NB> D;
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int lane = threadIdx.x;
     const int k = prm.max_nb;
     const uint32_t blk = (uint32_t) map.blk, blk8 = blk * 8u, stride3 = 3u * blk8;

@@ -55,6 +55,7 @@ struct KpView {
     const uint32_t *order;   // k_accumulate_rows works on keypoint order[s] at position s (positions sorted by home voxel); nullptr = identity
     int chunk;               // rounds of a tile that take consecutive positions (>= 1)
     int xcd_split;           // 1: the blocks of XCD x (blockIdx % 8) work inside the x-th eighth of the tiles (needs gridDim >= 8)
+    unsigned long long *clk_iter_start;   // &GnState::clk_iter_start (the search kernels see the state read-only); nullptr = do not stamp
 };
 
 // working copy of the keypoint block in position order (ctgn_api.hip, order_keypoints): dst[a][pos] = src[a][order[pos]]
@@ -87,6 +88,10 @@ struct alignas(8) GnState {
     int failed;              // fewer than 100 keypoints contributed (ct_icp.cpp:860-871)
     int n_used;
     unsigned long long solve_cycles[4];   // shader clocks of the last k_reduce_solve: reduce | factorise | substitute | pose update
+    // ICPSummary's avg_duration_* (include/ct_icp/ct_icp.h:164-168) without extra launches or events: the constant 100 MHz
+    // wall clock (s_memrealtime) read by the first thread of the search kernel and at the start / end of the solve kernel
+    unsigned long long clk_iter_start;    // written by the neighbour-search kernel of the running iteration
+    unsigned long long ticks_neighborhood, ticks_solve, ticks_iter;   // sums over the executed iterations, 10 ns ticks
 };
 
 struct DebugView {
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
                                                                 double *partials, DebugView dbg, int first_iter) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int tid = threadIdx.x;
     const int k = prm.max_nb;
     double *d2s = reinterpret_cast<double *>(smem);                        // [k][LANE_BLOCK]
@@ -606,6 +612,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
     WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
     RowList &R = W.list[row];
@@ -1183,7 +1190,7 @@ __device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wa
 
 // normalise, motion prior, LDL^T, pose update, stop test (ct_icp.cpp:860-962, :978-980) by ONE wave on the packed system in S.sys
 __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const GnParams &prm, int min_used, int lane,
-                                            unsigned long long tc0) {
+                                            unsigned long long tc0, unsigned long long wall0) {
     double *s_sys = S.sys, *s_m = S.m, *s_temp = S.temp, *s_x = S.x, *s_b = S.b, *s_sc = S.sc, *s_q = S.q;
     int *s_perm = S.perm;
     const unsigned long long tc1 = __builtin_readcyclecounter();
@@ -1359,6 +1366,10 @@ __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const 
     if (nrm < prm.thr_norm) st->done = 1;                           // :978-980
     st->solve_cycles[0] = tc1 - tc0; st->solve_cycles[1] = tc2 - tc1; st->solve_cycles[2] = tc3 - tc2;
     st->solve_cycles[3] = __builtin_readcyclecounter() - tc3;
+    // search + residual of this iteration ran from clk_iter_start to this kernel's start; the solve from there to now
+    const unsigned long long wall1 = wall_clock64(), it0 = st->clk_iter_start;
+    if (it0 != 0ull && wall0 >= it0) { st->ticks_neighborhood += wall0 - it0; st->ticks_iter += wall1 - it0; }
+    st->ticks_solve += wall1 - wall0;
 }
 
 __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
@@ -1367,6 +1378,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tc0 = __builtin_readcyclecounter();
+    const unsigned long long wall0 = wall_clock64();
     if (mode != 2) {
         reduce_partials([&](int e, int b) { return *reinterpret_cast<const double2 *>(partials + (size_t) e * MAX_PARTIAL_BLOCKS + b); },
                         nblocks, wave, lane, sys, S.sys);
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
     }
     __syncthreads();
     if (mode == 1 || wave != 0) return;
-    solve_wave0(S, st, prm, min_used, lane, tc0);
+    solve_wave0(S, st, prm, min_used, lane, tc0, wall0);
 }
 
 #undef WSYNC
@@ -1432,6 +1444,7 @@ __global__ void k_state_init(GnState *st, const double *pose_in, double tb, doub
     for (int i = 0; i < 12; ++i) st->x[i] = 0.0;
     st->step_norm = 0.0;
     st->iter = 0; st->done = 0; st->failed = 0; st->n_used = 0;
+    st->clk_iter_start = 0ull; st->ticks_neighborhood = 0ull; st->ticks_solve = 0ull; st->ticks_iter = 0ull;
 }
 
 // ================================================================================================

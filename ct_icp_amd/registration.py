@@ -66,9 +66,9 @@ def _c_robust_prior(motion_model, continuous_time=True) -> L.RobustPrior | None:
 
 def _summary(s: L.Summary) -> ICPSummary:
     return ICPSummary(success=bool(s.success), num_residuals_used=s.num_residuals_used, num_iters=s.num_iters,
-                      error_log=s.error_log.decode(), duration_total=s.duration_total_ms * 1e-3,
-                      avg_duration_iter=(s.duration_device_ms * 1e-3 / s.num_iters) if s.num_iters else 0.0,
-                      last_step_norm=s.last_step_norm)
+                      error_log=s.error_log.decode(), duration_total=s.duration_total_ms, duration_init=s.duration_init_ms,
+                      avg_duration_iter=s.avg_duration_iter_ms, avg_duration_neighborhood=s.avg_duration_neighborhood_ms,
+                      avg_duration_solve=s.avg_duration_solve_ms, last_step_norm=s.last_step_norm)          # milliseconds, as ICPSummary
 
 
 class CT_ICP_Registration:

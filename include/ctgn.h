@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CTGN_ABI_VERSION 2
+#define CTGN_ABI_VERSION 3
 #define CTGN_MAX_RESOLUTIONS 8
 /* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
 #define CTGN_MIN_KEYPOINTS_USED 100
@@ -166,6 +166,15 @@ typedef struct {
     double duration_total_ms;            /* host wall time of the call                            */
     double duration_device_ms;           /* HIP-event time of the iteration loop                  */
     double last_step_norm;               /* ||x||_2 of the last solve                             */
+    /* ICPSummary::duration_init / avg_duration_neighborhood / avg_duration_solve / avg_duration_iter (ct_icp.h:164-168; the
+     * reference fills them on its CERES route, :670-672,688-691). Per executed iteration, from the device's constant 100 MHz
+     * clock stamped by the kernels themselves (no extra launches or events): neighbourhood = start of the neighbour-search
+     * kernel -> start of the solve kernel (search + normals + residuals + reduction), solve = the solve kernel, iter = both.
+     * The robust route reports the totals of its ICP iterations the same way through duration_device_ms only. */
+    double duration_init_ms;
+    double avg_duration_neighborhood_ms;
+    double avg_duration_solve_ms;
+    double avg_duration_iter_ms;
     char error_log[256];                 /* ICPSummary::error_log (same text as ct_icp.cpp:862-863) */
 } ctgn_summary;
 
