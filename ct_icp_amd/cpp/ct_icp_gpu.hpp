@@ -42,7 +42,7 @@ struct alignas(16) SE3 {
     double tr[3] = {0, 0, 0};
 };
 // slam::TPose<double> (types.h:161-167), the reference's member ORDER: pose, ref_timestamp, dest_timestamp, ref_frame_id, dest_frame_id
-// (frame_id_t = unsigned int, types.h:19). Same size and offsets as the reference's struct as compiled (oracle/_ref: ref_layout()).
+// (frame_id_t = unsigned int, types.h:19). Same size and offsets as the reference's struct as compiled (tests/test_oracle_vs_ref.py).
 struct Pose {
     SE3 pose;
     double ref_timestamp = 0.0;
