@@ -137,6 +137,7 @@ struct ctgn_context {
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
+    uint64_t skipped_points_total = 0;  // insert calls that met points outside the voxel key range / non-finite (skipped, inserted = 0)
     std::string last_error;
 };
 
@@ -288,8 +289,8 @@ ctgn_status sync_level(ctgn_handle h, int li) {
     DeviceLevel &D = h->dlevels[li];
     const size_t nslots = (size_t) L.mask + 1;
     const size_t nblk_doubles = (size_t) L.nblocks_cap * 3 * L.blk;
-    if ((size_t) L.nblocks_used * 3 * L.blk * sizeof(double) >= ((size_t) 1 << 32))
-        return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB (32-bit block offsets in the kernels)");
+    if ((size_t) L.nblocks_used * 3 * L.blk * sizeof(double) >= ((size_t) 1 << 32) || (size_t) L.nblocks_used >= ((size_t) 1 << 25))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB or 2^25 blocks (32-bit block offsets / packed block index in the kernels)");
     bool full = L.need_full_upload || !D.resident;
     if (!full && L.slot_edits.size() * 4 > nslots) full = true;
     if (full) {
@@ -356,8 +357,8 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     search_params(h->levels, radius, &map_id, &res, &nb);
     if (h->update_mode == 1) {
         const DevLevel &DL = h->devlevels[map_id];
-        if ((size_t) DL.host.next_block * 3 * DL.blk * sizeof(double) >= ((size_t) 1 << 32))
-            return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB (32-bit block offsets in the kernels)");
+        if ((size_t) DL.host.next_block * 3 * DL.blk * sizeof(double) >= ((size_t) 1 << 32) || (size_t) DL.host.next_block >= ((size_t) 1 << 25))
+            return fail(h, CTGN_ERR_UNSUPPORTED, "point blocks of one resolution exceed 4 GiB or 2^25 blocks (32-bit block offsets / packed block index in the kernels)");
         mv->slots = DL.slots;
         mv->blocks = DL.blocks;
         mv->mask = (uint32_t) (DL.slots_cap - 1);
@@ -817,8 +818,11 @@ static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t str
     }
     if (overflow) return fail(h, CTGN_ERR_HIP, "device map capacity exhausted (internal sizing error)");
     if (range_error) {
+        // the batch HAS been inserted (every in-range point) and `out` says 0 for the skipped ones: report it, do not fail the call —
+        // a caller that retried after an error would insert the batch twice
         for (auto &DL : h->devlevels) (void) hipMemsetAsync(&DL.counters->range_error, 0, sizeof(unsigned int), h->stream);
-        return fail(h, CTGN_ERR_VOXEL_RANGE, "a point fell outside the 21-bit voxel key range and was skipped");
+        h->skipped_points_total++;
+        h->last_error = "a point fell outside the 21-bit voxel key range (or was not finite) and was skipped";
     }
     return CTGN_OK;
 }
@@ -841,7 +845,10 @@ ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, 
         }
         if (out) out[i] = (uint8_t) any;
     }
-    if (range_error) return fail(h, CTGN_ERR_VOXEL_RANGE, "a point fell outside the 21-bit voxel key range and was skipped");
+    if (range_error) {                              // inserted = 0 for the skipped points; the map holds all the others: not an error
+        h->skipped_points_total++;
+        h->last_error = "a point fell outside the 21-bit voxel key range (or was not finite) and was skipped";
+    }
     return CTGN_OK;
 }
 

@@ -1398,7 +1398,10 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *part
 __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st, double *state_copy = nullptr) {
     if (state_copy && blockIdx.x == 0 && threadIdx.x < sizeof(GnState) / 8)
         state_copy[threadIdx.x] = reinterpret_cast<const double *>(st)[threadIdx.x];
-    if (st->failed || st->iter == 0) return;      // failure: world points stay as the failing iteration saw them
+    // Nothing solved yet: the world points stay as uploaded. A soft failure at iteration i >= 1 (ct_icp.cpp:860-871) returns the world
+    // points the failing iteration saw, T(pose after iteration i-1) raw — which is what this recomputes from the (unchanged) pose;
+    // in ordered mode the GN kernels wrote them to the position-ordered working copy, not here.
+    if (st->iter == 0) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp.n; i += gridDim.x * blockDim.x) {
         Vec3 raw{kp.rx[i], kp.ry[i], kp.rz[i]};
         double alpha = alpha_timestamp(kp.t[i], st->tbe[0], st->tbe[1]);

@@ -101,7 +101,9 @@ int32_t ctgn_abi_version(void);
 /* InsertPointCloud on world points (map.h:153-254 -> InsertPointInVoxelMap :261-293), applied to every
  * resolution. Points are read from a strided view (base + i*stride_bytes -> 3 x dtype).
  * out_inserted (optional, n bytes): 1 if the point was inserted in at least one resolution
- * (the reference's `selected_indices`, map.h:196-206). */
+ * (the reference's `selected_indices`, map.h:196-206). A point whose voxel coordinate does not fit the 21-bit key range, or that is
+ * not finite, is SKIPPED (out_inserted = 0) and the call still returns CTGN_OK with a note in ctgn_last_error: the rest of the batch
+ * is in the map, and an error return would invite a retry that inserts it twice (the reference has no such failure at all). */
 ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride_bytes, ctgn_dtype dtype,
                             size_t n, uint8_t *out_inserted);
 /* RemoveElementsFarFromLocation (map.h:305-322): drops a voxel iff its FIRST point is farther than

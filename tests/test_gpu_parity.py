@@ -1134,3 +1134,30 @@ def test_two_rank_sharded_registration_over_rccl(street_case, tmp_path):
     pose, summ, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=5, threshold_orientation_norm=0.0))
     assert int(p0[14]) == summ.num_residuals_used and int(p0[15]) == summ.num_iters
     assert np.abs(p0[:14] - pose).max() < 1e-12
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_soft_failure_at_a_later_iteration_returns_the_last_completed_state(box_case, ordering):
+    """ct_icp.cpp:860-871 at iteration i >= 1: the poses are those after iteration i - 1 and the world points the ones that iteration
+    wrote (:964-966). A constant-velocity prior with an absurd previous velocity throws the first update metres away, so the second
+    iteration finds fewer than 100 usable keypoints. Same answer in caller order, in home-voxel order (where the GN kernels iterate on
+    a position-ordered working copy) and from the oracle; the device-resident map path rides along."""
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.5)
+    mm = cia.PreviousFrameMotionModel(beta_location_consistency=1e6, beta_constant_velocity=1e6)
+    far = np.zeros(14); far[3] = far[10] = 1.0; far[11:14] = [40.0, 0.0, 0.0]
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(far, 0.0, 0.0)
+    op = orc.MotionPrior(beta_location_consistency=1e6, beta_constant_velocity=1e6, previous_begin_tr=far[4:7], previous_end_tr=far[11:14])
+    o = _opts(num_iters_icp=6, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_ordering(ordering)
+    s.set_keypoints(raw, world0, t)
+    pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o, mm)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
+    assert not so.success and so.num_iters == 2                              # the oracle fails in its third iteration, after two completed ones
+    assert not summ.success and summ.num_iters == so.num_iters and summ.num_residuals_used == so.num_residuals_used
+    assert summ.error_log == so.error_log
+    tr, rot = se3.pose_error(pose1, pose_o)
+    assert tr < 1e-5 and rot < 1e-6                                          # a 40 m jump through a 1e6-weighted prior: conditioning, not parity
+    assert np.abs(s.world_points() - world_o).max() < 1e-4
+    assert np.abs(s.world_points() - world0).max() > 10.0                    # not the uploaded points: the last completed iteration's

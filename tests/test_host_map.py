@@ -60,3 +60,22 @@ def test_eviction_tombstones_and_reuse(street_case):
     assert gm.NumPoints() == 0 and gm.NumVoxels(0) == 0
     gm.InsertPointCloud(street_case["scans"][0].world_gt[:100])
     assert gm.NumPoints() > 0
+
+
+def test_out_of_range_and_non_finite_points_are_skipped_not_fatal(box_case):
+    """ctgn_map_insert on a batch that contains points outside the 21-bit voxel key range (or NaN / inf): the in-range points are
+    inserted, the others report inserted = 0, the call returns CTGN_OK (a retry after an error would have inserted the batch twice)
+    and the map equals the oracle's map of the in-range points."""
+    gm, om = _pair([(0.5, 0.05, 20)], 0.8)
+    pts = box_case["scans"][0].world_gt[:3000].copy()
+    bad = np.array([10, 500, 1234, 2999])
+    ok = np.ones(len(pts), dtype=bool); ok[bad] = False
+    pts[10] = [3e9, 0.0, 0.0]
+    pts[500] = [np.nan, 1.0, 1.0]
+    pts[1234] = [0.0, -np.inf, 0.0]
+    pts[2999] = [0.0, 0.0, -7e8]
+    kept = gm.InsertPointCloud(pts)                      # must not raise
+    assert not kept[bad].any()
+    assert np.array_equal(kept[ok], om.insert(pts[ok]))
+    assert gm.NumPoints() == om.num_points()
+    assert np.array_equal(_sorted(gm.MapAsPointCloud(0)), _sorted(om.export(0)))
