@@ -83,6 +83,18 @@ class AdaptiveSamplingOptions(C.Structure):
                 ("reserved", C.c_int32), ("distance", C.c_double * 16), ("voxel_size", C.c_double * 16)]
 
 
+class FrameOptions(C.Structure):
+    _fields_ = [("frame_voxel_size", C.c_double), ("sample_voxel_size", C.c_double), ("max_num_keypoints", C.c_int32),
+                ("override_timestamps", C.c_int32), ("override_timestamp", C.c_double)]
+
+
+class FrameOutputs(C.Structure):
+    _fields_ = [("all_world_base", C.c_void_p), ("all_world_stride_bytes", C.c_size_t), ("all_world_dtype", C.c_int32),
+                ("_pad0", C.c_int32), ("sampled_indices", C.c_void_p), ("sampled_world_base", C.c_void_p),
+                ("sampled_world_stride_bytes", C.c_size_t), ("sampled_world_dtype", C.c_int32), ("_pad1", C.c_int32),
+                ("keypoint_indices", C.c_void_p), ("num_sampled", C.c_uint64), ("num_keypoints", C.c_uint64)]
+
+
 class View(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_bytes", C.c_size_t), ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
@@ -123,6 +135,14 @@ SYMBOLS = {
     "ctgn_transform_points": (C.c_int, [_H, View, View, C.c_size_t, _dp, _dp, C.c_void_p, C.c_size_t, C.c_int]),
     "ctgn_register": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,
                                 C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_frame_options_default": (None, [C.POINTER(FrameOptions)]),
+    "ctgn_frame_register": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
+                                      C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior),
+                                      C.POINTER(FrameOutputs), C.POINTER(Summary)]),
+    "ctgn_frame_update_map": (C.c_int, [_H, _dp, C.c_double, C.c_int32, C.c_void_p]),
+    "ctgn_frame": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
+                             C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.c_double,
+                             C.POINTER(FrameOutputs), C.POINTER(Summary)]),
     "ctgn_robust_options_default": (None, [C.POINTER(RobustOptions)]),
     "ctgn_solve_robust": (C.c_int, [_H, _dp, _dp, C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.POINTER(Summary)]),
     "ctgn_register_robust": (C.c_int, [_H, View, C.c_void_p, C.c_size_t, C.c_int, View, C.c_size_t, _dp, _dp,

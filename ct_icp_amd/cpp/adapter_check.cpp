@@ -80,6 +80,30 @@ int main() {
             std::printf("adapter-sampling %s grid=%zu adaptive=%zu undistort-err=%.1e\n", side_ok ? "ok" : "FAIL", sampled.size(),
                         adaptive.size(), dmax);
         }
+        // one whole frame with the scan resident on the device, on a device-maintained map built from the same points: it must agree
+        // with the stage-by-stage spelling above (same kernels, same inputs)
+        {
+            GpuVoxelMap dmap(mo);
+            if (ctgn_map_set_update_mode(dmap.handle(), 1) != CTGN_OK) { std::printf("adapter FAIL: update mode\n"); return 1; }
+            dmap.InsertPoints(pts.data(), pts.size() / 3);
+            TrajectoryFrame f3;
+            f3.begin_pose.dest_timestamp = 0.0;
+            f3.end_pose.dest_timestamp = 1.0;
+            FrameOptions fopt;
+            fopt.voxel_size = 0.0;                                // every point of `kps` stays ...
+            fopt.sample_voxel_size = 0.0;                         // ... and is a keypoint: the same registration as `s`
+            std::vector<WPoint3D> all, corrected;
+            std::vector<uint32_t> kp_idx;
+            CTICPOptions go = reg.Options();
+            ICPSummary s3 = RegisterFrame(dmap, go, fopt, kps, f3, nullptr, &all, &corrected, &kp_idx);
+            bool same = s3.success && s3.num_iters == s.num_iters && s3.num_residuals_used == s.num_residuals_used;
+            for (int c = 0; c < 3; ++c) same = same && f3.end_pose.pose.tr[c] == frame.end_pose.pose.tr[c];
+            const size_t before = dmap.NumPoints();
+            UpdateMapFromFrame(dmap, f3.end_pose.pose.tr, 100.0, true);
+            std::printf("adapter-frame %s sampled=%zu keypoints=%zu map_points %zu -> %zu\n", same ? "ok" : "FAIL", corrected.size(),
+                        kp_idx.size(), before, dmap.NumPoints());
+            side_ok = side_ok && same && all.size() == kps.size() && corrected.size() == kps.size() && dmap.NumPoints() >= before;
+        }
         // the `case CERES:` arm on the same map and keypoints
         TrajectoryFrame frame2;
         frame2.begin_pose.dest_timestamp = 0.0;

@@ -431,4 +431,106 @@ inline void TransformFrame(GpuVoxelMap &voxel_map, std::vector<WPoint3D> &frame,
     if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn: ") + ctgn_last_error(voxel_map.handle()));
 }
 
+// One frame of Odometry::DoRegister with the scan resident on the device (ctgn_frame_register / ctgn_frame_update_map, SURVEY.md
+// section 8f): InitializeFrame's sub_sample_frame + initial transform (src/ct_icp/odometry.cpp:333-382), TryRegister's grid_sampling +
+// Register (:526-590) and both undistortion loops (:461-486) in one call — `all_corrected_points` receives every scan point with its
+// world point, `corrected_points` the sampled frame, `keypoint_indices` the scan indices of the keypoints — then UpdateMap's evict +
+// insert (:936-952) from the device-resident corrected points, after the host has decided (add_points). The map must maintain itself
+// on the device: ctgn_map_set_update_mode(map.handle(), 1) right after construction. GN route (options.solver == GN).
+struct FrameOptions {
+    double voxel_size = 0.5;                 // OdometryOptions::voxel_size (sub_sample_frame)
+    double sample_voxel_size = 1.5;          // OdometryOptions::sample_voxel_size (grid_sampling); <= 0: sampling NONE
+    int max_num_keypoints = -1;
+    const std::vector<uint32_t> *order = nullptr;    // the caller's shuffle of the scan (odometry.cpp:349), or scan order
+};
+inline ICPSummary RegisterFrame(GpuVoxelMap &voxel_map, const CTICPOptions &options, const FrameOptions &frame_options,
+                                const std::vector<WPoint3D> &scan, TrajectoryFrame &trajectory_frame,
+                                const PreviousFrameMotionModel *motion_model, std::vector<WPoint3D> *all_corrected_points,
+                                std::vector<WPoint3D> *corrected_points, std::vector<uint32_t> *keypoint_indices) {
+    if (options.solver != GN) throw std::runtime_error("RegisterFrame: GN route only (use ctgn_frame_register for the robust route)");
+    ctgn_options o;
+    ctgn_options_default(&o);
+    o.num_iters_icp = options.num_iters_icp;
+    o.min_number_neighbors = options.min_number_neighbors;
+    o.max_number_neighbors = options.max_number_neighbors;
+    o.debug_print = options.debug_print ? 1 : 0;
+    o.max_dist_to_plane_ct_icp = options.max_dist_to_plane_ct_icp;
+    o.threshold_orientation_norm = options.threshold_orientation_norm;
+    ctgn_motion_prior prior, *pp = nullptr;
+    if (motion_model) {
+        prior.beta_location_consistency = motion_model->options.beta_location_consistency;
+        prior.beta_constant_velocity = motion_model->options.beta_constant_velocity;
+        std::memcpy(prior.previous_begin_tr, motion_model->PreviousFrame().BeginTr(), 24);
+        std::memcpy(prior.previous_end_tr, motion_model->PreviousFrame().EndTr(), 24);
+        pp = &prior;
+    }
+    ctgn_frame_options fo;
+    ctgn_frame_options_default(&fo);
+    fo.frame_voxel_size = frame_options.voxel_size;
+    fo.sample_voxel_size = frame_options.sample_voxel_size;
+    fo.max_num_keypoints = frame_options.max_num_keypoints;
+    double pose[14];
+    std::memcpy(pose, trajectory_frame.begin_pose.pose.quat, 32);
+    std::memcpy(pose + 4, trajectory_frame.begin_pose.pose.tr, 24);
+    std::memcpy(pose + 7, trajectory_frame.end_pose.pose.quat, 32);
+    std::memcpy(pose + 11, trajectory_frame.end_pose.pose.tr, 24);
+    const double tbe[2] = {trajectory_frame.begin_pose.dest_timestamp, trajectory_frame.end_pose.dest_timestamp};
+    const size_t n = scan.size();
+    WPoint3D dummy{};
+    const WPoint3D *base = n ? scan.data() : &dummy;
+    ctgn_view raw{base->raw_point, sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_view ts{&base->timestamp, sizeof(WPoint3D), CTGN_F64, 0};
+    ctgn_frame_outputs fout{};
+    std::vector<uint32_t> sampled(n), kps(n);
+    std::vector<double> sampled_world(3 * n);
+    if (all_corrected_points) {
+        *all_corrected_points = scan;                                        // raw point, timestamp, index_frame (odometry.cpp:472-476)
+        fout.all_world_base = n ? (*all_corrected_points)[0].world_point : nullptr;
+        fout.all_world_stride_bytes = sizeof(WPoint3D);
+        fout.all_world_dtype = CTGN_F64;
+    }
+    fout.sampled_indices = sampled.data();
+    fout.keypoint_indices = kps.data();
+    fout.sampled_world_base = sampled_world.data();
+    fout.sampled_world_stride_bytes = 24;
+    fout.sampled_world_dtype = CTGN_F64;
+    ctgn_summary s;
+    const ctgn_status st = ctgn_frame_register(voxel_map.handle(), raw, ts, n, frame_options.order ? frame_options.order->data() : nullptr, &fo,
+                                               pose, tbe, &o, pp, nullptr, nullptr, &fout, &s);
+    ICPSummary out;
+    if (st != CTGN_OK) {
+        out.success = false;
+        out.error_log = ctgn_last_error(voxel_map.handle());
+        return out;
+    }
+    std::memcpy(trajectory_frame.begin_pose.pose.quat, pose, 32);
+    std::memcpy(trajectory_frame.begin_pose.pose.tr, pose + 4, 24);
+    std::memcpy(trajectory_frame.end_pose.pose.quat, pose + 7, 32);
+    std::memcpy(trajectory_frame.end_pose.pose.tr, pose + 11, 24);
+    if (corrected_points) {
+        corrected_points->resize(fout.num_sampled);
+        for (size_t k = 0; k < fout.num_sampled; ++k) {
+            (*corrected_points)[k] = scan[sampled[k]];
+            std::memcpy((*corrected_points)[k].world_point, &sampled_world[3 * k], 24);
+        }
+    }
+    if (keypoint_indices) keypoint_indices->assign(kps.begin(), kps.begin() + fout.num_keypoints);
+    out.success = s.success != 0;
+    out.num_residuals_used = s.num_residuals_used;
+    out.num_iters = s.num_iters;
+    out.error_log = s.error_log;
+    out.duration_total = s.duration_total_ms;
+    out.duration_init = s.duration_init_ms;
+    out.avg_duration_iter = s.avg_duration_iter_ms;
+    out.avg_duration_neighborhood = s.avg_duration_neighborhood_ms;
+    out.avg_duration_solve = s.avg_duration_solve_ms;
+    return out;
+}
+
+// Odometry::UpdateMap's map part for the frame RegisterFrame left on the device (odometry.cpp:936-952)
+inline void UpdateMapFromFrame(GpuVoxelMap &voxel_map, const double location[3], double max_distance, bool add_points) {
+    const ctgn_status st = ctgn_frame_update_map(voxel_map.handle(), location, max_distance, add_points ? 1 : 0, nullptr);
+    if (st != CTGN_OK) throw std::runtime_error(std::string("ctgn: ") + ctgn_last_error(voxel_map.handle()));
+}
+
 }  // namespace ct_icp_gpu

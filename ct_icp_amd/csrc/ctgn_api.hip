@@ -133,6 +133,22 @@ struct ctgn_context {
     ncclComm_t comm = nullptr;
     int dist_rank = 0, dist_world = 1;
 
+    // frame pipeline (ctgn_frame_register / ctgn_frame_update_map): the scan and its undistorted images stay on the device
+    struct FrameScratch {
+        double *d_scan = nullptr;       // 16 doubles: the initial pose, then n records x y z t in processing order
+        double *d_world = nullptr;      // [3][stride] every point undistorted with the final poses
+        double *d_corr = nullptr;       // [3][stride] the sampled frame undistorted (compact: num_sampled points)
+        uint8_t *d_flag1 = nullptr, *d_flag2 = nullptr;
+        uint32_t *d_sel1 = nullptr, *d_sel2 = nullptr;
+        int *d_counts = nullptr;
+        double *h_scan = nullptr;       // pinned, same layout
+        double *h_out = nullptr;        // pinned [6][cap]: world | corrected
+        uint32_t *h_sel = nullptr;      // pinned [2][cap]
+        int *h_counts = nullptr;        // pinned
+        size_t cap = 0, stride = 0, n = 0, n1 = 0, n2 = 0;
+        bool valid = false;             // a registered frame is resident (ctgn_frame_update_map may insert it)
+    } fr;
+
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
@@ -736,6 +752,23 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
     return CTGN_OK;
 }
 
+static void frame_scratch_free(ctgn_handle h) {
+    auto &F = h->fr;
+    if (F.d_scan) hipFree(F.d_scan);
+    if (F.d_world) hipFree(F.d_world);
+    if (F.d_corr) hipFree(F.d_corr);
+    if (F.d_flag1) hipFree(F.d_flag1);
+    if (F.d_flag2) hipFree(F.d_flag2);
+    if (F.d_sel1) hipFree(F.d_sel1);
+    if (F.d_sel2) hipFree(F.d_sel2);
+    if (F.d_counts) hipFree(F.d_counts);
+    if (F.h_scan) hipHostFree(F.h_scan);
+    if (F.h_out) hipHostFree(F.h_out);
+    if (F.h_sel) hipHostFree(F.h_sel);
+    if (F.h_counts) hipHostFree(F.h_counts);
+    F = ctgn_context::FrameScratch{};
+}
+
 void ctgn_destroy(ctgn_handle h) {
     if (!h) return;
     if (h->device >= 0) {
@@ -767,6 +800,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_nnb) { hipFree(h->d_nnb); hipFree(h->d_normal); hipFree(h->d_a2d); hipFree(h->d_far); hipFree(h->d_used); }
         if (h->d_edit) hipFree(h->d_edit);
         if (h->h_edit) hipHostFree(h->h_edit);
+        frame_scratch_free(h);
         for (auto &e : h->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
         if (h->ev_loop_start) hipEventDestroy(h->ev_loop_start);
         if (h->ev_loop_stop) hipEventDestroy(h->ev_loop_stop);
@@ -791,16 +825,22 @@ ctgn_status ctgn_map_set_update_mode(ctgn_handle h, int32_t device_updates) {
     return CTGN_OK;
 }
 
+static ctgn_status devmap_insert_staged(ctgn_handle h, size_t n, uint8_t *out);
 static ctgn_status devmap_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
     if (n == 0) return CTGN_OK;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_scratch_reserve(h->dm, n));
-    DevMapScratch &S = h->dm;
     {
         ctgn_status gs = stage_batch(h, xyz_base, stride, dt, n);
         if (gs != CTGN_OK) return gs;
     }
+    return devmap_insert_staged(h, n, out);
+}
+
+// the batch is in h->dm.pts (stride h->dm.stride): insert into every level, copy the `inserted` mask out
+static ctgn_status devmap_insert_staged(ctgn_handle h, size_t n, uint8_t *out) {
+    DevMapScratch &S = h->dm;
     HIPCHK(h, hipMemsetAsync(S.inserted, 0, n, h->stream));
     bool range_error = false, overflow = false;
     for (auto &DL : h->devlevels) {                      // map.h:199-205: every resolution
@@ -956,14 +996,8 @@ ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries, size_t 
 }
 
 // ---------------------------------------------------------------------------------------- keypoints
-ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n) {
-    NEED_DEVICE(h);
-    if (n > 0 && (!raw.base || !world.base || !ts.base)) return CTGN_ERR_INVALID_ARGUMENT;
-    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
-    h->pose_on_device = false;
-    const bool dev = n > 0 && on_device(raw.base);
-    if (n > 0 && (on_device(world.base) != dev || on_device(ts.base) != dev))
-        return fail(h, CTGN_ERR_UNSUPPORTED, "the raw, world and timestamp views must all be host memory or all be device memory");
+// (re)size the keypoint arrays for n keypoints and reset the per-upload state
+static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
     if ((int) n > h->cap_kp) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_kp) HIPCHK(h, hipFree(h->d_kp));
@@ -982,6 +1016,21 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
     h->kp_stride = (int) std::min<size_t>((n + 63) & ~(size_t) 63, (size_t) h->cap_kp);
     if (n >= 32768 && h->ordering_mode != 0) {       // this upload may be ordered (want_order): have the buffers ready
         ctgn_status rs = order_reserve(h);
+        if (rs != CTGN_OK) return rs;
+    }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n) {
+    NEED_DEVICE(h);
+    if (n > 0 && (!raw.base || !world.base || !ts.base)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
+    h->pose_on_device = false;
+    const bool dev = n > 0 && on_device(raw.base);
+    if (n > 0 && (on_device(world.base) != dev || on_device(ts.base) != dev))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the raw, world and timestamp views must all be host memory or all be device memory");
+    {
+        ctgn_status rs = reserve_keypoints(h, n);
         if (rs != CTGN_OK) return rs;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));      // staging reuse
@@ -1175,6 +1224,7 @@ ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done) {
     return CTGN_OK;
 }
 
+static ctgn_status gn_collect(ctgn_handle h, double pose_out[14], ctgn_summary *summary);
 ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summary) {
     NEED_DEVICE(h);
     if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
@@ -1194,8 +1244,13 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
         if (h->prefetch_world) { ctgn_status ws = enqueue_world_readback(h); if (ws != CTGN_OK) return ws; }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->gn_active = false;
     if (merged) std::memcpy(h->h_state, h->h_kp + 7 * c + 16, sizeof(GnState));
+    return gn_collect(h, pose_out, summary);
+}
+
+// after the final state has arrived in h->h_state: pose + ICPSummary
+static ctgn_status gn_collect(ctgn_handle h, double pose_out[14], ctgn_summary *summary) {
+    h->gn_active = false;
     const GnState &s = *h->h_state;
     if (h->profiling) harvest_events(h, s.iter + (s.failed ? 1 : 0));
     if (h->gn_opts.debug_print > 1)
@@ -1478,6 +1533,268 @@ ctgn_status ctgn_register(ctgn_handle h, ctgn_view raw, void *world_base, size_t
     return CTGN_OK;
 }
 
+
+
+/* -------------------------------------------------------------------------------------------------
+ * Frame pipeline: scan resident on the device from the samplers to the map update
+ * ---------------------------------------------------------------------------------------------- */
+void ctgn_frame_options_default(ctgn_frame_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->frame_voxel_size = 0.5;               // OdometryOptions::voxel_size (odometry.h)
+    o->sample_voxel_size = 1.5;              // OdometryOptions::sample_voxel_size
+    o->max_num_keypoints = -1;
+}
+
+static ctgn_status frame_reserve(ctgn_handle h, size_t n) {
+    auto &F = h->fr;
+    if (n <= F.cap) return CTGN_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    frame_scratch_free(h);
+    const size_t cap = ((n + n / 4 + 1024) + 63) & ~(size_t) 63;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_scan), (4 * cap + 16) * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_world), 3 * cap * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_corr), 3 * cap * sizeof(double)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_flag1), cap));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_flag2), cap));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_sel1), cap * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_sel2), cap * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_counts), 2 * sizeof(int)));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_scan), (4 * cap + 16) * sizeof(double), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_out), 6 * cap * sizeof(double), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_sel), 2 * cap * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_counts), 2 * sizeof(int), hipHostMallocDefault));
+    F.cap = cap;
+    return CTGN_OK;
+}
+
+static void write_point(void *base, size_t stride, ctgn_dtype dt, size_t i, double x, double y, double z) {
+    char *p = static_cast<char *>(base) + i * stride;
+    if (dt == CTGN_F64) { double *q = reinterpret_cast<double *>(p); q[0] = x; q[1] = y; q[2] = z; }
+    else { float *q = reinterpret_cast<float *>(p); q[0] = (float) x; q[1] = (float) y; q[2] = (float) z; }
+}
+
+ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                ctgn_frame_outputs *out, ctgn_summary *summary) {
+    NEED_DEVICE(h);
+    if (summary) std::memset(summary, 0, sizeof(*summary));
+    if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
+    if (!fo || !pose_io || !tbe || (!opts && !robust)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    if (n && (on_device(raw.base) || on_device(ts.base)))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_register takes host views (the stage entry points accept device memory)");
+    const auto t_call = std::chrono::steady_clock::now();
+    // CTGN_FRAME_TIMING=1: host-clock marks of the call's phases on stderr (measurement hook; no extra synchronisation)
+    static const bool timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;
+    double marks[8] = {0};
+    auto mark = [&](int k) { if (timing) marks[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
+    auto &F = h->fr;
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // pinned staging reuse
+    {
+        ctgn_status rs = frame_reserve(h, n);
+        if (rs != CTGN_OK) return rs;
+        DMCHK(h, devmap_scratch_reserve(h->dm, std::max<size_t>(n, 1)));
+    }
+    // ---- stage: caller's records -> x y z t records in processing order behind the pose, uploaded chunk by chunk while the next
+    // chunk is being staged
+    const size_t c = std::min((n + 63) & ~(size_t) 63, F.cap);                      // plane stride of the undistorted outputs
+    F.valid = false;
+    F.stride = c; F.n = n; F.n1 = 0; F.n2 = 0;
+    for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];
+    double *hs = F.h_scan + 16;
+    const double *d_recs = F.d_scan + 16;
+    double tmin = INFINITY, tmax = -INFINITY;
+    constexpr size_t CHUNK = 32768;
+    const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
+    const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
+    for (size_t j0 = 0; j0 < n || j0 == 0; j0 += CHUNK) {
+        const size_t j1 = std::min(n, j0 + CHUNK);
+        for (size_t j = j0; j < j1; ++j) {
+            const size_t i = order ? (size_t) order[j] : j;
+            if (i >= n) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
+            double *q = hs + 4 * j;
+            if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            const double t = fo->override_timestamps ? fo->override_timestamp
+                             : tf64 ? *reinterpret_cast<const double *>(tb_ + i * ts.stride_bytes)
+                                    : (double) *reinterpret_cast<const float *>(tb_ + i * ts.stride_bytes);
+            q[3] = t;
+            tmin = t < tmin ? t : tmin;
+            tmax = t > tmax ? t : tmax;
+            if (t != t) tmax = NAN;
+        }
+        const size_t lo = j0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first chunk carries the pose
+        HIPCHK(h, hipMemcpyAsync(F.d_scan + lo, F.h_scan + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (j1 >= n) break;
+    }
+    // every point is undistorted below: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
+    if (n && !(tbe[0] <= tmin && tmax <= tbe[1])) {
+        hipStreamSynchronize(h->stream);
+        return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+    }
+    mark(0);                                          // staged + upload enqueued
+    // ---- both samplers, then the one read-back that sizes the launches
+    DMCHK(h, devmap_frame_sampling(h->dm, d_recs, 1, 4, n, fo->frame_voxel_size, fo->sample_voxel_size, F.d_flag1, F.d_flag2, F.d_sel1, F.d_sel2,
+                                   F.d_counts, h->stream));
+    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    mark(1);                                          // samplers enqueued
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    mark(2);                                          // counts on the host
+    const size_t n1 = (size_t) F.h_counts[0];
+    size_t n2 = (size_t) F.h_counts[1];
+    if (fo->max_num_keypoints > 0 && n2 > (size_t) fo->max_num_keypoints) n2 = (size_t) fo->max_num_keypoints;
+    F.n1 = n1; F.n2 = n2;
+    // ---- keypoints: gathered into the solver's arrays, world points from the initial estimate (odometry.cpp:374-378)
+    h->pose_on_device = false;
+    {
+        ctgn_status rs = reserve_keypoints(h, n2);
+        if (rs != CTGN_OK) return rs;
+    }
+    const size_t kc = (size_t) h->kp_stride;
+    if (n2) {
+        hipLaunchKernelGGL(k_frame_keypoints, dim3(grid_for(n2)), dim3(256), 0, h->stream, d_recs, F.d_sel2, (int) n2, h->d_kp, kc);
+        hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n2)), dim3(256), 0, h->stream, h->d_kp, h->d_kp + 4 * kc, (int) n2, kc,
+                           F.d_scan, tbe[0], tbe[1]);
+        HIPCHK(h, hipGetLastError());
+    }
+    h->t_min = tmin; h->t_max = tmax;
+    h->kp_coherent = false;
+    if (n2 >= 32768) {
+        // spatial coherence of the keypoint order (see ctgn_set_keypoints), probed on the staged raw points — a rigid motion keeps
+        // neighbours neighbours: pairs one keypoint spacing apart in processing order
+        int map_id, nb;
+        double res;
+        search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
+        const size_t gap = std::max<size_t>(1, n / n2), step = std::max<size_t>(1, (n - gap) / 4096);
+        size_t pairs = 0, near = 0;
+        for (size_t i = 0; i + gap < n; i += step, ++pairs) {
+            bool ok = true;
+            for (int a = 0; a < 3 && ok; ++a)
+                ok = std::abs(voxel_coord(hs[4 * i + a], res) - voxel_coord(hs[4 * (i + gap) + a], res)) <= 1;
+            near += ok ? 1 : 0;
+        }
+        h->kp_coherent = pairs > 0 && 2 * near >= pairs;
+    }
+    {
+        ctgn_status ds = ensure_debug(h);
+        if (ds != CTGN_OK) return ds;
+    }
+    // ---- registration
+    ctgn_status st;
+    if (robust) {
+        st = ctgn_solve_robust(h, pose_io, tbe, robust, robust_prior, summary);      // host-driven LM loop; the final pose stays in d_state
+        if (st != CTGN_OK) return st;
+    } else {
+        st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
+        MapView mv;
+        if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
+        for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {           // ct_icp.cpp:745
+            st = launch_accumulate(h, mv, it == 0);
+            if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
+        }
+        if (st != CTGN_OK) {
+            h->gn_active = false;
+            hipStreamSynchronize(h->stream);
+            if (summary) std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", ctgn_last_error(h));
+            return st;
+        }
+        HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    }
+    mark(3);                                          // registration enqueued (GN) / done (robust)
+    // ---- undistortion with the device's own copy of the final poses (odometry.cpp:461-486): the sampled frame (the map update's
+    // input) always, every scan point when asked for
+    const double *d_pose = reinterpret_cast<const double *>(reinterpret_cast<const char *>(h->d_state) + offsetof(GnState, pose));
+    const bool want_all = out && out->all_world_base && n;
+    if (n1) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, d_recs, F.d_corr, (int) n1, (size_t) 1, d_pose,
+                               tbe[0], tbe[1], F.d_sel1, c, (size_t) 4);
+    if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1, d_pose,
+                                     tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4);
+    HIPCHK(h, hipGetLastError());
+    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (out && out->sampled_world_base && n1)
+        HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (out && out->sampled_indices && n1)
+        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out && out->keypoint_indices && n2)
+        HIPCHK(h, hipMemcpyAsync(F.h_sel + c, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    mark(4);                                          // undistortion + read-backs enqueued
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    mark(5);                                          // everything on the host
+    if (!robust) {
+        st = gn_collect(h, pose_io, summary);
+        if (st != CTGN_OK) return st;
+    }
+    if (summary) summary->duration_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    if (out) {
+        out->num_sampled = n1;
+        out->num_keypoints = n2;
+        if (want_all)
+            for (size_t j = 0; j < n; ++j)
+                write_point(out->all_world_base, out->all_world_stride_bytes, out->all_world_dtype, order ? (size_t) order[j] : j, F.h_out[j],
+                            F.h_out[c + j], F.h_out[2 * c + j]);
+        if (out->sampled_world_base)
+            for (size_t k = 0; k < n1; ++k)
+                write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
+                            F.h_out[4 * c + k], F.h_out[5 * c + k]);
+        if (out->sampled_indices)
+            for (size_t k = 0; k < n1; ++k) out->sampled_indices[k] = order ? order[F.h_sel[k]] : F.h_sel[k];
+        if (out->keypoint_indices)
+            for (size_t k = 0; k < n2; ++k) out->keypoint_indices[k] = order ? order[F.h_sel[c + k]] : F.h_sel[c + k];
+    }
+    F.valid = true;
+    if (timing) {
+        mark(6);
+        std::fprintf(stderr, "[ctgn] frame_register us: stage+upload enqueue %.0f | enqueue samplers %.0f | wait counts %.0f | keypoints+registration "
+                             "enqueue %.0f | undistort enqueue %.0f | wait %.0f | scatter outputs %.0f | total %.0f (n %zu, sampled %zu, "
+                             "keypoints %zu)\n", marks[0], marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3],
+                     marks[5] - marks[4], marks[6] - marks[5], marks[6], n, n1, n2);
+    }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_frame_update_map(ctgn_handle h, const double location[3], double max_distance, int32_t add_points, uint8_t *inserted) {
+    NEED_DEVICE(h);
+    if (!location) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->update_mode != 1)
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the frame pipeline updates the device-resident map (ctgn_map_set_update_mode(h, 1))");
+    auto &F = h->fr;
+    if (add_points && !F.valid) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no registered frame is resident (ctgn_frame_register)");
+    static const bool timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto &DL : h->devlevels) DMCHK(h, devmap_level_remove_far(DL, location, max_distance, h->stream));   // odometry.cpp:938-940
+    const auto t1 = std::chrono::steady_clock::now();
+    if (!add_points || F.n1 == 0) return CTGN_OK;
+    DMCHK(h, devmap_scratch_reserve(h->dm, F.n1));
+    DevMapScratch &S = h->dm;
+    double *own_pts = S.pts;
+    const size_t own_stride = S.stride;
+    S.pts = F.d_corr;                                  // the undistorted sampled frame is the batch: nothing is copied
+    S.stride = F.stride;
+    const ctgn_status st = devmap_insert_staged(h, F.n1, inserted);                    // odometry.cpp:943-949
+    S.pts = own_pts;
+    S.stride = own_stride;
+    if (timing)
+        std::fprintf(stderr, "[ctgn] frame_update_map us: evict %.0f | insert %.0f\n", std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
+    return st;
+}
+
+ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
+                       double pose_io[14], const double tbe[2], const ctgn_options *opts, const ctgn_motion_prior *prior,
+                       const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior, double max_distance,
+                       ctgn_frame_outputs *out, ctgn_summary *summary) {
+    ctgn_summary local;
+    if (!summary) summary = &local;
+    if (h && h->update_mode != 1)
+        return fail(h, CTGN_ERR_UNSUPPORTED, "the frame pipeline updates the device-resident map (ctgn_map_set_update_mode(h, 1))");
+    ctgn_status st = ctgn_frame_register(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary);
+    if (st != CTGN_OK) return st;
+    return ctgn_frame_update_map(h, pose_io + 11, max_distance, summary->success, nullptr);
+}
 
 // ---------------------------------------------------------------------------------------- robust-loss route
 void ctgn_robust_options_default(ctgn_robust_options *o) {

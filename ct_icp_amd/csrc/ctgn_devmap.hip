@@ -111,10 +111,25 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
 
 // RemoveElementsFarFromLocation (map.h:305-322): voxel removed iff ||first point - location|| > distance.
 __global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *blocks, int blk, uint32_t *free_list, DevCounters *cnt,
-                                double lx, double ly, double lz, double distance) {
+                                double lx, double ly, double lz, double distance, double resolution) {
     for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         const Slot s = slots[i];
         if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
+        // The voxel's own coordinates bound its first point: int(p / res) == v puts p inside [(v - 1) res, (v + 1) res] on every axis
+        // (truncation toward zero makes voxel 0 two cells wide; the one-cell margin also swallows the rounding of the division). A
+        // voxel whose whole box is nearer than `distance` stays without its block being read — all but a thin shell of a map that is
+        // trimmed every frame; the decision for the shell (and for far voxels) is the reference's, on the point itself.
+        {
+            double far2 = 0.0;
+            const double l[3] = {lx, ly, lz};
+            for (int a = 0; a < 3; ++a) {
+                const int v = (int) ((s.key >> (21 * a)) & 0x1FFFFFu) - COORD_BIAS;
+                const double lo = (double) (v - 1) * resolution - l[a], hi = (double) (v + 1) * resolution - l[a];
+                const double m = fmax(fabs(lo), fabs(hi));
+                far2 += m * m;
+            }
+            if (sqrt(far2) * (1.0 + 1e-9) < distance) continue;
+        }
         const double *bx = blocks + (size_t) s.block * 3 * blk;
         const double dx = bx[0] - lx, dy = bx[blk] - ly, dz = bx[2 * blk] - lz;
         if (sqrt(sq_norm3(dx, dy, dz)) > distance) {
@@ -149,12 +164,15 @@ __global__ void k_dm_rehash(const Slot *old_slots, uint64_t old_n, Slot *slots, 
 // with atomicMin; a point survives iff it is the smallest index of its voxel, i.e. the first one the reference's loop inserts
 // (ct_icp.cpp:73-75). Integer atomics only: the result does not depend on the execution order.
 constexpr unsigned long long GS_EMPTY = ~0ull;
+// Point i's coordinate a is pts[i * es + a * cap]: planes `cap` apart (es = 1) or x y z t records (es = 4, cap = 1).
 __global__ void k_gs_hash(const double *pts, size_t cap, size_t n, double voxel_size, unsigned long long *tkeys, uint32_t *tfirst,
-                          uint32_t mask, uint32_t *slot_of) {
+                          uint32_t mask, uint32_t *slot_of, const uint8_t *active, size_t es = 1) {
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint16_t vx = (uint16_t) (short) (int) (pts[i] / voxel_size), vy = (uint16_t) (short) (int) (pts[cap + i] / voxel_size),
-                   vz = (uint16_t) (short) (int) (pts[2 * cap + i] / voxel_size);
+    if (active && !active[i]) return;                 // second-level sampling: only the points the first level kept take part
+    const double *p = pts + i * es;
+    const uint16_t vx = (uint16_t) (short) (int) (p[0] / voxel_size), vy = (uint16_t) (short) (int) (p[cap] / voxel_size),
+                   vz = (uint16_t) (short) (int) (p[2 * cap] / voxel_size);
     const unsigned long long key = (unsigned long long) vx | ((unsigned long long) vy << 16) | ((unsigned long long) vz << 32);
     unsigned long long hsh = key * 0x9E3779B97F4A7C15ull;
     uint32_t s = (uint32_t) (hsh >> 32) & mask;
@@ -164,12 +182,63 @@ __global__ void k_gs_hash(const double *pts, size_t cap, size_t n, double voxel_
         if (cur == GS_EMPTY || cur == key) break;
         s = (s + 1) & mask;
     }
-    atomicMin(&tfirst[s], (uint32_t) i);
+    // a scan puts ~17 points into a frame voxel: once a smaller index sits in the slot the atomic is skipped (the value only falls)
+    if (*reinterpret_cast<volatile uint32_t *>(&tfirst[s]) > (uint32_t) i) atomicMin(&tfirst[s], (uint32_t) i);
     slot_of[i] = s;
 }
-__global__ void k_gs_first_flags(const uint32_t *tfirst, const uint32_t *slot_of, size_t n, uint8_t *flags) {
+
+// both levels' tables in one launch
+__global__ void k_gs_clear(unsigned long long *tkeys, uint32_t *tfirst, size_t nslots) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < nslots; i += (size_t) gridDim.x * blockDim.x) {
+        tkeys[i] = GS_EMPTY;
+        tfirst[i] = 0xFFFFFFFFu;
+    }
+}
+
+// flags of one level + how many of them each 256-point block holds (the compaction's input). tfirst == nullptr: every (active) point.
+__global__ __launch_bounds__(256) void k_gs_flags_count(const uint32_t *tfirst, const uint32_t *slot_of, size_t n, uint8_t *flags,
+                                                        const uint8_t *active, uint32_t *block_counts) {
+    __shared__ uint32_t s_cnt[4];
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = tfirst[slot_of[i]] == (uint32_t) i ? 1 : 0;
+    bool f = false;
+    if (i < n) {
+        f = (!active || active[i]) && (!tfirst || tfirst[slot_of[i]] == (uint32_t) i);
+        flags[i] = f ? 1 : 0;
+    }
+    const uint32_t c = (uint32_t) __popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Ordered compaction of two flag arrays at once: sel_a / sel_b receive the ascending indices whose flag is set, totals[0 / 1] the
+// counts. Every block adds up the counts of the blocks before it (a few hundred values out of L2) instead of waiting on a scan.
+__global__ __launch_bounds__(256) void k_gs_compact2(const uint8_t *flag_a, const uint8_t *flag_b, const uint32_t *counts_a,
+                                                     const uint32_t *counts_b, size_t n, uint32_t *sel_a, uint32_t *sel_b, int *totals) {
+    __shared__ uint32_t s_red[2][4], s_wave[2][4];
+    uint32_t pa = 0, pb = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) { pa += counts_a[b]; pb += counts_b[b]; }
+    for (int d = 32; d >= 1; d >>= 1) { pa += __shfl_xor(pa, d); pb += __shfl_xor(pb, d); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_red[0][wave] = pa; s_red[1][wave] = pb; }
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    const bool fa = i < n && flag_a[i], fb = i < n && flag_b[i];
+    const unsigned long long ma = __ballot(fa), mb = __ballot(fb);
+    if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(ma); s_wave[1][wave] = (uint32_t) __popcll(mb); }
+    __syncthreads();
+    uint32_t base_a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3], base_b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    for (int w = 0; w < wave; ++w) { base_a += s_wave[0][w]; base_b += s_wave[1][w]; }
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (fa) sel_a[base_a + (uint32_t) __popcll(ma & below)] = (uint32_t) i;
+    if (fb) sel_b[base_b + (uint32_t) __popcll(mb & below)] = (uint32_t) i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {     // the last thread of the last block sees both totals
+        totals[0] = (int) (base_a + (uint32_t) __popcll(ma & below) + (fa ? 1u : 0u));
+        totals[1] = (int) (base_b + (uint32_t) __popcll(mb & below) + (fb ? 1u : 0u));
+    }
+}
+__global__ void k_gs_first_flags(const uint32_t *tfirst, const uint32_t *slot_of, size_t n, uint8_t *flags, const uint8_t *active) {
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = ((!active || active[i]) && tfirst[slot_of[i]] == (uint32_t) i) ? 1 : 0;
 }
 
 // Adaptive sampling keys (sampling.h:65-79): band from the range |p| (std::lower_bound on the distance list, minus one),
@@ -276,6 +345,7 @@ hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n) {
     DM_CHK(hipHostMalloc(reinterpret_cast<void **>(&S.h_count), sizeof(int), hipHostMallocDefault));
     size_t gs_cap = 1024;
     while (gs_cap < 2 * cap) gs_cap <<= 1;
+    gs_cap *= 2;                                     // two tables: both sampling levels of a frame (devmap_frame_sampling)
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_keys), gs_cap * sizeof(unsigned long long)));
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_first), gs_cap * sizeof(uint32_t)));
     S.gs_cap = gs_cap;
@@ -373,8 +443,8 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
     DM_CHK(hipMemsetAsync(S.gs_keys, 0xFF, tcap * sizeof(unsigned long long), stream));
     DM_CHK(hipMemsetAsync(S.gs_first, 0xFF, tcap * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, voxel_size, S.gs_keys, S.gs_first, (uint32_t) (tcap - 1),
-                       S.idx);
-    hipLaunchKernelGGL(k_gs_first_flags, dim3(grid), dim3(256), 0, stream, S.gs_first, S.idx, n, S.inserted);
+                       S.idx, (const uint8_t *) nullptr);
+    hipLaunchKernelGGL(k_gs_first_flags, dim3(grid), dim3(256), 0, stream, S.gs_first, S.idx, n, S.inserted, (const uint8_t *) nullptr);
     DM_CHK(hipGetLastError());
     size_t tmp = S.cub_temp_bytes;
     DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, hipcub::CountingInputIterator<uint32_t>(0u), S.inserted, S.sel_out, S.sel_count,
@@ -386,6 +456,44 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
     DM_CHK(hipStreamSynchronize(stream));
     *out_count = (size_t) count;
     return hipSuccess;
+}
+
+hipError_t devmap_frame_sampling(DevMapScratch &S, const double *pts, size_t stride, size_t es, size_t n, double frame_voxel,
+                                 double keypoint_voxel, uint8_t *flag1, uint8_t *flag2, uint32_t *sel1, uint32_t *sel2, int *counts,
+                                 hipStream_t stream) {
+    if (n == 0) return hipMemsetAsync(counts, 0, 2 * sizeof(int), stream);
+    const unsigned grid = (unsigned) ((n + 255) / 256);
+    size_t tcap = 1024;
+    while (tcap < 2 * n) tcap <<= 1;
+    if (2 * tcap > S.gs_cap || (size_t) grid * 2 > S.cap) return hipErrorInvalidValue;
+    const uint32_t mask = (uint32_t) (tcap - 1);
+    uint32_t *counts1 = S.sel_out, *counts2 = S.sel_out + grid;                    // per-block counts of the two levels
+    hipLaunchKernelGGL(k_gs_clear, dim3((unsigned) std::min<size_t>((2 * tcap + 255) / 256, 2048)), dim3(256), 0, stream, S.gs_keys, S.gs_first,
+                       2 * tcap);
+    if (frame_voxel > 0) {
+        hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, pts, stride, n, frame_voxel, S.gs_keys, S.gs_first, mask, S.idx,
+                           (const uint8_t *) nullptr, es);
+        hipLaunchKernelGGL(k_gs_flags_count, dim3(grid), dim3(256), 0, stream, (const uint32_t *) S.gs_first, (const uint32_t *) S.idx, n, flag1,
+                           (const uint8_t *) nullptr, counts1);
+    } else {
+        hipLaunchKernelGGL(k_gs_flags_count, dim3(grid), dim3(256), 0, stream, (const uint32_t *) nullptr, (const uint32_t *) nullptr, n, flag1,
+                           (const uint8_t *) nullptr, counts1);
+    }
+    const uint8_t *kp_flags = flag1;
+    const uint32_t *kp_counts = counts1;
+    if (keypoint_voxel > 0) {
+        // "first point of every voxel, in the order of the sampled frame" = smallest index among the kept points: the sampled frame is
+        // the kept points in ascending index order
+        hipLaunchKernelGGL(k_gs_hash, dim3(grid), dim3(256), 0, stream, pts, stride, n, keypoint_voxel, S.gs_keys + tcap, S.gs_first + tcap, mask,
+                           S.idx, (const uint8_t *) flag1, es);
+        hipLaunchKernelGGL(k_gs_flags_count, dim3(grid), dim3(256), 0, stream, (const uint32_t *) (S.gs_first + tcap), (const uint32_t *) S.idx, n,
+                           flag2, (const uint8_t *) flag1, counts2);
+        kp_flags = flag2;
+        kp_counts = counts2;
+    }
+    hipLaunchKernelGGL(k_gs_compact2, dim3(grid), dim3(256), 0, stream, (const uint8_t *) flag1, kp_flags, (const uint32_t *) counts1, kp_counts,
+                       n, sel1, sel2, counts);
+    return hipGetLastError();
 }
 
 hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBands &bands, int max_num_points, uint32_t *out_idx,
@@ -450,7 +558,7 @@ void order_scratch_free(OrderScratch &S) {
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {
     hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
-                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance);
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution);
     DM_CHK(hipGetLastError());
     return read_counters(L, stream);
 }

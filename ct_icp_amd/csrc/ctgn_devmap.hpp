@@ -83,6 +83,15 @@ hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double dist
 // device memory) must hold n entries.
 hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, uint32_t *out_idx_host, size_t *out_count,
                                 hipStream_t stream);
+// The two samplers of a frame chained on the device, nothing read back (the frame pipeline, ctgn_frame_register): level 1 =
+// sub_sample_frame(frame, frame_voxel) (odometry.cpp:352; <= 0: every point kept), level 2 = grid_sampling(sampled frame, keypoints,
+// keypoint_voxel) (odometry.cpp:527; <= 0: keypoints = sampled frame). Coordinate a of point i = pts[i * es + a * stride]
+// (planes: es 1; x y z t records: es 4, stride 1). flag1 / flag2: n bytes, sel1 / sel2: n indices (ascending), counts: 2 device
+// ints {n sampled, n keypoints}. Six launches: clear, hash + flags per level, one two-way ordered compaction. Needs
+// devmap_scratch_reserve(S, n).
+hipError_t devmap_frame_sampling(DevMapScratch &S, const double *pts, size_t stride, size_t es, size_t n, double frame_voxel,
+                                 double keypoint_voxel, uint8_t *flag1, uint8_t *flag2, uint32_t *sel1, uint32_t *sel2, int *counts,
+                                 hipStream_t stream);
 // AdaptiveSamplePointsInGrid (reference include/ct_icp/algorithm/sampling.h:55-110): range band -> voxel size, the first
 // num_points_per_voxel indices of every (band, voxel); order band, voxel (z, y, x), index; at most max_num_points + 1
 // indices when max_num_points > 0 (the reference stops on size() > max). The band list must be validated by the caller.

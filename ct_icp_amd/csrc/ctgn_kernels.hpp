@@ -1412,8 +1412,13 @@ __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st,
 
 // Full-scan undistortion (reference src/ct_icp/odometry.cpp:461-486): out = InterpolatePose(t) * raw for n points given as
 // SoA arrays [x | y | z | t] with stride `cap`; pose = begin|end (14 doubles), slerp constants computed per thread block.
+// sel (optional): point i of the output is point sel[i] of the input (the sampled frame of the frame pipeline); out_cap = stride
+// of the output arrays.
+// in_es: coordinate a of input point j is in[j * in_es + a * cap] (x y z t records: in_es 4, cap 1; then out_cap must be given).
 __global__ __launch_bounds__(256) void k_transform_points(const double *in, double *out, int n, size_t cap, const double *pose,
-                                                          double tb, double te) {
+                                                          double tb, double te, const uint32_t *sel = nullptr, size_t out_cap = 0,
+                                                          size_t in_es = 1) {
+    if (out_cap == 0) out_cap = cap;
     __shared__ GnState s;
     if (threadIdx.x == 0) {
         const Quat qb = quat_normalized(Quat{pose[0], pose[1], pose[2], pose[3]});
@@ -1426,10 +1431,20 @@ __global__ __launch_bounds__(256) void k_transform_points(const double *in, doub
     }
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const Vec3 raw{in[i], in[cap + i], in[2 * cap + i]};
-        const double alpha = alpha_timestamp(in[3 * cap + i], tb, te);
+        const double *q = in + (sel ? (size_t) sel[i] : (size_t) i) * in_es;
+        const Vec3 raw{q[0], q[cap], q[2 * cap]};
+        const double alpha = alpha_timestamp(q[3 * cap], tb, te);
         const Vec3 p = ct_transform(&s, alpha, raw);
-        out[i] = p.x; out[cap + i] = p.y; out[2 * cap + i] = p.z;
+        out[i] = p.x; out[out_cap + i] = p.y; out[2 * out_cap + i] = p.z;
+    }
+}
+
+// Frame pipeline: keypoint i = scan point sel[i] (x y z t records): raw point and timestamp into the solver's keypoint arrays
+// (planes c apart).
+__global__ __launch_bounds__(256) void k_frame_keypoints(const double *scan, const uint32_t *sel, int n, double *kp, size_t c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double *q = scan + (size_t) sel[i] * 4;
+        kp[i] = q[0]; kp[c + i] = q[1]; kp[2 * c + i] = q[2]; kp[3 * c + i] = q[3];
     }
 }
 

@@ -194,6 +194,82 @@ def AdaptiveSamplePointsInGrid(voxel_map: GpuVoxelMap, points, options: Adaptive
     return out[:cnt.value].copy()
 
 
+class FramePipeline:
+    """One frame of the odometry loop with the scan resident on the device (ctgn_frame_register / ctgn_frame_update_map): what
+    Odometry::DoRegister does around the registration (reference src/ct_icp/odometry.cpp:333-382, 455-501, 526-590, 936-952) —
+    sub_sample_frame, grid_sampling, Register, both undistortions, RemoveElementsFarFromLocation + InsertPointCloud — with one
+    upload, one small read-back in the middle and one copy back. The map must be device-maintained (update_mode 1)."""
+
+    def __init__(self, voxel_map: GpuVoxelMap, frame_voxel_size=0.5, sample_voxel_size=1.5, max_num_keypoints=-1):
+        self.map = voxel_map
+        self._h = voxel_map.handle
+        self.frame_voxel_size, self.sample_voxel_size, self.max_num_keypoints = frame_voxel_size, sample_voxel_size, max_num_keypoints
+
+    def _call(self, fn, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all, want_sampled, extra):
+        raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        n = len(raw)
+        assert len(t) == n
+        pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
+                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp))
+        out = L.FrameOutputs()
+        res = {}
+        if want_all:
+            res["all_world"] = np.zeros((n, 3))
+            out.all_world_base, out.all_world_stride_bytes, out.all_world_dtype = res["all_world"].ctypes.data, 24, L.CTGN_F64
+        sampled_idx, kp_idx = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        out.sampled_indices, out.keypoint_indices = sampled_idx.ctypes.data, kp_idx.ctypes.data
+        if want_sampled:
+            sw = np.zeros((n, 3))
+            out.sampled_world_base, out.sampled_world_stride_bytes, out.sampled_world_dtype = sw.ctypes.data, 24, L.CTGN_F64
+        robust = options.solver == CERES
+        s = L.Summary()
+        dp = C.POINTER(C.c_double)
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            assert len(order) == n
+        c_opts = c_prior = c_ropts = c_rprior = None
+        if robust:
+            c_ropts, c_rprior = _c_robust_options(options), _c_robust_prior(motion_model)
+        else:
+            c_opts, c_prior = _c_options(options), _c_prior(motion_model)
+        st = fn(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0), n,
+                order.ctypes.data if order is not None else None, C.byref(fo), pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp),
+                C.byref(c_opts) if c_opts is not None else None, C.byref(c_prior) if c_prior is not None else None,
+                C.byref(c_ropts) if c_ropts is not None else None, C.byref(c_rprior) if c_rprior is not None else None,
+                *extra, C.byref(out), C.byref(s))
+        L.check(self._h, st)
+        self._last_n1 = int(out.num_sampled)
+        res.update(pose=pose, summary=_summary(s), sampled_indices=sampled_idx[:out.num_sampled].copy(),
+                   keypoint_indices=kp_idx[:out.num_keypoints].copy())
+        if want_sampled:
+            res["sampled_world"] = sw[:out.num_sampled].copy()
+        return res
+
+    def register(self, raw, t, pose14, t_begin_end, options: CTICPOptions, motion_model=None, order=None, override_timestamp=None,
+                 want_all=True, want_sampled=True) -> dict:
+        """Sampling -> keypoints -> registration -> undistortion. Returns pose (14), summary, sampled_indices, keypoint_indices and
+        (as asked) all_world / sampled_world."""
+        return self._call(L.lib().ctgn_frame_register, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp,
+                          want_all, want_sampled, ())
+
+    def update_map(self, location, max_distance: float, add_points: bool = True) -> np.ndarray | None:
+        """UpdateMap for the frame register() left on the device; returns the `inserted` mask of the sampled frame."""
+        loc = np.ascontiguousarray(location, dtype=np.float64)
+        mask = np.zeros(max(1, getattr(self, "_last_n1", 0)), dtype=np.uint8)
+        L.check(self._h, L.lib().ctgn_frame_update_map(self._h, loc.ctypes.data_as(C.POINTER(C.c_double)), float(max_distance),
+                                                      1 if add_points else 0, mask.ctypes.data if add_points else None))
+        return mask[:getattr(self, "_last_n1", 0)] if add_points else None
+
+    def frame(self, raw, t, pose14, t_begin_end, options: CTICPOptions, max_distance: float, motion_model=None, order=None,
+              override_timestamp=None, want_all=True, want_sampled=False) -> dict:
+        """register() + update_map(end translation, max_distance, success) in one call (always_insert policy)."""
+        return self._call(L.lib().ctgn_frame, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all,
+                          want_sampled, (C.c_double(float(max_distance)),))
+
+
 class GnSolver:
     """Array-level access to the same entry points (resident keypoints, repeated solves, stepwise GN for the
     sharded multi-GPU mode, introspection). Used by bench.py, ct_icp_amd.distributed and the parity tests."""

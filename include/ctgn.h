@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CTGN_ABI_VERSION 3
+#define CTGN_ABI_VERSION 4
 #define CTGN_MAX_RESOLUTIONS 8
 /* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
 #define CTGN_MIN_KEYPOINTS_USED 100
@@ -365,6 +365,66 @@ ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done);
 /* Use an externally owned HIP stream (e.g. torch's current stream) instead of the handle's own. */
 ctgn_status ctgn_set_stream(ctgn_handle h, void *hip_stream);
 ctgn_status ctgn_get_stream(ctgn_handle h, void **hip_stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * One frame of the odometry loop with the scan resident on the device: what Odometry::DoRegister does
+ * around the path — InitializeFrame's sub_sample_frame + initial transform (reference src/ct_icp/odometry.cpp:333-382), TryRegister's
+ * grid_sampling + Register + frame transform (:526-590), the undistortion of every point and of the sampled frame (:461-486) and
+ * UpdateMap's RemoveElementsFarFromLocation + InsertPointCloud (:936-952) — chained on the handle's stream: the scan is uploaded
+ * once, the two samplers, the keypoint gather, the GN (or robust) loop and both undistortions run without the host, ONE small
+ * read-back (the two sampled counts) sizes the launches, and one copy returns the pose, the summary and the outputs that were asked
+ * for. ctgn_frame_update_map then evicts and inserts from the device-resident undistorted frame: the reference decides in between
+ * (AssessRegistration / insertion policy, host logic), which is why the frame is two calls; ctgn_frame is both with the
+ * always_insert policy.
+ *
+ * The reference shuffles the frame before each sampler (its own std::mt19937, odometry.cpp:349,365). The first shuffle decides which
+ * point of a voxel survives, so the caller passes it: `order` (host, n entries, a permutation of 0..n-1, or NULL = scan order) — the
+ * frame is processed as points order[0], order[1], ... The second shuffle only randomises the reference's robin_map iteration order;
+ * here the sampled frame is in ascending processing order, which is already a random order of space when `order` is a shuffle.
+ * Every index this API reports is the caller's own point number.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double frame_voxel_size;             /* sub_sample_frame's voxel (options.voxel_size / init_voxel_size); <= 0: keep all points */
+    double sample_voxel_size;            /* grid_sampling's voxel for the keypoints; <= 0: keypoints = sampled frame (sampling NONE) */
+    int32_t max_num_keypoints;           /* > 0: keep the first max_num_keypoints keypoints (odometry.cpp:549-552)            */
+    int32_t override_timestamps;         /* 1: every point takes override_timestamp (registered_fid <= 1, odometry.cpp:357-361)  */
+    double override_timestamp;
+} ctgn_frame_options;
+void ctgn_frame_options_default(ctgn_frame_options *o);
+
+typedef struct {                         /* any pointer may be NULL = not wanted; host memory                                     */
+    void *all_world_base;                /* n records: every scan point undistorted with the final poses (all_corrected_points)  */
+    size_t all_world_stride_bytes;
+    ctgn_dtype all_world_dtype;
+    int32_t _pad0;
+    uint32_t *sampled_indices;           /* capacity n: scan index of every point of the sampled frame                           */
+    void *sampled_world_base;            /* capacity n records: the sampled frame undistorted (corrected_points)                 */
+    size_t sampled_world_stride_bytes;
+    ctgn_dtype sampled_world_dtype;
+    int32_t _pad1;
+    uint32_t *keypoint_indices;          /* capacity n: scan index of every keypoint                                             */
+    uint64_t num_sampled;                /* out                                                                                  */
+    uint64_t num_keypoints;              /* out                                                                                  */
+} ctgn_frame_outputs;
+
+/* Sampling -> keypoints -> registration -> undistortion of one scan. `robust` NULL: the GN route with `opts` (+ `prior`, may be
+ * NULL); `robust` non-NULL: the robust-loss route (`opts` / `prior` ignored, `robust_prior` may be NULL). pose_io in: the initial
+ * begin|end estimate (trajectory_[kIndexFrame]); out: the optimised poses. The views are host memory. Errors leave the map and
+ * the previous resident frame untouched. */
+ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const uint32_t *order,
+                                const ctgn_frame_options *fopts, double pose_io[14], const double t_begin_end[2],
+                                const ctgn_options *opts, const ctgn_motion_prior *prior, const ctgn_robust_options *robust,
+                                const ctgn_robust_prior *robust_prior, ctgn_frame_outputs *out, ctgn_summary *summary);
+/* UpdateMap for the resident frame (odometry.cpp:936-952): RemoveElementsFarFromLocation(location, max_distance) on every level,
+ * then — if add_points — insert the sampled frame's undistorted points. Needs the device-resident map (ctgn_map_set_update_mode 1).
+ * inserted (host, num_sampled bytes, may be NULL): 1 where the point entered some level. */
+ctgn_status ctgn_frame_update_map(ctgn_handle h, const double location[3], double max_distance, int32_t add_points,
+                                  uint8_t *inserted);
+/* ctgn_frame_register, then ctgn_frame_update_map(end translation, max_distance, success). */
+ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const uint32_t *order,
+                       const ctgn_frame_options *fopts, double pose_io[14], const double t_begin_end[2], const ctgn_options *opts,
+                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                       double max_distance, ctgn_frame_outputs *out, ctgn_summary *summary);
 
 /* -------------------------------------------------------------------------------------------------
  * Introspection for tests / measurement.

@@ -362,6 +362,7 @@ def test_cpp_adapter_program():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("adapter ok") and "adapter-ceres ok" in out.stdout, out.stdout + out.stderr
+    assert "adapter-frame ok" in out.stdout, out.stdout                      # RegisterFrame / UpdateMapFromFrame (frame pipeline)
 
 
 def test_sharded_loop_single_rank_equals_fused(box_case):
@@ -696,6 +697,98 @@ def test_sequence_of_frames_end_to_end(street_case):
         assert gm.NumPoints() == om.num_points() and gm.NumVoxels(0) == om.num_voxels(0)
         prev_g, prev_o = pose_g, pose_o
     assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(om.export(0)))
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
+    """ctgn_frame_register / ctgn_frame_update_map / ctgn_frame (scan resident on the device) against the same
+    frame loop spelled with the stage entry points that the test above pins to the oracle: identical sampled frame, keypoints, poses
+    (bit for bit: same kernels on the same inputs in the same order), undistorted points, insert decisions and map — with the scan in
+    firing order and behind a caller-side shuffle (`order`), for the GN route and once for the robust-loss route."""
+    case = street_case
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    mk = lambda: cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius,
+                                                        device_updates=True))
+    ga, gb = mk(), mk()                       # a: stage by stage, b: frame pipeline
+    fp = cia.FramePipeline(gb, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    o = _opts(num_iters_icp=5, threshold_orientation_norm=1e-4, min_number_neighbors=10)
+    reg = cia.CT_ICP_Registration(o)
+    rng = np.random.default_rng(3)
+
+    def stage_frame(sc, pose0, options, mm, order, register=True):
+        raw_all, t_all = (sc.raw, sc.t) if order is None else (sc.raw[order], sc.t[order])
+        keep = cia.grid_sampling(ga, raw_all, 0.5)
+        assert np.all(np.diff(keep.astype(np.int64)) > 0)
+        raw, t = raw_all[keep], t_all[keep]
+        kp = cia.grid_sampling(ga, raw, 0.7)
+        pose = pose0.copy()
+        summ = None
+        if register:
+            kps = np.zeros(len(kp), dtype=cia.WPOINT3D_DTYPE)
+            kps["raw_point"], kps["t"] = raw[kp], t[kp]
+            kps["world_point"] = cia.transform_points(ga, raw[kp], t[kp], pose0, sc.t_begin_end)
+            frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+            summ = cia.CT_ICP_Registration(options).Register(ga, kps, frame, mm)
+            pose = frame.pose14()
+        world = cia.transform_points(ga, raw, t, pose, sc.t_begin_end)
+        all_world = cia.transform_points(ga, sc.raw, sc.t, pose, sc.t_begin_end)
+        ga.RemoveElementsFarFromLocation(pose[11:14], 60.0)
+        mask = ga.InsertPointCloud(world)
+        idx = keep if order is None else order[keep]
+        return dict(pose=pose, summary=summ, sampled=idx, keypoints=idx[kp], world=world, all_world=all_world, mask=mask)
+
+    def check(a, b, mask_b):
+        assert np.array_equal(a["sampled"], b["sampled_indices"]) and np.array_equal(a["keypoints"], b["keypoint_indices"])
+        assert np.array_equal(a["pose"], b["pose"])
+        assert np.array_equal(a["world"], b["sampled_world"]) and np.array_equal(a["all_world"], b["all_world"])
+        if mask_b is not None:
+            assert np.array_equal(np.asarray(a["mask"]).astype(bool), mask_b.astype(bool))
+        assert ga.NumPoints() == gb.NumPoints() and ga.NumVoxels(0) == gb.NumVoxels(0)
+
+    # frames 0-4: no registration (num_iters_icp = 0 leaves the initial estimate), everything else runs
+    o0 = _opts(num_iters_icp=0)
+    for j in range(5):
+        sc = case["scans"][j]
+        order = rng.permutation(len(sc.t)).astype(np.uint32) if shuffled else None
+        a = stage_frame(sc, sc.pose_gt, o0, None, order, register=False)
+        b = fp.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o0, order=order)
+        assert b["summary"].success and b["summary"].num_iters == 0
+        mask = fp.update_map(b["pose"][11:14], 60.0, True)
+        check(a, b, mask)
+    prev = case["scans"][4].pose_gt.copy()
+    for j in range(5, 10):
+        sc = case["scans"][j]
+        order = rng.permutation(len(sc.t)).astype(np.uint32) if shuffled else None
+        pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=j)
+        mm = cia.PreviousFrameMotionModel()
+        mm.previous_frame = cia.TrajectoryFrame.from_pose14(prev, 0.0, 0.0)
+        options = o if j != 7 else cia.CTICPOptions(solver=cia.CERES, num_iters_icp=4, ls_max_num_iters=4, min_number_neighbors=10,
+                                                    debug_print=False)
+        a = stage_frame(sc, pose0, options, mm, order)
+        if j % 2:                                                                 # both spellings of the second half
+            b = fp.register(sc.raw, sc.t, pose0, sc.t_begin_end, options, motion_model=mm, order=order)
+            mask = fp.update_map(b["pose"][11:14], 60.0, True)
+        else:
+            b = fp.frame(sc.raw, sc.t, pose0, sc.t_begin_end, options, 60.0, motion_model=mm, order=order, want_sampled=True)
+            mask = None
+        assert a["summary"].success and b["summary"].success
+        assert a["summary"].num_residuals_used == b["summary"].num_residuals_used and a["summary"].num_iters == b["summary"].num_iters
+        assert b["summary"].num_iters > 0 and not np.array_equal(b["pose"], pose0)        # and it is a registration, not a no-op
+        check(a, b, mask)
+        prev = b["pose"]
+    assert np.array_equal(_sorted_rows(ga.MapAsPointCloud(0)), _sorted_rows(gb.MapAsPointCloud(0)))
+    # error paths: timestamps outside the frame, a bad order, no resident frame on a fresh handle
+    sc = case["scans"][9]
+    with pytest.raises(cia.CtgnError):
+        fp.register(sc.raw, sc.t + 10.0, sc.pose_gt, sc.t_begin_end, o)
+    with pytest.raises(cia.CtgnError):
+        fp.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o, order=np.full(len(sc.t), len(sc.t), dtype=np.uint32))
+    with pytest.raises(cia.CtgnError):
+        cia.FramePipeline(mk()).update_map(np.zeros(3), 10.0, True)
+    # the first frames of a sequence: every point takes the end timestamp (odometry.cpp:357-361)
+    b = fp.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o0, override_timestamp=sc.t_begin_end[1], want_sampled=False)
+    want = cia.transform_points(ga, sc.raw, np.full(len(sc.t), sc.t_begin_end[1]), sc.pose_gt, sc.t_begin_end)
+    assert np.array_equal(b["all_world"], want)
 
 
 # ------------------------------------------------------------------------------------------------- device-memory views
