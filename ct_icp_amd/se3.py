@@ -12,6 +12,11 @@ import numpy as np
 _ONE = 1.0 - np.finfo(np.float64).eps
 
 
+def identity_pose14():
+    """begin | end pose, both the identity."""
+    return np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0] * 2)
+
+
 def quat_normalize(q):
     q = np.asarray(q, dtype=np.float64)
     return q / np.linalg.norm(q, axis=-1, keepdims=True)

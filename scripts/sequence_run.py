@@ -197,6 +197,24 @@ def run_sequence_device(seq, args, device: int):
                 map_points=int(gm.NumPoints()))
 
 
+def run_sequence_pipeline(seq, args, device: int):
+    """The same loop as ONE ctgn_frame call per frame (ct_icp_amd/sequence_runner.py): the scan stays on the device from the samplers
+    to the map update."""
+    from ct_icp_amd import sequence_runner as sr
+    knots = seq["knots"]
+    offs = np.concatenate([[0], np.cumsum(seq["counts"])])
+    scans = [(seq["raw"][offs[j]:offs[j + 1]], seq["t"][offs[j]:offs[j + 1]], (0.1 * j, 0.1 * (j + 1))) for j in range(len(seq["counts"]))]
+    solver = cia.GN if args.solver == "GN" else cia.CERES
+    r = sr.run_sequence(scans, device=device, solver=solver, voxel_size=args.voxel_size, sample_voxel_size=args.sample_voxel_size,
+                        max_distance=args.max_distance, init_poses=[syn.frame_pose14(knots, j) for j in range(args.init_frames)],
+                        init_frames=args.init_frames, use_motion_model=(solver == cia.CERES or args.gn_prior))
+    errs = np.array([se3.pose_error(r["poses"][j], syn.frame_pose14(knots, j)) for j in range(args.init_frames, r["frames"])] or [(0.0, 0.0)])
+    return dict(frames=r["frames"], seconds=r["seconds"], stages={}, registered=r["frames"] - args.init_frames,
+                failures=int(np.count_nonzero(~r["success"])), keypoints_mean=float(r["keypoints"][args.init_frames:].mean()),
+                points_per_frame=float(np.mean(seq["counts"])), err_tr_max=float(errs[:, 0].max()), err_tr_mean=float(errs[:, 0].mean()),
+                err_rot_max=float(errs[:, 1].max()), map_points=r["map_points"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=40)
@@ -213,6 +231,7 @@ def main():
     ap.add_argument("--gn-prior", action="store_true", help="pass the PreviousFrameMotionModel to the GN solver too")
     ap.add_argument("--device-views", action="store_true", help="keep the scan in device memory and hand the library device views")
     ap.add_argument("--host-map", action="store_true", help="maintain the map on the host mirror instead of the device")
+    ap.add_argument("--pipeline", action="store_true", help="one ctgn_frame call per frame (scan resident on the device) instead of the stage calls")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -226,10 +245,10 @@ def main():
     if mine:                              # warm-up: first touches of the library, allocations, code objects
         s0 = seqs[mine[0]]
         m = int(s0["counts"][:8].sum())
-        runner = run_sequence_device if args.device_views else run_sequence
+        runner = run_sequence_pipeline if args.pipeline else run_sequence_device if args.device_views else run_sequence
         runner({**s0, "counts": s0["counts"][:8], "raw": s0["raw"][:m], "t": s0["t"][:m]}, args, device)
     for i in mine:
-        r = (run_sequence_device if args.device_views else run_sequence)(seqs[i], args, device)
+        r = runner(seqs[i], args, device)
         r["sequence"] = i
         results.append(r)
     if world > 1:
@@ -252,7 +271,7 @@ def main():
         print(json.dumps({"metric": "frames/s, whole per-frame loop through libctgn", "value": frames / wall, "n_gpus": world,
                           "solver": args.solver, "sequences": len(results), "frames": frames, "wall_seconds": wall,
                           "map": "host mirror" if args.host_map else "device-resident",
-                          "views": "device memory" if args.device_views else "host memory", "keypoint_sampling": args.sampling, "per_sequence": results}))
+                          "views": "frame pipeline (one ctgn_frame per frame)" if args.pipeline else "device memory" if args.device_views else "host memory", "keypoint_sampling": args.sampling, "per_sequence": results}))
 
 
 if __name__ == "__main__":

@@ -87,3 +87,45 @@ def test_allreduce_of_packed_system_world_size_2(tmp_path):
     res = [np.load(tmp_path / f"ok_{r}.npy") for r in range(2)]
     assert all(r[0] == 1 and r[1] == 1 for r in res), res
     assert res[0][3] == res[1][3] > 100
+
+
+# ------------------------------------------------------------------------------------------------- config E: sequences per rank
+def _batch_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ct_icp_amd import sequence_runner as sr
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = [40, 10, 41, 8, 3, 25, 10]
+    ran = []
+
+    def fake_run_sequence(scans, **kw):                       # stands in for the GPU loop: one "second" per frame
+        ran.append(len(scans))
+        return dict(poses=np.zeros((len(scans), 14)), success=np.ones(len(scans), bool), seconds=float(len(scans)), frames=len(scans),
+                    keypoints=np.zeros(len(scans)), sampled=np.zeros(len(scans)), map_points=0)
+
+    sr.run_sequence = fake_run_sequence
+    _, shares = sr.deal_sequences(lengths, world)
+    mine = {sid: [None] * lengths[sid] for sid in shares[rank]}          # a rank only holds its own sequences
+    out = sr.run_batch(mine, lengths, rank=rank, world_size=world)
+    np.save(os.path.join(tmpdir, f"batch_{rank}.npy"), np.array([out["frames"], out["wall_seconds"], sum(ran), len(out["results"])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config_e_sequences_are_dealt_longest_first_and_aggregated(tmp_path):
+    """SURVEY.md 8d config E on CPU (gloo, world size 2): every rank runs only its own sequences (longest first, round-robin), nothing
+    is exchanged while they run, the gathered result counts every frame once and the job's wall time is the slowest rank's."""
+    import torch.multiprocessing as mp
+    from ct_icp_amd import sequence_runner as sr
+    lengths = [40, 10, 41, 8, 3, 25, 10]
+    order, shares = sr.deal_sequences(lengths, 2)
+    assert order == [2, 0, 5, 1, 6, 3, 4] and shares == [[2, 5, 6, 4], [0, 1, 3]]
+    assert sorted(shares[0] + shares[1]) == list(range(7))
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_batch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "batch_0.npy"), np.load(tmp_path / "batch_1.npy")
+    assert r0[0] == r1[0] == sum(lengths) and r0[3] == r1[3] == 7
+    assert r0[2] == 41 + 25 + 10 + 3 and r1[2] == 40 + 10 + 8
+    assert r0[1] == r1[1] == max(41 + 25 + 10 + 3, 40 + 10 + 8)

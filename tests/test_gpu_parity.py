@@ -791,6 +791,35 @@ def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
     assert np.array_equal(b["all_world"], want)
 
 
+def test_config_e_two_sequences_on_one_gpu(street_case):
+    """SURVEY.md 8d config E (one sequence per GPU, zero communication) through ct_icp_amd.sequence_runner on ONE GPU with two
+    sequences: every frame is one ctgn_frame call; each sequence owns its map and handle, so a sequence's trajectory does not depend
+    on what else ran in the process (bit-identical alone and in the batch); every registration succeeds and tracks the ground truth."""
+    from ct_icp_amd import sequence_runner as sr
+    case = street_case
+    rng = np.random.default_rng(11)
+    seq_a = [(sc.raw, sc.t, tuple(sc.t_begin_end)) for sc in case["scans"][:11]]
+    seq_b = [(sc.raw, sc.t, tuple(sc.t_begin_end)) for sc in case["scans"][:8]]
+    orders_b = [rng.permutation(len(sc.t)).astype(np.uint32) for sc in case["scans"][:8]]
+    gt = [sc.pose_gt for sc in case["scans"]]
+    kw = dict(device=0, solver=cia.GN, voxel_size=0.5, sample_voxel_size=0.7, max_distance=60.0, init_poses=gt, init_frames=5)
+    alone = sr.run_sequence(seq_a, **kw)
+    assert alone["frames"] == 11 and alone["success"].all() and alone["map_points"] > 10_000
+    out = sr.run_batch({0: seq_a, 1: seq_b}, [len(seq_a), len(seq_b)], rank=0, world_size=1, **kw)
+    assert out["frames"] == 19 and out["shares"] == [[0, 1]] and out["frames_per_sec"] > 0
+    ra, rb = out["results"]
+    assert ra["sequence"] == 0 and np.array_equal(ra["poses"], alone["poses"]) and ra["map_points"] == alone["map_points"]
+    assert rb["frames"] == 8 and rb["success"].all()
+    for j in range(5, 11):
+        tr, rot = se3.pose_error(ra["poses"][j], gt[j])
+        assert tr < 0.6 and rot < 5e-3, (j, tr, rot)          # a street canyon: the along-street translation is weakly observed
+    # the shuffled copy of the same scans tracks the same trajectory (another random choice of voxel representatives)
+    rb2 = sr.run_sequence(seq_b, orders=orders_b, **kw)
+    for j in range(5, 8):
+        tr, rot = se3.pose_error(rb2["poses"][j], rb["poses"][j])
+        assert tr < 0.3 and rot < 5e-3, (j, tr, rot)
+
+
 # ------------------------------------------------------------------------------------------------- device-memory views
 def test_device_memory_views_match_host_views(street_case):
     """Every entry point that takes point views also takes them in device memory (torch CUDA tensors here): identical results,
