@@ -94,6 +94,8 @@ struct ctgn_context {
     GnParams prm{};
     ctgn_options gn_opts{};
     int launched_iters = 0;
+    bool kth_fresh = false;             // the k-th distances on the device were written by the previous search of this solve
+    int searches_in_solve = 0;          // neighbour searches launched since the solve began (the first one has no carried-over bound)
     int last_grid = 0;
     bool gn_active = false;
     std::chrono::steady_clock::time_point gn_t0;
@@ -474,6 +476,8 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.wx = base + 4 * c; v.wy = base + 5 * c; v.wz = base + 6 * c;
     v.sel = h->d_res;
     v.cnt = h->d_res + (size_t) h->cap_kp * SEL_STRIDE;
+    v.kth = reinterpret_cast<float *>(h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 1));
+    v.kth_valid = 0;
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
@@ -548,6 +552,10 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     }
     KpView kv = kp_view(h, !search_only);
     if (!search_only) kv.clk_iter_start = &h->d_state->clk_iter_start;
+    // the previous search's k-th distances bound this one — only inside one solve (same keypoints, same map, world points untouched)
+    kv.kth_valid = (!first_iter && h->searches_in_solve > 0 && h->kth_fresh) ? 1 : 0;
+    h->searches_in_solve++;
+    h->kth_fresh = false;               // set again below by the kernel that writes them
     DebugView dv = dbg_view(h);
     EventPair *ev = nullptr;
     if (h->profiling) {
@@ -600,6 +608,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : (h->order_valid && !h->kp_coherent)) && g1 >= 64 ? 1 : 0;
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
+            h->kth_fresh = true;
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
             ev = nullptr;
             if (search_only) { grid = g1; return; }
@@ -1006,7 +1015,7 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), (cap * 7 + KP_TAIL) * sizeof(double)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + cap) * sizeof(uint32_t)));   // records | counts
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 2 * cap) * sizeof(uint32_t)));   // records | counts | k-th distances
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
@@ -1153,6 +1162,7 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
     h->launched_iters = 0;
+    h->searches_in_solve = 0;
     h->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
     h->planned_iters = opts->num_iters_icp;
     h->events_used = 0;
@@ -1916,6 +1926,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     const int grid_eval = std::max(1, std::min((n + EVAL_BLOCK - 1) / EVAL_BLOCK, h->res_grid_cap));
     const bool saved_prof = h->profiling;
     h->profiling = false;
+    h->searches_in_solve = 0;
     for (int it = 0; st == CTGN_OK && it < o->num_iters_icp; ++it) {                     // :535
         st = launch_accumulate(h, mv, false, true);                                      // transform_keypoints + neighbourhoods
         if (st != CTGN_OK) break;

@@ -51,6 +51,9 @@ struct KpView {
     double *wx, *wy, *wz;
     uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: count, then the byte offsets of the kept points
     uint32_t *cnt;           // [n] the record's count again, dense: the residual kernel looks here first and only fetches the records it will use
+    float *kth;              // [n] squared distance of the k-th neighbour the last search found (rounded up; +inf: fewer than k): with the
+                             // keypoint's displacement since then it bounds the next search (k_accumulate_rows); nullptr = not kept
+    int kth_valid;           // 1: kth[] and the world points come from the previous search of THIS solve on the same map (set per launch)
     int n;
     const uint32_t *order;   // k_accumulate_rows works on keypoint order[s] at position s (positions sorted by home voxel); nullptr = identity
     int chunk;               // rounds of a tile that take consecutive positions (>= 1)
@@ -415,18 +418,19 @@ __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
 }
 
 // Issue the hash probe of this lane's voxel of probe batch `it`: sweep index v (255 = none), skipped when the
-// keypoint has no search or when the whole voxel lies farther than the radius from the query (exact: no point of
-// such a voxel can pass map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
+// keypoint has no search or when the whole voxel lies farther from the query than r2bound — the radius, or the tighter
+// bound on the k-th neighbour's distance carried over from the previous search (exact: no point of such a voxel can be
+// among the k nearest within the radius, map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
 template <int NB>
 __device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
-                                             double qx, double qy, double qz, int &v_out, int ablate = 0) {
+                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound) {
     constexpr int S = 2 * NB + 1;
     const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
     v_out = v;
     const int vv = (v == 255) ? 0 : v;
     const int vx = kx + vv / (S * S) - NB, vy = ky + (vv / S) % S - NB, vz = kz + vv % S - NB;
     const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
-    const bool reachable = (ablate & 64) || gx * gx + gy * gy + gz * gz <= m.r2thr * (1.0 + 1e-8);
+    const bool reachable = (ablate & 64) || gx * gx + gy * gy + gz * gz <= r2bound * (1.0 + 1e-8) + 1e-12;
     return probe_issue(m, searching && v != 255 && reachable && !(ablate & 16), vx, vy, vz);
 }
 
@@ -471,6 +475,7 @@ struct WaveScratch {
     double px[64], py[64], pz[64];     // world point of the tile's keypoints
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
     int id[64];                        // its index in the caller's arrays; -1 = none
+    float kb[64];                      // admission bound of its search (squared distance, rounded up); +inf = the radius only
     union {
         struct {
             RowList list[4];
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                                                                unsigned long long *prof = nullptr, int ablate = 0) {
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (st->done) return;
+    if (st->done && !ablate) return;                  // an ablated run starves the solve: keep timing the search anyway
     if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
     WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
@@ -669,14 +674,24 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         {
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
+        float kbv = __int_as_float(0x7f800000);
         if (own) {
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
             const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+            const Vec3 before{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};          // where the last search (or the upload) saw it
             if (first_iter) {
-                p = Vec3{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};
+                p = before;
             } else {
                 p = ct_transform(st, alpha, raw);
                 kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
+                if (kp.kth_valid && !(ablate & 256)) {
+                    // The k neighbours of the previous search lie within sqrt(kth) + |p - before| of the new position (the map does not
+                    // change inside a solve): an upper bound on the new k-th distance, usually a few millimetres above it. Admitting
+                    // only candidates inside it leaves ~k of the ~260 streamed points in the list; the result is the same set.
+                    const double dx = p.x - before.x, dy = p.y - before.y, dz = p.z - before.z;
+                    const double reach = sqrt((double) kp.kth[my_kp]) + sqrt(sq_norm3(dx, dy, dz));
+                    kbv = __double2float_ru(reach * reach * (1.0 + 1e-9));
+                }
             }
             int a = voxel_coord(p.x, map.resolution), b = voxel_coord(p.y, map.resolution), c = voxel_coord(p.z, map.resolution);
             if (sweep_in_short_range(a, NB) && sweep_in_short_range(b, NB) && sweep_in_short_range(c, NB)) {
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
         W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
         W.id[lane] = my_kp;
+        W.kb[lane] = kbv;
         }
         CTGN_TICK(0)
 
@@ -693,8 +709,26 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         Probe nxt;
         int nxt_v = 255, nxt_round = -1;            // generic path: probe batch already in flight for round nxt_round
         int st_kx = INT_MIN, st_ky = 0, st_kz = 0, st_P = 0;   // fast path: home voxel whose neighbourhood is staged, its size
-        Probe snxt;                                 // fast path: the wave's 27 probes for round snxt_round, already in flight
+        Probe snxt;                                 // fast path: the wave's probes for round snxt_round, already in flight
         int snxt_round = -1;
+        unsigned long long snxt_need = 0, st_need = 0;    // bit i: the i-th nearest sweep voxel is (being) probed / is in the staged table
+        // Which of the 27 sweep voxels of home voxel (hx, hy, hz) can hold one of the k nearest of some row's keypoint of round rr: those
+        // whose box reaches inside that keypoint's admission bound (the radius, or the bound carried over from the previous search —
+        // then typically 1-4 voxels instead of 27). Bit i = the i-th nearest sweep voxel, lane i's.
+        auto shared_need = [&](int rr, int hx, int hy, int hz) -> unsigned long long {
+            if (ablate & 512) return (1ull << 27) - 1ull;
+            const int svl = lane < 27 ? (int) c_sweep1.v[lane] : 13;
+            const int vx = hx + svl / 9 - 1, vy = hy + (svl / 3) % 3 - 1, vz = hz + svl % 3 - 1;
+            bool any_row = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s2 = j * 16 + rr;
+                const double gx = axis_gap(W.px[s2], vx, map.resolution), gy = axis_gap(W.py[s2], vy, map.resolution),
+                             gz = axis_gap(W.pz[s2], vz, map.resolution);
+                any_row = any_row || gx * gx + gy * gy + gz * gz <= fmin(map.r2thr, (double) W.kb[s2]) * (1.0 + 1e-8) + 1e-12;
+            }
+            return __ballot(any_row && lane < 27);
+        };
         for (int r = 0; r < rounds; ++r) {
             const int src = row * 16 + r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
@@ -702,7 +736,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             const bool searching = kx != INT_MIN;
             const uint32_t lt_mask = (1u << sub) - 1u;
             int Ln = 0;
-            double kth_d2 = map.r2thr;            // admission bound of the stream: the radius, then the k-th best so far
+            // admission bound of the stream: the radius or the bound carried over from the previous search, then the k-th best so far
+            double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
@@ -712,17 +747,22 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (uniform_home) {
                 // ===== fast path: shared, flattened neighbourhood =====
                 occ_tab = SH.occ;
-                if (!(kx == st_kx && ky == st_ky && kz == st_kz)) {
-                    // probe the 27 sweep voxels once for the wave (lane v < 27 takes sweep voxel v)
+                const unsigned long long need = (snxt_round == r) ? snxt_need : shared_need(r, kx, ky, kz);
+                if (!(kx == st_kx && ky == st_ky && kz == st_kz && (need & ~st_need) == 0ull)) {
+                    // probe the sweep voxels some row needs, once for the wave: lane i < 27 takes the i-th NEAREST sweep voxel (centre,
+                    // faces, edges, corners), so the flattened table starts with the home voxel's points and the first prune of the
+                    // stream already leaves a tight k-th-best bound for the rest
+                    const int sv = lane < 27 ? (int) c_sweep1.v[lane] : 27;
                     if (snxt_round != r)
-                        snxt = probe_issue(map, lane < 27 && !(ablate & 16), kx + lane / 9 - 1, ky + (lane / 3) % 3 - 1, kz + lane % 3 - 1);
+                        snxt = probe_issue(map, ((need >> lane) & 1ull) && !(ablate & 16), kx + sv / 9 - 1, ky + (sv / 3) % 3 - 1, kz + sv % 3 - 1);
+                    st_need = need;
                     if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(snxt.active));
                     const uint32_t bc = probe_resolve(map, snxt);
                     const int cnt = (int) (bc & 127u);
                     const int inc = row_scan_i32(cnt);                       // inclusive prefix within each DPP row
                     const int tot0 = __builtin_amdgcn_readlane(inc, 15), tot1 = __builtin_amdgcn_readlane(inc, 31);
                     const int pre = inc - cnt + (row == 1 ? tot0 : 0);       // flat position of this voxel's first point
-                    if (lane < 28) SH.occ[lane] = bc;
+                    if (lane < 28) SH.occ[sv] = bc;
                     int nchunk = 0;
                     for (int hh = 0; hh < 2; ++hh) {
                         const int left = cnt - 16 * hh;
@@ -731,7 +771,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                         if (!hb) break;
                         if (has) SH.chunk[nchunk + __popcll(hb & ((1ull << lane) - 1ull))] =
                                 make_uint2((bc >> 7) * stride3 + 128u * hh,
-                                           ((((uint32_t) lane << 6) | (16u * hh)) << 15) | ((uint32_t) (pre + 16 * hh) << 5) | (uint32_t) min(left, 16));
+                                           ((((uint32_t) sv << 6) | (16u * hh)) << 15) | ((uint32_t) (pre + 16 * hh) << 5) | (uint32_t) min(left, 16));
                         nchunk += __popcll(hb);
                     }
                     // flatten: 4 chunks per step, one per row; candidate c of the table = (offset of its x, visit index)
@@ -750,11 +790,26 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     st_P = tot0 + tot1;
                 }
                 CTGN_TICK(1)
-                // two register sets in ping-pong: the loads of the next 16 candidates are in flight while the current 16
-                // are tested (no copies between the sets, so the wait only covers the set being consumed)
+                // The four rows hold four DIFFERENT queries over the SAME candidate table: every lane fetches its own candidate (64
+                // distinct ones per step instead of 16 fetched four times) and tests it against all four queries, whose coordinates
+                // and admission bounds are wave-uniform (SGPRs). The chain of dependent load round trips — what this phase waits
+                // on — is a quarter as long; each row's list receives the same candidates in the same order as before.
+                // Two register sets in ping-pong: the loads of the next 64 candidates are in flight while the current 64 are tested.
+                auto bcast = [](double v, int l) {
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+                };
+                double Qx[4], Qy[4], Qz[4], Kth[4];
+                int L[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Qx[j] = bcast(qx, 16 * j); Qy[j] = bcast(qy, 16 * j); Qz[j] = bcast(qz, 16 * j);
+                    Kth[j] = bcast(kth_d2, 16 * j);
+                    L[j] = 0;
+                }
+                const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
                 struct Cand { double x, y, z; uint32_t vis; bool valid; };
                 auto fetch = [&](int c0, Cand &o) {
-                    const int c = c0 + sub;
+                    const int c = c0 + lane;
                     o.valid = c < st_P;
                     const int cc = o.valid ? c : 0;
                     const uint32_t off = o.valid ? SH.off[cc] : 0u;       // masked lanes read the start of the block storage
@@ -764,42 +819,60 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     o.z = *reinterpret_cast<const double *>(pbase_z + off);
                 };
                 auto test = [&](const Cand &cnd) {
-                    if (PROF) pc[11] += (unsigned long long) __popcll(__ballot(cnd.valid));
-                    const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
-                    const double d2 = sq_norm3(dx, dy, dz);
-                    // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
-                    // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
-                    const bool pass = cnd.valid && d2 <= kth_d2;
-                    const uint32_t pm = row_bits(__ballot(pass), row);
-                    if (pass) {
-                        const int pos = Ln + __popc(pm & lt_mask);
-                        R.d2[pos] = d2;
-                        R.vis[pos] = cnd.vis;
+                    if (PROF) pc[11] += 4ull * (unsigned long long) __popcll(__ballot(cnd.valid));   // per keypoint, as the row path counts
+                    double d2[4];
+                    unsigned long long pm[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double dx = cnd.x - Qx[j], dy = cnd.y - Qy[j], dz = cnd.z - Qz[j];
+                        d2[j] = sq_norm3(dx, dy, dz);
+                        // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
+                        // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
+                        pm[j] = __ballot(cnd.valid && d2[j] <= Kth[j] && !(ablate & 128));
                     }
-                    Ln += __popc(pm);
+                    // a list that cannot take this step's admissions: cut every row back to its k best first, then admit against the
+                    // tighter bounds (after the cut a list holds <= k <= 32 entries and a step adds <= 64)
+                    if (max(max(L[0] + (int) __popcll(pm[0]), L[1] + (int) __popcll(pm[1])),
+                            max(L[2] + (int) __popcll(pm[2]), L[3] + (int) __popcll(pm[3]))) > LCAP) {
+                        CTGN_TICK(2)
+                        Ln = row == 0 ? L[0] : row == 1 ? L[1] : row == 2 ? L[2] : L[3];
+                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
+                        if (Ln >= k) kth_d2 = R.d2[k - 1];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            L[j] = __builtin_amdgcn_readlane(Ln, 16 * j);
+                            Kth[j] = bcast(kth_d2, 16 * j);
+                            pm[j] = __ballot(cnd.valid && d2[j] <= Kth[j]);
+                        }
+                        CTGN_TICK(3)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if ((pm[j] >> lane) & 1ull) {
+                            const int pos = L[j] + __popcll(pm[j] & below);
+                            W.list[j].d2[pos] = d2[j];
+                            W.list[j].vis[pos] = cnd.vis;
+                        }
+                        L[j] += __popcll(pm[j]);
+                    }
                 };
                 // straight-line loop body: the fetches are unconditional (out-of-range lanes re-read candidate 0 and are
                 // masked), so the compiler's s_waitcnt covers exactly the set being consumed, not the one in flight
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
                 fetch(0, ca);
-                for (int c0 = 0; c0 < ((ablate & 1) ? 0 : st_P); c0 += 32) {
-                    fetch(c0 + 16, cb);
+                for (int c0 = 0; c0 < ((ablate & 1) ? 0 : st_P); c0 += 128) {
+                    fetch(c0 + 64, cb);
                     test(ca);
-                    fetch(c0 + 32, ca);
+                    fetch(c0 + 128, ca);
                     test(cb);
-                    if (__any(Ln > LCAP - 32)) {
-                        // list nearly full somewhere in the wave: cut every row back to its k best
-                        CTGN_TICK(2)
-                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
-                        if (Ln >= k) kth_d2 = R.d2[k - 1];
-                        CTGN_TICK(3)
-                    }
                 }
+                Ln = row == 0 ? L[0] : row == 1 ? L[1] : row == 2 ? L[2] : L[3];
                 CTGN_TICK(2)
             } else {
             // ===== generic path: every row probes and streams its own keypoint's neighbourhood =====
             st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
-            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate);
+            const double r2bound = kth_d2;        // the probes are culled against the bound the round starts with
+            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
@@ -813,11 +886,12 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 Probe cur = nxt;
                 const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
-                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate);
+                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound);
                 } else if (r + 1 < rounds) {
                     const int src2 = row * 16 + r + 1;
                     const int kx2 = W.kx[src2];
-                    nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate);
+                    nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
+                                          fmin(map.r2thr, (double) W.kb[src2]));
                     nxt_round = r + 1;
                 }
                 if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(cur.active));
@@ -866,7 +940,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     if (PROF) pc[11] += (unsigned long long) __popcll(__ballot(cnd.valid));
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
                     const double d2 = sq_norm3(dx, dy, dz);
-                    const bool pass = cnd.valid && d2 <= kth_d2;
+                    const bool pass = cnd.valid && d2 <= kth_d2 && !(ablate & 128);
                     const uint32_t pm = row_bits(__ballot(pass), row);
                     if (pass) {
                         const int pos = Ln + __popc(pm & lt_mask);
@@ -905,9 +979,15 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (NB == 1 && blk <= 32 && r + 1 < rounds) {
                 const int src2 = row * 16 + r + 1;
                 const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
-                if (rows_share_home(kx2, ky2, kz2) && !(uniform_home && kx2 == kx && ky2 == ky && kz2 == kz)) {
-                    snxt = probe_issue(map, lane < 27 && !(ablate & 16), kx2 + lane / 9 - 1, ky2 + (lane / 3) % 3 - 1, kz2 + lane % 3 - 1);
-                    snxt_round = r + 1;
+                if (rows_share_home(kx2, ky2, kz2)) {
+                    const unsigned long long need2 = shared_need(r + 1, kx2, ky2, kz2);
+                    if (!(kx2 == st_kx && ky2 == st_ky && kz2 == st_kz && (need2 & ~st_need) == 0ull)) {     // not served by the staged table
+                        const int sv2 = lane < 27 ? (int) c_sweep1.v[lane] : 27;
+                        snxt = probe_issue(map, ((need2 >> lane) & 1ull) && !(ablate & 16), kx2 + sv2 / 9 - 1, ky2 + (sv2 / 3) % 3 - 1,
+                                           kz2 + sv2 % 3 - 1);
+                        snxt_round = r + 1;
+                        snxt_need = need2;
+                    }
                 }
             }
             // B3: final selection -> list sorted ascending, [0..n). A row that ends with fewer than min_number_neighbors (or 5)
@@ -924,7 +1004,11 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 const int kp_r = W.id[src];
                 if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
-                    if (sub == 0) { o[0] = (uint32_t) n; kp.cnt[kp_r] = (uint32_t) n; }
+                    if (sub == 0) {
+                        o[0] = (uint32_t) n; kp.cnt[kp_r] = (uint32_t) n;
+                        // a full, sorted list (Ln >= k implies the selection ran): its last entry is the k-th neighbour
+                        if (kp.kth) kp.kth[kp_r] = (n >= k && !(ablate & 2)) ? __double2float_ru(R.d2[k - 1]) : __int_as_float(0x7f800000);
+                    }
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const int e = sub + 16 * m;

@@ -38,3 +38,15 @@ tot = float(sum(pc[:8])) or 1.0
 print(json.dumps(dict(workload=wl, order=order, kernel_ms=round(ms, 4), launches=n, waves=pc[11], fast_path_rounds=round(pc[8] / max(pc[9], 1), 3),
                       slowest_over_mean=round(pc[10] / (tot / max(pc[11], 1)), 2), probes_per_kp=round(probes / n / len(t), 2),
                       points_per_kp=round(points / n / len(t), 1), phases={k: round(v / tot, 3) for k, v in zip(names, pc[:8])})))
+if os.environ.get("TIMELINE"):
+    tl = s.wave_timeline()
+    tl = tl[(tl[:, 1] > 0)]
+    t0 = tl[:, 0].min()
+    start, end = (tl[:, 0] - t0).astype(float), (tl[:, 1] - t0).astype(float)
+    dur = end - start
+    pct = lambda a: [round(float(np.percentile(a, q)), 0) for q in (0, 10, 50, 90, 99, 100)]
+    print("waves", len(tl), "start pct", pct(start), "end pct", pct(end), "dur pct", pct(dur))
+    blk = np.arange(len(tl)) // 4
+    for x in range(8):
+        m = (blk % 8) == x
+        print("xcd", x, "n", int(m.sum()), "dur med", float(np.median(dur[m])), "end max", float(end[m].max()), "fast rounds", float(tl[m, 2].sum() / max(1, tl[m, 3].sum())))
