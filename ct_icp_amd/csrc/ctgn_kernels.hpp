@@ -711,25 +711,37 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         int st_kx = INT_MIN, st_ky = 0, st_kz = 0, st_P = 0;   // fast path: home voxel whose neighbourhood is staged, its size
         Probe snxt;                                 // fast path: the wave's probes for round snxt_round, already in flight
         int snxt_round = -1;
-        unsigned long long snxt_need = 0, st_need = 0;    // bit i: the i-th nearest sweep voxel is (being) probed / is in the staged table
+        unsigned long long need_next = 0, st_need = 0;    // bit i: the i-th nearest sweep voxel is needed by round need_round / is in the staged table
+        int need_round = -1;
         // Which of the 27 sweep voxels of home voxel (hx, hy, hz) can hold one of the k nearest of some row's keypoint of round rr: those
         // whose box reaches inside that keypoint's admission bound (the radius, or the bound carried over from the previous search —
         // then typically 1-4 voxels instead of 27). Bit i = the i-th nearest sweep voxel, lane i's.
+        // Per axis a voxel offset -1 / 0 / +1 is needed iff the slab of that offset lies within the bound of the row's keypoint (offset 0
+        // always): the product of the three per-axis sets is a superset of the voxels whose box reaches inside the bound — cheap (six
+        // 1-D gaps per row, four readlanes) and exact enough; a superfluous voxel only streams candidates that the bound then rejects.
         auto shared_need = [&](int rr, int hx, int hy, int hz) -> unsigned long long {
             if (ablate & 512) return (1ull << 27) - 1ull;
+            const int s2 = row * 16 + rr;
+            const double bnd = fmin(map.r2thr, (double) W.kb[s2]) * (1.0 + 1e-8) + 1e-12;
+            const double qx_ = W.px[s2], qy_ = W.py[s2], qz_ = W.pz[s2];
+            uint32_t m9 = 0x92u;                                      // bit 3 a + (o + 1): offset 0 of every axis
+            {
+                double g;
+                g = axis_gap(qx_, hx - 1, map.resolution); m9 |= g * g <= bnd ? 0x001u : 0u;
+                g = axis_gap(qx_, hx + 1, map.resolution); m9 |= g * g <= bnd ? 0x004u : 0u;
+                g = axis_gap(qy_, hy - 1, map.resolution); m9 |= g * g <= bnd ? 0x008u : 0u;
+                g = axis_gap(qy_, hy + 1, map.resolution); m9 |= g * g <= bnd ? 0x020u : 0u;
+                g = axis_gap(qz_, hz - 1, map.resolution); m9 |= g * g <= bnd ? 0x040u : 0u;
+                g = axis_gap(qz_, hz + 1, map.resolution); m9 |= g * g <= bnd ? 0x100u : 0u;
+            }
             const int svl = lane < 27 ? (int) c_sweep1.v[lane] : 13;
-            const int vx = hx + svl / 9 - 1, vy = hy + (svl / 3) % 3 - 1, vz = hz + svl % 3 - 1;
+            const uint32_t bx = 1u << (svl / 9), by = 8u << ((svl / 3) % 3), bz = 64u << (svl % 3), want = bx | by | bz;
             bool any_row = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int s2 = j * 16 + rr;
-                const double gx = axis_gap(W.px[s2], vx, map.resolution), gy = axis_gap(W.py[s2], vy, map.resolution),
-                             gz = axis_gap(W.pz[s2], vz, map.resolution);
-                any_row = any_row || gx * gx + gy * gy + gz * gz <= fmin(map.r2thr, (double) W.kb[s2]) * (1.0 + 1e-8) + 1e-12;
-            }
+            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) __builtin_amdgcn_readlane((int) m9, 16 * j) & want) == want;
             return __ballot(any_row && lane < 27);
         };
-        for (int r = 0; r < rounds; ++r) {
+        for (int r = 0; r < ((ablate & 1024) ? 0 : rounds); ++r) {
             const int src = row * 16 + r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
             const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
@@ -747,7 +759,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (uniform_home) {
                 // ===== fast path: shared, flattened neighbourhood =====
                 occ_tab = SH.occ;
-                const unsigned long long need = (snxt_round == r) ? snxt_need : shared_need(r, kx, ky, kz);
+                const unsigned long long need = (need_round == r) ? need_next : shared_need(r, kx, ky, kz);
                 if (!(kx == st_kx && ky == st_ky && kz == st_kz && (need & ~st_need) == 0ull)) {
                     // probe the sweep voxels some row needs, once for the wave: lane i < 27 takes the i-th NEAREST sweep voxel (centre,
                     // faces, edges, corners), so the flattened table starts with the home voxel's points and the first prune of the
@@ -981,12 +993,13 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
                 if (rows_share_home(kx2, ky2, kz2)) {
                     const unsigned long long need2 = shared_need(r + 1, kx2, ky2, kz2);
+                    need_next = need2;
+                    need_round = r + 1;
                     if (!(kx2 == st_kx && ky2 == st_ky && kz2 == st_kz && (need2 & ~st_need) == 0ull)) {     // not served by the staged table
                         const int sv2 = lane < 27 ? (int) c_sweep1.v[lane] : 27;
                         snxt = probe_issue(map, ((need2 >> lane) & 1ull) && !(ablate & 16), kx2 + sv2 / 9 - 1, ky2 + (sv2 / 3) % 3 - 1,
                                            kz2 + sv2 % 3 - 1);
                         snxt_round = r + 1;
-                        snxt_need = need2;
                     }
                 }
             }
