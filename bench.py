@@ -700,6 +700,48 @@ def cpu_baseline(inp, pose0, world0, args, om=None):
     t0 = time.perf_counter()
     pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=1)
     robust_ms = (time.perf_counter() - t0) * 1e3
+    # M2 (frames/s): one whole Register(solver GN) on the reference's keypoint count (1.5 m grid of the 0.5 m-subsampled sweep), driving
+    # profile (5 iterations, stop at ||x|| < 0.1) — the same call measure_frames_per_sec times through the C ABI. Port: the oracle on 1
+    # thread (the reference's GN keypoint loop is serial) and on `cores`; reference: the reference's own Register compiled from its
+    # sources (oracle/_ref, built by __graft_entry__.build(); GN runs on one thread there too, ct_icp.cpp:753).
+    se3_ = __import__("ct_icp_amd.se3", fromlist=["x"])
+    pose_f = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
+    raw_f, t_f = inp["raw"][sel], inp["t"][sel]
+    world_f = se3_.ct_transform(pose_f, inp["tbe"], t_f, raw_f)
+    of = orc.Options(num_iters_icp=5, threshold_orientation_norm=0.1)
+
+    def frame_ms(threads, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, _, sf = orc.register_gn(om, raw_f, world_f, t_f, pose_f, inp["tbe"], of, prior, heap_mode=0, num_threads=threads)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts)), sf
+    f1, sf1 = frame_ms(1, 5)
+    fn, _ = frame_ms(cores, 5)
+    frames = {"keypoints": int(len(sel)), "gn_iterations": int(sf1.num_iters),
+              "port": {"ms_per_frame_1_thread": f1, "frames_per_sec_1_thread": 1e3 / f1, "ms_per_frame": fn, "frames_per_sec": 1e3 / fn, "cores": cores}}
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            t0 = time.perf_counter()
+            rmap = oref.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
+            for s0 in range(0, len(inp["map_points"]), 2_000_000):
+                rmap.insert(inp["map_points"][s0:s0 + 2_000_000])
+            build_s = time.perf_counter() - t0
+            ropt = oref.Options(solver="GN", num_iters_icp=5, threshold_orientation_norm=0.1)
+            rprior = oref.Prior(previous_pose=np.concatenate([[0, 0, 0, 1], inp["prev_b"], [0, 0, 0, 1], inp["prev_e"]]).astype(np.float64))
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                pose_ref, _, s_ref = oref.register(rmap, raw_f, world_f, t_f, pose_f, inp["tbe"], ropt, rprior)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            frames["reference"] = {"ms_per_frame": float(np.median(ts)), "frames_per_sec": 1e3 / float(np.median(ts)), "cores": 1,
+                                   "gn_iterations": int(s_ref.num_iters), "map_build_seconds": build_s,
+                                   "what": "CT_ICP_Registration::Register of the reference's own sources (oracle/_ref/libctgn_ref.so, "
+                                           "compiled against header shims), its MultipleResolutionVoxelMap holding the same map points"}
+    except Exception as e:        # noqa: BLE001 — the reference build is optional on a box
+        frames["reference"] = {"unavailable": f"{type(e).__name__}: {e}"}
     # the steps either side of the path on one core, as the reference runs them (only its undistortion loop is OpenMP)
     om2 = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
     om2.insert(inp["map_points"])
@@ -713,7 +755,7 @@ def cpu_baseline(inp, pose0, world0, args, om=None):
     t3 = time.perf_counter()
     stages = {"grid_sampling_ms": (t1 - t0) * 1e3, "undistortion_ms": (t2 - t1) * 1e3, "map_update_ms": (t3 - t2) * 1e3,
               "cores": f"1 (undistortion: {cores}, the reference's OpenMP loop)", "sampled": int(len(keep)), "inserted": int(np.count_nonzero(kept)), "map_points_after": int(om2.num_points())}
-    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port", "frame_stages": stages,
+    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port", "frame_stages": stages, "frames_per_sec": frames,
             "reference_shaped": {"value": ref_n, "single_thread_value": ref_1, "cores": cores,
                                  "note": "accumulation pass only (search + normal + residual + sums), std::unordered_map<Voxel, "
                                          "vector<80 B record>> + std::priority_queue: the reference's container shapes"},
