@@ -1,6 +1,6 @@
 /*
  * ctgn_oracle.c — CPU restatement of the reference's GN CT-ICP path. See ctgn_oracle.h for the status
- * of this file (test infrastructure only; PARITY UNPINNED) and for what is restated from third parties.
+ * of this file (test infrastructure only; parity pinned against oracle/_ref) and for what is restated from third parties.
  *
  * Every function cites the reference lines it follows (paths relative to the reference root).
  */

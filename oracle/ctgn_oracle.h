@@ -5,13 +5,17 @@
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, __graft_entry__.smoke() and bench.py's
  * `cpu_baseline` leg may build, load or call it. Nothing under ct_icp_amd/ links or imports it.
  *
- * PARITY UNPINNED: the reference cannot be compiled here (Eigen, Ceres, glog, tsl::robin_map, yaml-cpp
- * absent, no network) and its own tests hold no golden vectors for this path (TEST(CT_ICP, GN) is an
- * empty body, reference test/unit/ct_icp/test_ct_icp.cxx:10-12). The oracle is therefore pinned only by
- * (i) the property tests the reference does have (test_map.cxx:25-36, test_neighborhood.cxx:40-53,
- * test_cost_functions.cxx:70-105, test_types.cxx:20-31), re-expressed in tests/test_oracle_*.py,
- * (ii) an independent NumPy/SciPy re-derivation (oracle/numpy_check.py) and (iii) recovery of a known
- * ground-truth pose on noise-free synthetic planes.
+ * PARITY PINNED (since round 2) against the reference's own sources: `make -C oracle _ref` compiles
+ * src/ct_icp/{ct_icp,map,motion_model,cost_function,neighborhood_strategy}.cpp and the SlamCore sources they need,
+ * where they lie under /root/reference, against header stand-ins for the absent libraries (oracle/shims/: mini-Eigen,
+ * glog, tsl::robin_map, mini-Ceres) into oracle/_ref/libctgn_ref.so; tests/test_oracle_vs_ref.py holds every function
+ * of this file to it (neighbour lists and ties bit-identical, poses to ~1e-16, both routes). The reference's own
+ * tests hold no golden vectors for this path (TEST(CT_ICP, GN) is an empty body, test/unit/ct_icp/test_ct_icp.cxx:10-12).
+ * Earlier anchors kept: (i) the property tests the reference does have (test_map.cxx:25-36,
+ * test_neighborhood.cxx:40-53, test_cost_functions.cxx:70-105, test_types.cxx:20-31), re-expressed in
+ * tests/test_oracle_*.py, (ii) an independent NumPy/SciPy re-derivation (oracle/numpy_check.py) and (iii) recovery
+ * of a known ground-truth pose on noise-free synthetic planes. What the pin does not cover: the stand-ins themselves
+ * (Eigen's JacobiSVD / LDLT and Ceres' trust-region loop are restated there too) — DESIGN.md section 12.
  *
  * Third-party arithmetic restated from published algorithms: Eigen 3 (unpinned `master` in the
  * reference's superbuild, superbuild/CMakeLists.txt:20-24) — Quaternion::slerp, Quaternion*Vector3,

@@ -3,7 +3,9 @@
  * CT_ICP_Registration::DoRegisterCeres (reference src/ct_icp/ct_icp.cpp:457-707) for
  * parametrization = CONTINUOUS_TIME, distance = POINT_TO_PLANE — the configuration every shipped config selects.
  *
- * TEST INFRASTRUCTURE ONLY (see ctgn_oracle.h). PARITY UNPINNED, and more so than the GN path: the inner solver of
+ * TEST INFRASTRUCTURE ONLY (see ctgn_oracle.h). Pinned against oracle/_ref (the reference's DoRegisterCeres and cost
+ * functors on a restated Ceres: tests/test_oracle_vs_ref.py, 5 losses x 4 configurations, poses to ~1e-16) — which pins
+ * this file to the reference's code, NOT to a real Ceres build: the inner solver of
  * this route is the third-party Ceres Solver (pulled in through an external superbuild at `master`,
  * superbuild/CMakeLists.txt:20-33 — version unpinned; absent from the reference tree and from this image).
  * Restated here from its published algorithm:

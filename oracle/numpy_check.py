@@ -1,6 +1,6 @@
 """Independent NumPy/SciPy re-derivation of one GN iteration of the reference's CT-ICP
-(src/ct_icp/ct_icp.cpp:745-981) — TEST INFRASTRUCTURE, used to pin oracle/ctgn_oracle.c (which is otherwise
-"parity unpinned": the reference cannot be built here and ships no golden vectors for this path).
+(src/ct_icp/ct_icp.cpp:745-981) — TEST INFRASTRUCTURE, round 1's anchor of oracle/ctgn_oracle.c (the reference ships no
+golden vectors for this path; since round 2 the oracle is also held to the reference's own sources, oracle/_ref).
 
 It deliberately shares no code with the C oracle or with ct_icp_amd: brute-force neighbour search over the
 exported map points, numpy.linalg.svd for the normal (the reference uses Eigen::JacobiSVD), numpy.linalg.solve

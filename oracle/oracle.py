@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 Nothing under ct_icp_amd/ may import this module (tests/test_layout.py enforces it).
-PARITY UNPINNED — see oracle/ctgn_oracle.h.
+Parity pinned against oracle/_ref (the reference's own sources) — see oracle/ctgn_oracle.h.
 """
 from __future__ import annotations
 
