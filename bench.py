@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip frames/s, robust route, frame stages")
     ap.add_argument("--clock-warm", type=int, default=CLOCK_WARM)
     ap.add_argument("--inner", action="store_true", help="the run the PMC passes profile: timed loop only, no extras")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the all-reduce goes "
+                         "through torch.distributed on the host; numbers are not scaling numbers)")
     args = ap.parse_args()
     if args.inner:
         args.no_pmc = args.no_cpu_baseline = args.no_extras = True
@@ -213,6 +216,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.workload is None:
         args.workload = "B2" if world == 1 else "D"
+    if args.dist_backend == "gloo":
+        args.torch_collective = True
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_dist
@@ -220,7 +226,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ------------------------------------------------------------------------------------------------ inputs
     if args.workload == "D":
@@ -413,7 +422,8 @@ def main():
                        "keypoints_per_gpu": n_kp, "keypoints_total": total_kp, "map_points": int(gm.NumPoints()),
                        "map_voxels": int(gm.NumVoxels(0)), "searched_level_mb": level_mb, "n_used_last_iter": summ.num_residuals_used,
                        "parallelism": "single GPU" if world == 1 else f"keypoints sharded x{world} (home-voxel sort, contiguous chunks), map replicated, "
-                                                                      "1 ncclAllReduce(96 f64) per iteration issued by the library",
+                                                                      + ("1 ncclAllReduce(96 f64) per iteration issued by the library" if not args.torch_collective else
+                                                                         f"1 torch.distributed all_reduce(96 f64) per iteration, backend {args.dist_backend}"),
                        "kernel_variant": args.variant, "keypoint_ordering": args.order},
             "clock_warmup_iterations": args.clock_warm,
             "clock_warmup_note": "untimed iterations of the same running GN loop immediately before the W warm-up and K timed steps (no upload in "
@@ -478,10 +488,18 @@ def main():
         wp0 = syn.perturb_pose(winp["pose_gt"], 0.003, 0.03, seed=4)
         shw.set_keypoints(winp["raw"], se3.ct_transform(wp0, winp["tbe"], winp["t"], winp["raw"]), winp["t"])
         shw.solver.gn_begin(wp0, winp["tbe"], options(args.clock_warm + args.steps), None)
-        shw.solver.gn_iterate(args.clock_warm, sharded=True)
+        def iterate_w(k):
+            if args.torch_collective:
+                for _ in range(k):
+                    shw.solver.gn_accumulate()
+                    allreduce_system(shw.system)
+                    shw.solver.gn_solve_update()
+            else:
+                shw.solver.gn_iterate(k, sharded=True)
+        iterate_w(args.clock_warm)
         sync_all()
         t0 = time.perf_counter()
-        shw.solver.gn_iterate(args.steps, sharded=True)
+        iterate_w(args.steps)
         sync_all()
         dw = time.perf_counter() - t0
         shw.solver.gn_end()
