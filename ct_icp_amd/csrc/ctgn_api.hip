@@ -1604,7 +1604,7 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     auto &F = h->fr;
     HIPCHK(h, hipStreamSynchronize(h->stream));       // pinned staging reuse
     {
-        ctgn_status rs = frame_reserve(h, n);
+        ctgn_status rs = frame_reserve(h, std::max<size_t>(n, 1));     // an empty scan still stages the pose
         if (rs != CTGN_OK) return rs;
         DMCHK(h, devmap_scratch_reserve(h->dm, std::max<size_t>(n, 1)));
     }

@@ -791,6 +791,68 @@ def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
     assert np.array_equal(b["all_world"], want)
 
 
+def test_frame_pipeline_edge_cases(street_case):
+    """ctgn_frame_register on the inputs a caller can throw at it: an empty scan, no sub-sampling at all (every point a keypoint),
+    the keypoint cap, float32 and strided (WPoint3D-shaped) views through the C ABI directly, and a second call on the same handle with
+    a larger scan (scratch growth)."""
+    import ctypes as C
+    from ct_icp_amd import _lib as L
+    case = street_case
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius,
+                                                device_updates=True))
+    o = _opts(num_iters_icp=3, min_number_neighbors=10)
+    o0 = _opts(num_iters_icp=0)
+    fp = cia.FramePipeline(gm, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    for j in range(4):                                                     # a map to register against
+        sc = case["scans"][j]
+        fp.frame(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o0, 60.0, want_all=False)
+    sc = case["scans"][4]
+    # empty scan: a soft failure of the registration (no keypoints), nothing inserted, the map untouched
+    before = gm.NumPoints()
+    r = fp.register(np.zeros((0, 3)), np.zeros(0), sc.pose_gt, sc.t_begin_end, o)
+    assert not r["summary"].success and len(r["sampled_indices"]) == 0 and r["all_world"].shape == (0, 3)
+    fp.update_map(sc.pose_gt[11:14], 1e9, True)                        # nothing to evict at this distance, nothing to insert
+    assert gm.NumPoints() == before
+    # a small scan first, then the full one on the same handle (the frame scratch grows), no sub-sampling: every point is a keypoint
+    fp_all = cia.FramePipeline(gm, frame_voxel_size=0.0, sample_voxel_size=0.0)
+    sub = np.sort(cia.grid_sampling(gm, sc.raw, 1.0))
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=3)
+    r = fp_all.register(sc.raw[sub], sc.t[sub], pose0, sc.t_begin_end, o)
+    assert np.array_equal(r["sampled_indices"], np.arange(len(sub))) and np.array_equal(r["keypoint_indices"], np.arange(len(sub)))
+    s = cia.GnSolver(gm)
+    s.set_keypoints(sc.raw[sub], cia.transform_points(gm, sc.raw[sub], sc.t[sub], pose0, sc.t_begin_end), sc.t[sub])
+    pose_ref, summ_ref, _ = s.solve(pose0, sc.t_begin_end, o)
+    assert np.array_equal(r["pose"], pose_ref) and r["summary"].num_residuals_used == summ_ref.num_residuals_used
+    # the keypoint cap keeps the first max_num_keypoints keypoints (odometry.cpp:549-552)
+    fp_cap = cia.FramePipeline(gm, frame_voxel_size=0.5, sample_voxel_size=0.7, max_num_keypoints=300)
+    full = fp.register(sc.raw, sc.t, pose0, sc.t_begin_end, o)
+    capped = fp_cap.register(sc.raw, sc.t, pose0, sc.t_begin_end, o)
+    assert len(full["keypoint_indices"]) > 300 and np.array_equal(capped["keypoint_indices"], full["keypoint_indices"][:300])
+    assert np.array_equal(capped["sampled_indices"], full["sampled_indices"])
+    # float32 xyz + float32 t inside 64-byte records (a WPoint3D-like layout), straight through the C ABI
+    n = len(sc.t)
+    rec = np.zeros(n, dtype=np.dtype({"names": ["xyz", "t", "pad"], "formats": [("<f4", 3), "<f4", ("<f4", 12)], "itemsize": 64}))
+    rec["xyz"], rec["t"] = sc.raw.astype(np.float32), sc.t.astype(np.float32)
+    t32 = rec["t"].astype(np.float64)
+    tbe = np.array([min(sc.t_begin_end[0], t32.min()), max(sc.t_begin_end[1], t32.max())])
+    fo = L.FrameOptions(0.5, 0.7, -1, 0, 0.0)
+    out = L.FrameOutputs()
+    allw = np.zeros((n, 3), dtype=np.float32)
+    out.all_world_base, out.all_world_stride_bytes, out.all_world_dtype = allw.ctypes.data, 12, L.CTGN_F32
+    pose = pose0.copy()
+    summ = L.Summary()
+    dp = C.POINTER(C.c_double)
+    c_o = cia.registration._c_options(o)
+    st = L.lib().ctgn_frame_register(gm.handle, L.View(rec.ctypes.data, 64, L.CTGN_F32, 0), L.View(rec.ctypes.data + 12, 64, L.CTGN_F32, 0), n, None,
+                                     C.byref(fo), pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(c_o), None, None, None,
+                                     C.byref(out), C.byref(summ))
+    L.check(gm.handle, st)
+    want = fp.register(rec["xyz"].astype(np.float64), t32, pose0, tbe, o)
+    assert np.array_equal(pose, want["pose"]) and out.num_keypoints == len(want["keypoint_indices"])
+    assert np.array_equal(allw, want["all_world"].astype(np.float32))
+
+
 def test_config_e_two_sequences_on_one_gpu(street_case):
     """SURVEY.md 8d config E (one sequence per GPU, zero communication) through ct_icp_amd.sequence_runner on ONE GPU with two
     sequences: every frame is one ctgn_frame call; each sequence owns its map and handle, so a sequence's trajectory does not depend
