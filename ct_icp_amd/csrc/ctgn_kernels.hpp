@@ -464,7 +464,6 @@ struct RowProbe {
 // stays valid for the following rounds with the same home voxel (keypoints are sorted by home voxel on upload).
 constexpr int STAGE_CAP = 27 * 32;
 struct SharedStage {
-    uint32_t off[STAGE_CAP];  // byte offset of candidate c's x in the block storage
     uint16_t vis[STAGE_CAP];  // its visit index (sweep voxel << 6) | slot
     uint32_t occ[28];         // block*128 + count per sweep voxel
     uint2 chunk[56];          // .x = byte offset of the chunk's first x; .y = (visit base << 15) | (flat position << 5) | points
@@ -476,6 +475,7 @@ struct WaveScratch {
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
     int id[64];                        // its index in the caller's arrays; -1 = none
     float kb[64];                      // admission bound of its search (squared distance, rounded up); +inf = the radius only
+    uint8_t m6[64];                    // per axis, whether the voxel offsets -1 / +1 of its home voxel reach inside that bound (bit 2 a + (o + 1) / 2)
     union {
         struct {
             RowList list[4];
@@ -671,6 +671,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (pos < kp.n) my_kp = kp.order ? (int) kp.order[pos] : pos;
         }
         const bool own = my_kp >= 0;
+        uint32_t uni16 = 0;
         {
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
@@ -702,6 +703,27 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
         W.id[lane] = my_kp;
         W.kb[lane] = kbv;
+        // Per axis a voxel offset -1 / 0 / +1 is needed iff the slab of that offset lies within the keypoint's bound (offset 0 always):
+        // the product of the three per-axis sets is a superset of the sweep voxels whose box reaches inside the bound — a superfluous
+        // voxel only streams candidates that the bound then rejects. Once per keypoint, here, where every lane has its own.
+        uint32_t m6 = 0u;
+        if (NB == 1 && kxv != INT_MIN) {
+            const double bnd = fmin(map.r2thr, (double) kbv) * (1.0 + 1e-8) + 1e-12;
+            double g;
+            g = axis_gap(p.x, kxv - 1, map.resolution); m6 |= g * g <= bnd ? 0x01u : 0u;
+            g = axis_gap(p.x, kxv + 1, map.resolution); m6 |= g * g <= bnd ? 0x02u : 0u;
+            g = axis_gap(p.y, kyv - 1, map.resolution); m6 |= g * g <= bnd ? 0x04u : 0u;
+            g = axis_gap(p.y, kyv + 1, map.resolution); m6 |= g * g <= bnd ? 0x08u : 0u;
+            g = axis_gap(p.z, kzv - 1, map.resolution); m6 |= g * g <= bnd ? 0x10u : 0u;
+            g = axis_gap(p.z, kzv + 1, map.resolution); m6 |= g * g <= bnd ? 0x20u : 0u;
+        }
+        W.m6[lane] = (uint8_t) ((ablate & 512) ? 0x3fu : m6);
+        // rounds whose four keypoints live in the same (valid) home voxel: bit r of uni16
+        {
+            const bool same = kxv != INT_MIN && kxv == __shfl(kxv, sub) && kyv == __shfl(kyv, sub) && kzv == __shfl(kzv, sub);
+            const unsigned long long um = __ballot(same);
+            uni16 = (uint32_t) (um & (um >> 16) & (um >> 32) & (um >> 48)) & 0xffffu;
+        }
         }
         CTGN_TICK(0)
 
@@ -713,32 +735,16 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         int snxt_round = -1;
         unsigned long long need_next = 0, st_need = 0;    // bit i: the i-th nearest sweep voxel is needed by round need_round / is in the staged table
         int need_round = -1;
-        // Which of the 27 sweep voxels of home voxel (hx, hy, hz) can hold one of the k nearest of some row's keypoint of round rr: those
-        // whose box reaches inside that keypoint's admission bound (the radius, or the bound carried over from the previous search —
-        // then typically 1-4 voxels instead of 27). Bit i = the i-th nearest sweep voxel, lane i's.
-        // Per axis a voxel offset -1 / 0 / +1 is needed iff the slab of that offset lies within the bound of the row's keypoint (offset 0
-        // always): the product of the three per-axis sets is a superset of the voxels whose box reaches inside the bound — cheap (six
-        // 1-D gaps per row, four readlanes) and exact enough; a superfluous voxel only streams candidates that the bound then rejects.
-        auto shared_need = [&](int rr, int hx, int hy, int hz) -> unsigned long long {
-            if (ablate & 512) return (1ull << 27) - 1ull;
-            const int s2 = row * 16 + rr;
-            const double bnd = fmin(map.r2thr, (double) W.kb[s2]) * (1.0 + 1e-8) + 1e-12;
-            const double qx_ = W.px[s2], qy_ = W.py[s2], qz_ = W.pz[s2];
-            uint32_t m9 = 0x92u;                                      // bit 3 a + (o + 1): offset 0 of every axis
-            {
-                double g;
-                g = axis_gap(qx_, hx - 1, map.resolution); m9 |= g * g <= bnd ? 0x001u : 0u;
-                g = axis_gap(qx_, hx + 1, map.resolution); m9 |= g * g <= bnd ? 0x004u : 0u;
-                g = axis_gap(qy_, hy - 1, map.resolution); m9 |= g * g <= bnd ? 0x008u : 0u;
-                g = axis_gap(qy_, hy + 1, map.resolution); m9 |= g * g <= bnd ? 0x020u : 0u;
-                g = axis_gap(qz_, hz - 1, map.resolution); m9 |= g * g <= bnd ? 0x040u : 0u;
-                g = axis_gap(qz_, hz + 1, map.resolution); m9 |= g * g <= bnd ? 0x100u : 0u;
-            }
+        // Which of the 27 sweep voxels of the shared home voxel can hold one of the k nearest of some row's keypoint of round rr: those in
+        // the product of that keypoint's per-axis offset sets (W.m6, phase A; with a carried-over bound typically 1-4 voxels instead of 27).
+        // Bit i = the i-th nearest sweep voxel, lane i's.
+        auto shared_need = [&](int rr) -> unsigned long long {
             const int svl = lane < 27 ? (int) c_sweep1.v[lane] : 13;
-            const uint32_t bx = 1u << (svl / 9), by = 8u << ((svl / 3) % 3), bz = 64u << (svl % 3), want = bx | by | bz;
+            const int ox = svl / 9, oy = (svl / 3) % 3, oz = svl % 3;                 // 0 / 1 / 2 = offset -1 / 0 / +1 (0 needs no bit)
+            const uint32_t want = (ox == 1 ? 0u : 1u << (ox >> 1)) | (oy == 1 ? 0u : 4u << (oy >> 1)) | (oz == 1 ? 0u : 16u << (oz >> 1));
             bool any_row = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) __builtin_amdgcn_readlane((int) m9, 16 * j) & want) == want;
+            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) W.m6[j * 16 + rr] & want) == want;
             return __ballot(any_row && lane < 27);
         };
         for (int r = 0; r < ((ablate & 1024) ? 0 : rounds); ++r) {
@@ -752,14 +758,14 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
-            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
+            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && ((uni16 >> r) & 1u);
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
             if (uniform_home) {
                 // ===== fast path: shared, flattened neighbourhood =====
                 occ_tab = SH.occ;
-                const unsigned long long need = (need_round == r) ? need_next : shared_need(r, kx, ky, kz);
+                const unsigned long long need = (need_round == r) ? need_next : shared_need(r);
                 if (!(kx == st_kx && ky == st_ky && kz == st_kz && (need & ~st_need) == 0ull)) {
                     // probe the sweep voxels some row needs, once for the wave: lane i < 27 takes the i-th NEAREST sweep voxel (centre,
                     // faces, edges, corners), so the flattened table starts with the home voxel's points and the first prune of the
@@ -793,7 +799,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                             const uint2 ch = SH.chunk[c];
                             const uint32_t n16 = ch.y & 31u, dest = (ch.y >> 5) & 1023u, visb = ch.y >> 15;
                             if ((uint32_t) sub < n16) {
-                                SH.off[dest + sub] = ch.x + 8u * (uint32_t) sub;
                                 SH.vis[dest + sub] = (uint16_t) (visb + (uint32_t) sub);
                             }
                         }
@@ -824,8 +829,10 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     const int c = c0 + lane;
                     o.valid = c < st_P;
                     const int cc = o.valid ? c : 0;
-                    const uint32_t off = o.valid ? SH.off[cc] : 0u;       // masked lanes read the start of the block storage
                     o.vis = SH.vis[cc];
+                    // the candidate's byte offset from its visit index: block of its sweep voxel + slot (no offset table in LDS: the
+                    // 3.4 KB it took per wave are what kept the block under the CU's LDS at three blocks)
+                    const uint32_t off = o.valid ? (SH.occ[o.vis >> 6] >> 7) * stride3 + (o.vis & 63u) * 8u : 0u;   // masked lanes read the start of the block storage
                     o.x = *reinterpret_cast<const double *>(pbase + off);
                     o.y = *reinterpret_cast<const double *>(pbase_y + off);
                     o.z = *reinterpret_cast<const double *>(pbase_z + off);
@@ -991,8 +998,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (NB == 1 && blk <= 32 && r + 1 < rounds) {
                 const int src2 = row * 16 + r + 1;
                 const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
-                if (rows_share_home(kx2, ky2, kz2)) {
-                    const unsigned long long need2 = shared_need(r + 1, kx2, ky2, kz2);
+                if (!(ablate & 32) && ((uni16 >> (r + 1)) & 1u)) {
+                    const unsigned long long need2 = shared_need(r + 1);
                     need_next = need2;
                     need_round = r + 1;
                     if (!(kx2 == st_kx && ky2 == st_ky && kz2 == st_kz && (need2 & ~st_need) == 0ull)) {     // not served by the staged table
