@@ -671,7 +671,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (pos < kp.n) my_kp = kp.order ? (int) kp.order[pos] : pos;
         }
         const bool own = my_kp >= 0;
-        uint32_t uni16 = 0;
         {
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
@@ -718,12 +717,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             g = axis_gap(p.z, kzv + 1, map.resolution); m6 |= g * g <= bnd ? 0x20u : 0u;
         }
         W.m6[lane] = (uint8_t) ((ablate & 512) ? 0x3fu : m6);
-        // rounds whose four keypoints live in the same (valid) home voxel: bit r of uni16
-        {
-            const bool same = kxv != INT_MIN && kxv == __shfl(kxv, sub) && kyv == __shfl(kyv, sub) && kzv == __shfl(kzv, sub);
-            const unsigned long long um = __ballot(same);
-            uni16 = (uint32_t) (um & (um >> 16) & (um >> 32) & (um >> 48)) & 0xffffu;
-        }
         }
         CTGN_TICK(0)
 
@@ -758,7 +751,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
-            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && ((uni16 >> r) & 1u);
+            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
@@ -998,7 +991,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             if (NB == 1 && blk <= 32 && r + 1 < rounds) {
                 const int src2 = row * 16 + r + 1;
                 const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
-                if (!(ablate & 32) && ((uni16 >> (r + 1)) & 1u)) {
+                if (!(ablate & 32) && rows_share_home(kx2, ky2, kz2)) {
                     const unsigned long long need2 = shared_need(r + 1);
                     need_next = need2;
                     need_round = r + 1;
