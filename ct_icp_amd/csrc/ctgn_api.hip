@@ -637,8 +637,15 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
 }
 
 ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
-    hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
-                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
+    // measurement hook (CTGN_SOLVE_SMALL=1): a 4-wave block for <= 128 partial columns. Slower on the B1 frame (0.0425 vs 0.0404 ms per
+    // iteration: the reduce is one trip to 96 freshly written lines, and four waves have a quarter of the loads in flight), so off.
+    static const int env_small = [] { const char *e = std::getenv("CTGN_SOLVE_SMALL"); return e ? std::atoi(e) : 0; }();
+    if (env_small == 1 && h->last_grid <= 128)
+        hipLaunchKernelGGL(k_reduce_solve<256>, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state, h->prm, mode,
+                           CTGN_MIN_KEYPOINTS_USED);
+    else
+        hipLaunchKernelGGL(k_reduce_solve<SOLVE_BLOCK>, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
+                           h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
     HIPCHK(h, hipGetLastError());
     return CTGN_OK;
 }

@@ -1253,9 +1253,12 @@ struct SolveScratch {                 // LDS of the 12 x 12 solve (wave 0)
 // Sum of the per-block partials of the packed system, 16 waves: wave w owns entries w, w+16, ..., w+80 — six independent
 // lane-strided sums (a lane takes blocks 2 lane and 2 lane + 1 of each 128-block span; 16-byte loads, all in flight together), then
 // six fixed shuffle trees. `load2(entry, b)` returns the partials of blocks b and b + 1 (b even). Deterministic.
-template <typename Load2>
+// NW waves share the 96 entries (wave w owns w, w + NW, ...); the lane -> block assignment and the shuffle tree of an entry do not
+// depend on NW, so every NW gives the same sums bit for bit.
+template <int NW, int RU, typename Load2>
 __device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wave, int lane, double *sys_global, double *s_sys) {
-    constexpr int EPW = SYS_N / (SOLVE_BLOCK / 64), RU = 3;
+    constexpr int EPW = SYS_N / NW;
+    static_assert(SYS_N % NW == 0, "entries split evenly over the waves");
     double acc[EPW];
 #pragma unroll
     for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
@@ -1266,7 +1269,7 @@ __device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wa
             const int b = b0 + 128 * u + 2 * lane;
             const int bb = b < nblocks ? b : 0;
 #pragma unroll
-            for (int q = 0; q < EPW; ++q) v[u][q] = load2(wave + 16 * q, bb);
+            for (int q = 0; q < EPW; ++q) v[u][q] = load2(wave + NW * q, bb);
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
@@ -1281,7 +1284,7 @@ __device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wa
 #pragma unroll
     for (int q = 0; q < EPW; ++q) {
         const double s = wave_sum_fixed(acc[q]);
-        if (lane == 0) { sys_global[wave + 16 * q] = s; s_sys[wave + 16 * q] = s; }
+        if (lane == 0) { sys_global[wave + NW * q] = s; s_sys[wave + NW * q] = s; }
     }
 }
 
@@ -1469,15 +1472,20 @@ __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const 
     st->ticks_solve += wall1 - wall0;
 }
 
-__global__ __launch_bounds__(SOLVE_BLOCK) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
-                                                              GnParams prm, int mode, int min_used) {
+// BLKS = 1024 (16 waves, three 128-block spans in flight per pass) for the thousands of partial columns of a large scan; BLKS = 256
+// (4 waves, 24 entries each, one span) when a small frame leaves at most 128 columns: a quarter of the waves to dispatch and to meet
+// at the barrier before the solve can start.
+template <int BLKS>
+__global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
+                                                       GnParams prm, int mode, int min_used) {
     __shared__ SolveScratch S;
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tc0 = __builtin_readcyclecounter();
     const unsigned long long wall0 = wall_clock64();
     if (mode != 2) {
-        reduce_partials([&](int e, int b) { return *reinterpret_cast<const double2 *>(partials + (size_t) e * MAX_PARTIAL_BLOCKS + b); },
+        reduce_partials<BLKS / 64, (BLKS == SOLVE_BLOCK ? 3 : 1)>(
+                        [&](int e, int b) { return *reinterpret_cast<const double2 *>(partials + (size_t) e * MAX_PARTIAL_BLOCKS + b); },
                         nblocks, wave, lane, sys, S.sys);
     } else {
         if (tid < SYS_N) S.sys[tid] = sys[tid];
