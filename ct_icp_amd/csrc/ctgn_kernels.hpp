@@ -423,15 +423,22 @@ __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
 // among the k nearest within the radius, map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
 template <int NB>
 __device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
-                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound) {
+                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound, uint32_t mreach) {
     constexpr int S = 2 * NB + 1;
     const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
     v_out = v;
     const int vv = (v == 255) ? 0 : v;
-    const int vx = kx + vv / (S * S) - NB, vy = ky + (vv / S) % S - NB, vz = kz + vv % S - NB;
-    const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
-    const bool reachable = (ablate & 64) || gx * gx + gy * gy + gz * gz <= r2bound * (1.0 + 1e-8) + 1e-12;
-    return probe_issue(m, searching && v != 255 && reachable && !(ablate & 16), vx, vy, vz);
+    const int ox = vv / (S * S) - NB, oy = (vv / S) % S - NB, oz = vv % S - NB;
+    const int vx = kx + ox, vy = ky + oy, vz = kz + oz;
+    // per-axis slab test first (the keypoint's reach mask, phase A: three bit tests): a voxel outside the box of reachable slabs is
+    // outside the sphere; only the others pay for the exact test. With a carried-over bound most of a 125-voxel sweep stops here.
+    bool reachable = searching && v != 255 &&
+                     ((mreach >> (ox + 2)) & (mreach >> (5 + oy + 2)) & (mreach >> (10 + oz + 2)) & 1u) != 0u;
+    if (reachable && !(ablate & 64)) {
+        const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
+        reachable = gx * gx + gy * gy + gz * gz <= r2bound * (1.0 + 1e-8) + 1e-12;
+    }
+    return probe_issue(m, reachable && !(ablate & 16), vx, vy, vz);
 }
 
 // the 16 ballot bits of DPP row `row`
@@ -475,7 +482,7 @@ struct WaveScratch {
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
     int id[64];                        // its index in the caller's arrays; -1 = none
     float kb[64];                      // admission bound of its search (squared distance, rounded up); +inf = the radius only
-    uint8_t m6[64];                    // per axis, whether the voxel offsets -1 / +1 of its home voxel reach inside that bound (bit 2 a + (o + 1) / 2)
+    uint16_t mr[64];                   // per axis, which voxel offsets -2 .. +2 of its home voxel reach inside that bound (bit 5 a + o + 2)
     union {
         struct {
             RowList list[4];
@@ -705,18 +712,19 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         // Per axis a voxel offset -1 / 0 / +1 is needed iff the slab of that offset lies within the keypoint's bound (offset 0 always):
         // the product of the three per-axis sets is a superset of the sweep voxels whose box reaches inside the bound — a superfluous
         // voxel only streams candidates that the bound then rejects. Once per keypoint, here, where every lane has its own.
-        uint32_t m6 = 0u;
-        if (NB == 1 && kxv != INT_MIN) {
+        uint32_t mr = 0x1084u;                     // offset 0 of every axis
+        if (kxv != INT_MIN) {
             const double bnd = fmin(map.r2thr, (double) kbv) * (1.0 + 1e-8) + 1e-12;
-            double g;
-            g = axis_gap(p.x, kxv - 1, map.resolution); m6 |= g * g <= bnd ? 0x01u : 0u;
-            g = axis_gap(p.x, kxv + 1, map.resolution); m6 |= g * g <= bnd ? 0x02u : 0u;
-            g = axis_gap(p.y, kyv - 1, map.resolution); m6 |= g * g <= bnd ? 0x04u : 0u;
-            g = axis_gap(p.y, kyv + 1, map.resolution); m6 |= g * g <= bnd ? 0x08u : 0u;
-            g = axis_gap(p.z, kzv - 1, map.resolution); m6 |= g * g <= bnd ? 0x10u : 0u;
-            g = axis_gap(p.z, kzv + 1, map.resolution); m6 |= g * g <= bnd ? 0x20u : 0u;
+#pragma unroll
+            for (int o = -NB; o <= NB; ++o) {
+                if (o == 0) continue;
+                double g;
+                g = axis_gap(p.x, kxv + o, map.resolution); mr |= g * g <= bnd ? 1u << (o + 2) : 0u;
+                g = axis_gap(p.y, kyv + o, map.resolution); mr |= g * g <= bnd ? 1u << (5 + o + 2) : 0u;
+                g = axis_gap(p.z, kzv + o, map.resolution); mr |= g * g <= bnd ? 1u << (10 + o + 2) : 0u;
+            }
         }
-        W.m6[lane] = (uint8_t) ((ablate & 512) ? 0x3fu : m6);
+        W.mr[lane] = (uint16_t) ((ablate & 512) ? 0x7fffu : mr);
         }
         CTGN_TICK(0)
 
@@ -729,15 +737,14 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         unsigned long long need_next = 0, st_need = 0;    // bit i: the i-th nearest sweep voxel is needed by round need_round / is in the staged table
         int need_round = -1;
         // Which of the 27 sweep voxels of the shared home voxel can hold one of the k nearest of some row's keypoint of round rr: those in
-        // the product of that keypoint's per-axis offset sets (W.m6, phase A; with a carried-over bound typically 1-4 voxels instead of 27).
+        // the product of that keypoint's per-axis offset sets (W.mr, phase A; with a carried-over bound typically 1-4 voxels instead of 27).
         // Bit i = the i-th nearest sweep voxel, lane i's.
         auto shared_need = [&](int rr) -> unsigned long long {
             const int svl = lane < 27 ? (int) c_sweep1.v[lane] : 13;
-            const int ox = svl / 9, oy = (svl / 3) % 3, oz = svl % 3;                 // 0 / 1 / 2 = offset -1 / 0 / +1 (0 needs no bit)
-            const uint32_t want = (ox == 1 ? 0u : 1u << (ox >> 1)) | (oy == 1 ? 0u : 4u << (oy >> 1)) | (oz == 1 ? 0u : 16u << (oz >> 1));
+            const uint32_t want = (1u << (svl / 9 + 1)) | (1u << (5 + (svl / 3) % 3 + 1)) | (1u << (10 + svl % 3 + 1));    // offsets -1 .. +1 = bits 1 .. 3
             bool any_row = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) W.m6[j * 16 + rr] & want) == want;
+            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) W.mr[j * 16 + rr] & want) == want;
             return __ballot(any_row && lane < 27);
         };
         for (int r = 0; r < ((ablate & 1024) ? 0 : rounds); ++r) {
@@ -884,7 +891,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // ===== generic path: every row probes and streams its own keypoint's neighbourhood =====
             st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
             const double r2bound = kth_d2;        // the probes are culled against the bound the round starts with
-            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound);
+            const uint32_t mreach = W.mr[src];
+            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
@@ -898,15 +906,17 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 Probe cur = nxt;
                 const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
-                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound);
+                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
                 } else if (r + 1 < rounds) {
                     const int src2 = row * 16 + r + 1;
                     const int kx2 = W.kx[src2];
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
-                                          fmin(map.r2thr, (double) W.kb[src2]));
+                                          fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
                 if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(cur.active));
+                // a batch none of whose voxels any row can reach (most batches of a bounded 125-voxel sweep): nothing to resolve or stream
+                if (__any(cur.active)) {
                 const uint32_t bc = probe_resolve(map, cur);
                 if (bc) RP.occ[cur_v] = bc;
                 // Once the row holds k candidates and knows its k-th best distance, a voxel that lies entirely farther away cannot
@@ -975,6 +985,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                         if (Ln >= k) kth_d2 = R.d2[k - 1];
                         CTGN_TICK(3)
                     }
+                }
                 }
                 CTGN_TICK(2)
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
