@@ -621,6 +621,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 case 2: launch(k_accumulate_rows<1, false, false, 3>, sm, nullptr); break;
                 case 3: launch(k_accumulate_rows<1, true, true, 3>, sm, h->d_prof); break;
                 case 4: launch(k_accumulate_rows<1, true, false, 4>, sm, nullptr); break;
+                case 5: launch(k_accumulate_rows<1, true, false, 3, true>, sm, nullptr); break;      // with the shared-home-voxel path (A/B hook)
                 default: launch(k_accumulate_rows<1, true, false, 3>, sm, nullptr); break;
             }
         } else {
@@ -2177,7 +2178,7 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask) {
 }
 
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant) {
-    if (!h || variant < 0 || variant > 4) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h || variant < 0 || variant > 5) return CTGN_ERR_INVALID_ARGUMENT;
     h->variant = variant;
     return CTGN_OK;
 }

@@ -617,7 +617,9 @@ __device__ __forceinline__ bool rows_share_home(int kx, int ky, int kz) {
 // PROF: per-phase shader-clock accounting (s_memtime) summed over waves into prof[0..7]:
 //   0 phase A (transform, voxel) | 1 hash probes + chunk lists | 2 candidate streaming | 3 in-stream prunes |
 //   4 final selection | 5 covariance sums | 6 phase C (normal, residual, u) | 7 phase D (u u^T accumulation)
-template <int NB, bool HIST, bool PROF = false, int WPS = 4>
+// SHARED: compile the shared-home-voxel path (NB = 1). Off in the default instantiation since round 2: with the carried-over bound
+// and the slab-gated probes the generic path runs a B2 launch in 0.098 ms against 0.108 ms with the shared path (B2-small 0.071 / 0.075).
+template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
                                                                unsigned long long *prof = nullptr, int ablate = 0) {
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
-            const bool uniform_home = (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
+            const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             }
             }
             // the next round's shared probes go out now, so their latency hides behind this round's selection and sums
-            if (NB == 1 && blk <= 32 && r + 1 < rounds) {
+            if (SHARED && NB == 1 && blk <= 32 && r + 1 < rounds) {
                 const int src2 = row * 16 + r + 1;
                 const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
                 if (!(ablate & 32) && rows_share_home(kx2, ky2, kz2)) {

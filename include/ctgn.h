@@ -448,7 +448,9 @@ ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t
 /* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
  * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection,
  * 3 = variant 0 instrumented with per-phase shader clocks (see ctgn_phase_cycles), 4 = variant 0 compiled for
- * 4 waves per SIMD instead of 3 (A/B hook). Test / measurement hook. */
+ * 4 waves per SIMD instead of 3 (A/B hook), 5 = variant 0 with the shared-home-voxel path of the 27-voxel sweep compiled in
+ * (the four keypoints of a round probe and stream one flattened neighbourhood; the default until round 2, now slower than the
+ * bounded generic path — A/B hook). Same results for every variant. Test / measurement hook. */
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 /* Measurement hook: skip phases of the row kernel (bit 0 candidate streaming, 1 selection, 2 covariance sums,
  * 3 normal/residual/Jacobian, 5 shared-home-voxel fast path). Results are INVALID while a mask is set; only timings

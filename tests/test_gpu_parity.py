@@ -78,7 +78,7 @@ def test_radius_search_is_bit_exact(case_name, request):
 
 
 # ------------------------------------------------------------------------------------------------- one accumulation
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5])
 @pytest.mark.parametrize("case_name,voxel", [("box_case", 0.4), ("street_case", 0.6)])
 def test_accumulate_matches_oracle(case_name, voxel, variant, request):
     case = request.getfixturevalue(case_name)
@@ -316,14 +316,14 @@ def test_full_size_properties(config_b_full):
     o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
     s = cia.GnSolver(gm)
     results = {}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 5):
         s.set_variant(variant)
         s.set_keypoints(sc.raw, world0, sc.t)
         pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
         results[variant] = (s.get_system(), pose1, summ.num_residuals_used)
     (A0, b0, n0), p0, _ = results[0]
     assert n0 > 20_000
-    for v in (1, 2):                                   # two independent search kernels agree at full size
+    for v in (1, 2, 5):                                # independent search kernels / paths agree at full size
         (A, b, nu), p, _ = results[v]
         assert nu == n0
         assert np.abs(A - A0).max() < 1e-9 * np.abs(A0).max() and np.abs(b - b0).max() < 1e-9 * np.abs(b0).max() + 1e-13
