@@ -886,6 +886,7 @@ static ctgn_status devmap_insert_staged(ctgn_handle h, size_t n, uint8_t *out) {
 
 ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, ctgn_dtype dt, size_t n, uint8_t *out) {
     if (!h || (!xyz_base && n)) return CTGN_ERR_INVALID_ARGUMENT;
+    h->kth_fresh = false;               // the bound carried from one search to the next assumes an unchanged map
     if (h->update_mode == 1) return devmap_insert(h, xyz_base, stride, dt, n, out);
     if (n && on_device(xyz_base))
         return fail(h, CTGN_ERR_UNSUPPORTED, "device-memory points need the device-resident map (ctgn_map_set_update_mode(h, 1)); "
@@ -911,6 +912,7 @@ ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, 
 
 ctgn_status ctgn_map_remove_far(ctgn_handle h, const double location[3], double distance) {
     if (!h || !location) return CTGN_ERR_INVALID_ARGUMENT;
+    h->kth_fresh = false;
     if (h->update_mode == 1) {
         HIPCHK(h, hipSetDevice(h->device));
         for (auto &DL : h->devlevels) DMCHK(h, devmap_level_remove_far(DL, location, distance, h->stream));
@@ -922,6 +924,7 @@ ctgn_status ctgn_map_remove_far(ctgn_handle h, const double location[3], double 
 
 ctgn_status ctgn_map_clear(ctgn_handle h) {
     if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    h->kth_fresh = false;
     if (h->update_mode == 1) {
         HIPCHK(h, hipSetDevice(h->device));
         for (auto &DL : h->devlevels) DMCHK(h, devmap_level_clear(DL, h->stream));
@@ -1028,6 +1031,7 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
         h->cap_kp = (int) cap;
     }
     h->n_kp = (int) n;
+    h->kth_fresh = false;               // new keypoints: no search of theirs has left a k-th distance
     h->order_stale = true;
     h->order_valid = false;
     h->kp_stride = (int) std::min<size_t>((n + 63) & ~(size_t) 63, (size_t) h->cap_kp);
@@ -1780,6 +1784,7 @@ ctgn_status ctgn_frame_update_map(ctgn_handle h, const double location[3], doubl
     if (h->update_mode != 1)
         return fail(h, CTGN_ERR_UNSUPPORTED, "the frame pipeline updates the device-resident map (ctgn_map_set_update_mode(h, 1))");
     auto &F = h->fr;
+    h->kth_fresh = false;
     if (add_points && !F.valid) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no registered frame is resident (ctgn_frame_register)");
     static const bool timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();

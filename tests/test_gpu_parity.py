@@ -791,6 +791,48 @@ def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
     assert np.array_equal(b["all_world"], want)
 
 
+def test_map_or_keypoints_changed_inside_a_stepwise_solve_drop_the_carried_bound(street_case):
+    """Every search after the first of a solve is bounded by the previous search's k-th neighbour distance —
+    valid only while map and keypoints stay what they were. The stepwise API lets a caller change either between two accumulate
+    calls: evicting the voxels around the keypoints, or uploading other keypoints, must make the next search start from the radius
+    again. Checked on the per-keypoint neighbour counts and farthest neighbours against the batched radius search at the world points
+    the search used, on the map as it then is."""
+    case = street_case
+    om, gm = build_maps(case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, 0.6)
+    o = _opts(num_iters_icp=8, threshold_orientation_norm=0.0, min_number_neighbors=5)
+    s = cia.GnSolver(gm)
+    s.set_debug(True)
+
+    def check(tag):
+        dbg = s.get_debug()
+        nbs = gm.ComputeNeighborhoods(s.world_points(), 20)
+        want_n = np.array([len(g) for g in nbs])
+        assert np.array_equal(dbg["n_neighbors"], want_n), (tag, int(np.count_nonzero(dbg["n_neighbors"] != want_n)))
+        for i in np.flatnonzero(want_n > 0)[::7]:
+            assert np.array_equal(dbg["farthest"][i], nbs[i][0]), (tag, i)                 # farthest first (map.h:508-513)
+        return want_n
+
+    s.set_keypoints(raw, world0, t)
+    s.gn_begin(pose0, sc.t_begin_end, o)
+    for _ in range(2):
+        s.gn_accumulate()
+        s.gn_solve_update()
+    full = check("bounded search, nothing changed")
+    # thin the map out under the keypoints: every voxel farther than 6 m from a point beside the sensor goes
+    gm.RemoveElementsFarFromLocation(sc.pose_gt[11:14] + np.array([3.0, 0.0, 0.0]), 6.0)
+    s.gn_accumulate()
+    thinned = check("after an eviction inside the solve")
+    assert (thinned < full).sum() > 100                                           # the eviction did bite
+    s.gn_solve_update()
+    # other keypoints inside the running solve
+    s.set_keypoints(raw[1::2], world0[1::2], t[1::2])
+    s.gn_accumulate()
+    check("after new keypoints inside the solve")
+    s.gn_solve_update()
+    s.gn_end()
+
+
 def test_frame_pipeline_edge_cases(street_case):
     """ctgn_frame_register on the inputs a caller can throw at it: an empty scan, no sub-sampling at all (every point a keypoint),
     the keypoint cap, float32 and strided (WPoint3D-shaped) views through the C ABI directly, and a second call on the same handle with
