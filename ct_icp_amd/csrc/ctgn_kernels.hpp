@@ -506,7 +506,9 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
     if (maxLn == 0) return 0;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const uint32_t lt_mask = (1u << sub) - 1u;
-    if (HIST && maxLn > k) {
+    // lists of at most 32 entries go straight to the register rank below (with a carried-over bound that is nearly every list);
+    // longer ones are first cut with the histogram
+    if (HIST && maxLn > 32) {
         R.hist[sub] = 0;
         const double scale = hi > 0.0 ? 16.0 / hi : 0.0;
         const int nown = (maxLn + 15) >> 4;
