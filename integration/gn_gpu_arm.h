@@ -8,7 +8,7 @@
 //
 // Both return std::nullopt — and the reference's own CPU loop runs, untouched — when the map is not a GpuVoxelMap, when a view's
 // source type is not FLOAT32 / FLOAT64, or (CERES) when the configuration is not CONTINUOUS_TIME + POINT_TO_PLANE.
-// oracle/Makefile applies exactly these two insertions to a scratch copy of the reference's ct_icp.cpp and links the result with
+// oracle/Makefile applies exactly these two insertions to the reference's ct_icp.cpp on its way into the compiler and links the result with
 // libctgn.so (target _ref/glue_check); tests/test_integration_glue.py compiles this header verbatim.
 #ifndef CT_ICP_GN_GPU_ARM_H
 #define CT_ICP_GN_GPU_ARM_H
