@@ -9,12 +9,16 @@
  *   InsertPointInVoxelMap / RemoveElementsFarFromLocation  (reference include/ct_icp/map.h:261-293, 305-322),
  * plus the rows either side of the path: grid sampling, full-scan undistortion, device-resident map
  * maintenance, and the robust-loss route the shipped configs select
- *   ct_icp::CT_ICP_Registration::DoRegisterCeres          (reference src/ct_icp/ct_icp.cpp:457-707; ctgn_register_robust).
+ *   ct_icp::CT_ICP_Registration::DoRegisterCeres          (reference src/ct_icp/ct_icp.cpp:457-707; ctgn_register_robust),
+ * those rows chained with the scan resident on the device — the data-parallel side of
+ *   ct_icp::Odometry::DoRegister                          (reference src/ct_icp/odometry.cpp:333-501, 936-952; ctgn_frame_*),
+ * and the keypoint-sharded multi-GPU loop with its one all-reduce issued by the library (ctgn_dist_*, ctgn_solve_sharded).
  *
  * The reference has no C ABI / FFI for this path (it is C++ member calls inside libCT_ICP.so), so the
  * entry points below are what a maintainer would bind from
  *   - a `GpuVoxelMap : ct_icp::ISlamMap` (reference include/ct_icp/map.h:14-83) -> ctgn_map_* calls
  *   - the `case GN:` / `case CERES:` arms of SELECT_SOLVER (reference src/ct_icp/ct_icp.cpp:1003-1014) -> ctgn_register / ctgn_register_robust
+ *   - Odometry::DoRegister's sampling / registration / undistortion / map update -> ctgn_frame_register + ctgn_frame_update_map
  * INTEGRATION.md shows that binding; ct_icp_amd/cpp/ct_icp_gpu.hpp is the C++ adapter.
  *
  * Conventions
