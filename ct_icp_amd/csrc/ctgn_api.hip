@@ -1632,26 +1632,35 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     constexpr size_t CHUNK = 32768;
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
     const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
+    // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
+    double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool has_nan = false, bad_order = false;
+    auto stage_one = [&](size_t j, int u) {
+        const size_t i = order ? (size_t) order[j] : j;
+        if (i >= n) { bad_order = true; return; }
+        double *q = hs + 4 * j;
+        if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+        else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+        const double t = fo->override_timestamps ? fo->override_timestamp
+                         : tf64 ? *reinterpret_cast<const double *>(tb_ + i * ts.stride_bytes)
+                                : (double) *reinterpret_cast<const float *>(tb_ + i * ts.stride_bytes);
+        q[3] = t;
+        mn[u] = t < mn[u] ? t : mn[u];
+        mx[u] = t > mx[u] ? t : mx[u];
+        has_nan = has_nan || t != t;
+    };
     for (size_t j0 = 0; j0 < n || j0 == 0; j0 += CHUNK) {
         const size_t j1 = std::min(n, j0 + CHUNK);
-        for (size_t j = j0; j < j1; ++j) {
-            const size_t i = order ? (size_t) order[j] : j;
-            if (i >= n) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
-            double *q = hs + 4 * j;
-            if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
-            else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
-            const double t = fo->override_timestamps ? fo->override_timestamp
-                             : tf64 ? *reinterpret_cast<const double *>(tb_ + i * ts.stride_bytes)
-                                    : (double) *reinterpret_cast<const float *>(tb_ + i * ts.stride_bytes);
-            q[3] = t;
-            tmin = t < tmin ? t : tmin;
-            tmax = t > tmax ? t : tmax;
-            if (t != t) tmax = NAN;
-        }
+        size_t j = j0;
+        for (; j + 4 <= j1; j += 4) { stage_one(j, 0); stage_one(j + 1, 1); stage_one(j + 2, 2); stage_one(j + 3, 3); }
+        for (; j < j1; ++j) stage_one(j, 0);
+        if (bad_order) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
         const size_t lo = j0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first chunk carries the pose
         HIPCHK(h, hipMemcpyAsync(F.d_scan + lo, F.h_scan + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (j1 >= n) break;
     }
+    tmin = std::min(std::min(mn[0], mn[1]), std::min(mn[2], mn[3]));
+    tmax = has_nan ? NAN : std::max(std::max(mx[0], mx[1]), std::max(mx[2], mx[3]));
     // every point is undistorted below: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
     if (n && !(tbe[0] <= tmin && tmax <= tbe[1])) {
         hipStreamSynchronize(h->stream);
@@ -1754,10 +1763,22 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     if (out) {
         out->num_sampled = n1;
         out->num_keypoints = n2;
-        if (want_all)
-            for (size_t j = 0; j < n; ++j)
-                write_point(out->all_world_base, out->all_world_stride_bytes, out->all_world_dtype, order ? (size_t) order[j] : j, F.h_out[j],
-                            F.h_out[c + j], F.h_out[2 * c + j]);
+        if (want_all) {
+            const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
+            char *ob = static_cast<char *>(out->all_world_base);
+            const size_t os = out->all_world_stride_bytes;
+            if (out->all_world_dtype == CTGN_F64) {
+                for (size_t j = 0; j < n; ++j) {
+                    double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
+                    q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
+                }
+            } else {
+                for (size_t j = 0; j < n; ++j) {
+                    float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
+                    q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
+                }
+            }
+        }
         if (out->sampled_world_base)
             for (size_t k = 0; k < n1; ++k)
                 write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
