@@ -3,16 +3,22 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under torch.distributed.run, one
 rank per GPU. A "step" is ONE GN iteration (neighbour search + covariance/normal + residual/Jacobian + reduction + 12x12 solve +
-pose update, ct_icp.cpp:745-981) over the resident keypoint batch. Rank 0 prints one JSON line.
+pose update, ct_icp.cpp:745-981) over the resident keypoint batch, and the K timed steps are FRESH solves of the profile's iteration
+budget (driving profile: 5, config/odometry/driving_config.yaml; ct_icp.cpp:745): per solve the uploaded world points are put back
+(device-to-device), `gn_begin`, 5 iterations. The first search of every solve therefore runs on the radius alone and the library
+plans for a 5-iteration solve — what a frame pays. Round 2's figure (iterations 170.. of ONE running loop, every search bounded by a
+converged solve's k-th distances) rides along as `roofline.steady_state_*`. Rank 0 prints one JSON line.
 
 N = 1  workload B2 = BASELINE.json configs[1]: a KITTI-00-like HDL-64E sweep (~132 k returns, every return a keypoint: the
        throughput regime of SURVEY.md section 8d) registered against a STEADY-STATE driving-profile local map (0.8 m x 30 pts,
        radius 0.75 => 27 voxels per query, k = 20, everything within the 100 m eviction radius of an open residential scene:
-       ~3.3 x 10^5 voxels, searched level ~260 MB — larger than L2 + Infinity Cache). `--workload B2-small` keeps round 1's
-       20-frame street-canyon map (6.8 k voxels, 5 MB: an L2-resident best case).
-N > 1  config D (BASELINE.json configs[3]) STRONG scaling: ONE dense 2 M-keypoint scan, sorted by home voxel, cut into N
-       contiguous chunks (map replicated), one ncclAllReduce of the 96-double packed system per iteration issued by the
-       library (ctgn_solve_sharded's launch sequence). A weak-scaling line (one B2 sweep per rank) rides along.
+       ~3.3 x 10^5 voxels, searched level ~270 MB — larger than L2 + Infinity Cache). The line also carries `workloads`: B1 (the
+       reference's keypoint count), C (configs[2]: NCLT / HDL-32E profile) and D (configs[3] on one GPU), each with its own
+       roofline, parity and cpu_baseline. `--workload X` makes X the headline; `--workload B2-small` is round 1's 5 MB map.
+N > 1  config D (BASELINE.json configs[3]) STRONG scaling: ONE Ouster-128-style scan; every rank hands the library the whole scan,
+       the library sorts it by home voxel and keeps the rank's contiguous chunk (ctgn_set_keypoints_sharded; map replicated), one
+       ncclAllReduce of the 96-double packed system per iteration issued by the library (ctgn_solve_sharded's launch sequence).
+       The same scan on one GPU and a weak-scaling line (one B2-small sweep per rank) ride along.
 Inputs are synthetic (no dataset on the box) and resident in HBM before the timed region. Clocks: the GPU leaves its idle power
 state only under sustained load (profiles/r01_launch_series.txt), so `CLOCK_WARM` untimed iterations of the same loop run
 immediately before the W warm-up and the K timed steps — same launch sequence, same resident data, no upload in between.
@@ -51,7 +57,8 @@ def collect_pmc(args, timeout: int = 300):
     if exe is None:
         return {}, "rocprofv3 not found"
     kernel = "k_accumulate_lane" if args.variant == 1 else "k_accumulate_rows"
-    groups = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"]]
+    groups = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"],
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU"]]
     vals = {}
     for counters in groups:
         out_dir = tempfile.mkdtemp(prefix="ctgn_pmc_", dir="/tmp")
@@ -68,6 +75,8 @@ def collect_pmc(args, timeout: int = 300):
                         got[r["Counter_Name"]].append(float(r["Counter_Value"]))
             for c, rows in got.items():
                 if not rows:
+                    if c.startswith("SQ_INSTS"):
+                        continue                                 # a nicety: the other passes stand without it
                     return vals, f"rocprofv3 --pmc {c}: no rows for {kernel}"
                 rows = rows[len(rows) // 2:]                 # the second half of the inner run: clocks and caches are warm
                 vals[c] = sum(rows) / len(rows)
@@ -75,7 +84,7 @@ def collect_pmc(args, timeout: int = 300):
             return vals, f"rocprofv3 --pmc {' '.join(counters)}: {type(e).__name__}"
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
-    return vals, "live: rocprofv3 --kernel-trace --pmc, 3 passes (FETCH_SIZE | WRITE_SIZE | SQ_*), means over the second half of the launches"
+    return vals, "live: rocprofv3 --kernel-trace --pmc, 4 passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_INSTS_*), means over the second half of the launches"
 
 
 def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
@@ -162,15 +171,442 @@ def make_inputs_large(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cac
     return dict(map_points=map_points, prev_b=knots[0, 4:7], prev_e=knots[1, 4:7], **scan)
 
 
-def shard_of(inp, resolution, rank, world, pose0):
-    """Config D sharding: global sort of the keypoints by home voxel, contiguous chunk per rank."""
+def make_inputs_nclt(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
+    """Workload C = BASELINE.json configs[2]: a synthetic HDL-32E (32 beams, +10.67 .. -30.67 deg) on a Segway-like platform (2 m/s,
+    0.3 rad/s yaw, roll / pitch jitter) in a narrow campus street; the map is what the eight preceding sweeps left in the NCLT profile's
+    three-resolution map (reference config/odometry/nclt_config.yaml:41-53; default radius 0.8 => the 0.5 m level, 125 voxels per query).
+    Cached: nine small ray-cast sweeps."""
+    from ct_icp_amd import synthetic as syn
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"ctgn_bench_C_v1_r{rank}.npz")
+    if os.path.exists(path):
+        d = np.load(path)
+        return {k: d[k] for k in d.files}
+    scene = syn.street_scene(150.0, seed=2, half_width=(7.0, 9.0))
+    dirs, rel_t = syn.lidar_pattern("hdl32", azimuth_steps=1800)
+    knots = syn.driving_trajectory(10, dt=0.1, speed=2.0, yaw_rate=0.3, height=1.0, jitter=0.02, seed=2, start_x=20.0)
+    map_pts = []
+    for j in range(8):
+        sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), max_range=60.0, noise=0.02, seed=200 + j)
+        map_pts.append(sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)])                   # odometry voxel_size 0.5 (nclt_config.yaml:32)
+    sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 8), 0.8, 0.9, max_range=60.0, noise=0.02, seed=208 + 17 * rank)
+    out = dict(map_points=np.concatenate(map_pts), raw=sc.raw, t=sc.t, pose_gt=sc.pose_gt, tbe=sc.t_begin_end, prev_b=knots[7, 4:7], prev_e=knots[8, 4:7])
+    try:
+        np.savez(path, **out)
+    except OSError:
+        pass
+    return out
+
+
+def make_inputs_ouster(sweeps: int = 8, density: float = 100.0, radius: float = 100.0):
+    """Workload D = BASELINE.json configs[3], SURVEY.md section 8d: an Ouster-128-style scan (128 beams +-22.5 deg, 2048 columns x `sweeps`
+    accumulated sub-sweeps = 2.1 M rays at 8) RAY-CAST against the residential scene of workload B2 with the sensor moving through the
+    frame, keypoints = every return that survives a 0.05 m grid; the map is the scene's surfaces within `radius` sampled directly (what
+    ~50 dense frames from many viewpoints leave behind) and passed through the map's own insert rule at {0.5 m, 40 pts, 0.03 m}:
+    ~0.8 M voxels x 40 slots x 24 B — well beyond L2 + Infinity Cache. The ray-casting runs as broadcast torch operations on the GPU
+    (ct_icp_amd.synthetic.raycast_torch: seconds instead of minutes), so nothing is cached."""
+    from ct_icp_amd import synthetic as syn
+    scene = syn.suburb_scene(seed=7, n_buildings=220, n_trees=4000)
+    knots = syn.driving_trajectory(3, seed=0, start_x=20.0)
+    dirs, rel_t = syn.lidar_pattern("os128", sweeps=sweeps)
+    sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 1), 0.1, 0.2, noise=0.02, seed=3, use_torch=True)
+    keep = syn.grid_sample_indices(sc.raw, 0.05)
+    map_points = syn.sample_scene_surfaces(scene, knots[1, 4:7], radius=radius, density=density, noise=0.02, seed=6)
+    return dict(map_points=map_points, raw=sc.raw[keep], t=sc.t[keep], pose_gt=sc.pose_gt, tbe=sc.t_begin_end, prev_b=knots[0, 4:7], prev_e=knots[1, 4:7],
+                returns=len(sc.raw), rays=len(dirs))
+
+
+# per workload: (resolutions [(size, min distance, points per voxel)], default radius, GN iterations per frame, min_number_neighbors)
+PROFILES = {
+    "B2": ([(0.8, 0.1, 30)], 0.75, 5, 20),         # config/odometry/driving_config.yaml:18-90 with solver GN
+    "B2-small": ([(0.8, 0.1, 30)], 0.75, 5, 20),
+    "B1": ([(0.8, 0.1, 30)], 0.75, 5, 20),
+    "C": ([(0.5, 0.05, 30), (1.0, 0.1, 30), (2.0, 0.2, 30)], 0.8, 20, 10),      # config/odometry/nclt_config.yaml:41-53,69,83
+    "D": ([(0.5, 0.03, 40)], 0.8, 5, 20),          # SURVEY.md section 8d config D
+}
+NAMES = {
+    "B2": "config B2 = BASELINE.json configs[1]: synthetic HDL-64E sweep (KITTI-00-like, every return a keypoint) over the steady-state "
+          "driving-profile map of an open residential scene: 0.8 m x 30 pts, radius 0.75 (27 voxels), k=20, everything within the 100 m eviction radius",
+    "B2-small": "config B2-small: the same sweep regime over round 1's 20-frame street-canyon map (L2-resident best case)",
+    "B1": "config B1: street-canyon sweep and map, keypoints = 1.5 m grid of the 0.5 m-subsampled frame (the reference's keypoint count; latency regime)",
+    "C": "config C = BASELINE.json configs[2]: synthetic HDL-32E on a Segway-like platform, NCLT profile: map 0.5 / 1 / 2 m x 30 pts, radius 0.8 => 0.5 m "
+         "level, 125 voxels per query, min_number_neighbors 10, 20 GN iterations per frame, <= 1500 keypoints (0.8 m grid)",
+    "D": "config D = BASELINE.json configs[3]: Ouster-128-style 2.1 M-ray scan ray-cast against the residential scene, keypoints = 0.05 m grid of the "
+         "returns, map {0.5 m, 40 pts, 0.03 m} of every surface within 100 m (> L2 + Infinity Cache), radius 0.8 (125 voxels), k=20",
+}
+
+
+def build_workload(name, rank, world, args, cia, syn, se3):
+    """Inputs + map + keypoints of one workload. Returns a dict the measuring functions share."""
+    res_list, radius, ipf, min_nb = PROFILES[name]
+    if name == "D":
+        inp = make_inputs_ouster(sweeps=args.d_sweeps, radius=args.d_radius)      # ONE scan for all ranks (strong scaling)
+    elif name == "B2":
+        inp = make_inputs_large(rank)
+    elif name == "C":
+        inp = make_inputs_nclt(rank)
+    else:
+        inp = make_inputs(rank, args.map_frames)
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res_list], default_radius=radius, device=args.local_rank))
+    for s0 in range(0, len(inp["map_points"]), 2_000_000):
+        gm.InsertPointCloud(inp["map_points"][s0:s0 + 2_000_000])
+    gm.Sync()
+    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
+    raw, t = inp["raw"], inp["t"]
+    if name == "B1":                                   # the reference's two-stage grid sampling (odometry.cpp:349,538)
+        sel = syn.grid_sample_indices(raw, 0.5)
+        sel = sel[syn.grid_sample_indices(raw[sel], 1.5)]
+        raw, t = raw[sel], t[sel]
+    elif name == "C":                                  # voxel_size 0.5, then the 0.8 m keypoint grid capped at max_num_keypoints 1500
+        sel = syn.grid_sample_indices(raw, 0.5)
+        sel = sel[syn.grid_sample_indices(raw[sel], 0.8)][:1500]
+        raw, t = raw[sel], t[sel]
+    world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
+    mm = cia.PreviousFrameMotionModel()
+    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([[0, 0, 0, 1], inp["prev_b"], [0, 0, 0, 1], inp["prev_e"]]), 0, 0)
+    searched = gm.SearchParamsFromRadiusSearch()
+    lv = searched[0]
+    level_mb = (gm.NumVoxels(lv) * res_list[lv][2] * 24 + (1 << int(np.ceil(np.log2(max(gm.NumVoxels(lv), 1) * 4)))) * 16) / 1e6
+    return dict(name=name, inp=inp, gm=gm, res_list=res_list, radius=radius, ipf=ipf, min_nb=min_nb, raw=raw, t=t, world0=world0, pose0=pose0,
+                mm=mm, level=lv, level_mb=level_mb, nb=searched[2])
+
+
+def oracle_map(W):
+    from oracle import oracle as orc
+    om = orc.Map(resolutions=W["res_list"], default_radius=W["radius"])
+    for s0 in range(0, len(W["inp"]["map_points"]), 2_000_000):
+        om.insert(W["inp"]["map_points"][s0:s0 + 2_000_000])
+    return om
+
+
+class Runner:
+    """The GN loops of one workload on one rank: fresh solves (the headline) and the long running loop (steady state)."""
+
+    def __init__(self, W, args, cia, torch, dist, sharded):
+        self.W, self.args, self.cia, self.torch, self.dist = W, args, cia, torch, dist
+        self.sh = None
+        if sharded:
+            from ct_icp_amd.distributed import ShardedGnSolver
+            self.sh = ShardedGnSolver(W["gm"], library_collective=not args.torch_collective)
+            self.solver = self.sh.solver
+        else:
+            self.solver = cia.GnSolver(W["gm"])
+        self.solver.set_variant(args.variant)
+        self.solver.set_ordering({"auto": -1, "off": 0, "on": 1}[args.order])
+        self.solver.set_ablation(args.ablate)
+        self.solver.set_rewind(True)
+
+    def options(self, iters):   # threshold 0: no early stop, exactly `iters` GN iterations
+        return self.cia.CTICPOptions(solver=self.cia.GN, num_iters_icp=iters, min_number_neighbors=self.W["min_nb"], threshold_orientation_norm=0.0,
+                                     debug_print=False)
+
+    def sync_all(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def iterate(self, k):
+        """k GN iterations of the running loop, enqueued without synchronising."""
+        if self.sh is not None and self.args.torch_collective:
+            from ct_icp_amd.distributed import allreduce_system
+            for _ in range(k):
+                self.solver.gn_accumulate()
+                allreduce_system(self.sh.system)
+                self.solver.gn_solve_update()
+        else:
+            self.solver.gn_iterate(k, sharded=self.sh is not None)
+
+    def fresh(self, k, ipf=None):
+        """k GN iterations as FRESH solves of the profile's budget (5 for the driving profile, ct_icp.cpp:745): world points back to the
+        uploaded ones (device-to-device), gn_begin, `ipf` iterations — so the first search of every solve is unbounded and the library
+        plans for a `ipf`-iteration solve. Nothing synchronises; the last solve may be shorter so that exactly k iterations run."""
+        W, ipf = self.W, ipf or self.W["ipf"]
+        left = k
+        while left > 0:
+            m = min(ipf, left)
+            self.solver.rewind()
+            self.solver.gn_begin(W["pose0"], W["inp"]["tbe"], self.options(ipf), W["mm"])
+            self.iterate(m)
+            left -= m
+        return k
+
+    def upload(self):
+        """Keypoints resident on the device. Sharded config D: every rank hands the library the WHOLE scan; it sorts by home voxel and keeps
+        this rank's contiguous chunk (ctgn_set_keypoints_sharded)."""
+        W = self.W
+        if "shard" in W:
+            idx = self.solver.set_keypoints_sharded(W["all_raw"], W["all_world0"], W["all_t"], *W["shard"])
+            W["raw"], W["t"], W["world0"] = W["all_raw"][idx], W["all_t"][idx], W["all_world0"][idx]
+        else:
+            self.solver.set_keypoints(W["raw"], W["world0"], W["t"])
+
+    def timed(self, body, steps, warmup, clock_warm):
+        """clock_warm + warmup untimed iterations of `body`, then exactly `steps` timed ones bracketed by barrier + synchronize.
+        Returns (seconds, HIP-event kernel times: all, first-of-solve, bounded)."""
+        s = self.solver
+        s.set_profiling(False)
+        body(clock_warm)
+        body(warmup)
+        self.sync_all()
+        s.set_profiling(True)                                  # HIP-event pair around every neighbour-search launch from here on
+        s.kernel_timing(reset=True)
+        self.sync_all()
+        t0 = time.perf_counter()
+        body(steps)
+        self.sync_all()
+        dt = time.perf_counter() - t0
+        summ = s.gn_end()[1]
+        kern = s.kernel_timing(reset=False)
+        first, later = s.kernel_timing_split(reset=True)
+        s.set_profiling(False)
+        return dt, summ, kern, first, later
+
+    def requested(self, steady_after=10):
+        """Bytes the search kernel asks the memory system for (SURVEY.md 8d pricing: 32 B per keypoint + 16 B per hash probe it issues
+        + 24 B per map point it streams), counted by the instrumented instantiation: first search of a solve, the later ones of a
+        `ipf`-iteration solve, and one iteration of the steady state."""
+        s, W = self.solver, self.W
+        n = len(W["t"])
+        s.set_variant(3)
+        out = {}
+        s.rewind()
+        s.gn_begin(W["pose0"], W["inp"]["tbe"], self.options(W["ipf"]), W["mm"])
+        s.traffic_counters(reset=True)
+        self.iterate(1)
+        p0, q0 = s.traffic_counters(reset=True)
+        self.iterate(W["ipf"] - 1)
+        p1, q1 = s.traffic_counters(reset=True)
+        s.gn_end()
+        s.rewind()
+        s.gn_begin(W["pose0"], W["inp"]["tbe"], self.options(steady_after + 1), W["mm"])
+        self.iterate(steady_after)
+        s.traffic_counters(reset=True)
+        self.iterate(1)
+        ps, qs = s.traffic_counters(reset=True)
+        s.gn_end()
+        s.set_variant(self.args.variant)
+        later_n = max(1, W["ipf"] - 1)
+        for key, (p_, q_, launches) in {"first": (p0, q0, 1), "later": (p1, q1, later_n), "steady": (ps, qs, 1)}.items():
+            out[key] = {"bytes_per_launch": (n * B_KP * launches + p_ * B_SLOT + q_ * B_PT) / launches, "probes_per_keypoint": p_ / launches / n,
+                        "points_per_keypoint": q_ / launches / n}
+        return out
+
+    def close(self):
+        if self.sh is not None:
+            self.sh.close()
+
+
+def roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep, variant):
+    """`roofline` of the bench line for the neighbour-search kernel over the timed fresh solves."""
+    dt, summ, (kern_ms, kern_launches), (first_ms, first_n), (later_ms, later_n) = timing
+    ipf = W["ipf"]
+    t_k = kern_ms * 1e-3
+    if req is not None:
+        alg = (req["first"]["bytes_per_launch"] + (ipf - 1) * req["later"]["bytes_per_launch"]) / ipf
+    else:
+        alg = alg_all
+    achieved = alg / t_k / 1e9 if t_k > 0 else 0.0
+    roof = {"bound": "latency/issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": pmc_src,
+            "achieved_definition": f"mean over the {ipf} searches of a fresh solve of: algorithmic bytes the kernel requests per launch (32 B/keypoint + 16 B per "
+                                   "hash probe it issues + 24 B per map point it streams, counted by the instrumented instantiation) / HIP-event launch "
+                                   "time; the first search of a solve is bounded by the radius only, the others by the carried-over k-th distance",
+            "hbm_counter_gbs": (traffic / t_k / 1e9) if traffic and t_k > 0 else None,
+            "hbm_counter_frac": (traffic / t_k / 1e9 / HBM_PEAK_GBS) if traffic and t_k > 0 else None,
+            "kernel": "k_accumulate_rows (voxel-hash neighbour search + k-nearest selection)" if variant != 1 else "k_accumulate_lane",
+            "kernel_ms_avg": kern_ms, "kernel_launches": kern_launches,
+            "alg_bytes_per_launch": alg, "alg_bytes_per_keypoint": alg / n_kp,
+            "alg_bytes_per_launch_all_sweep_voxels": alg_all,     # SURVEY.md 8d's formula with every voxel of the sweep: what an unculled search reads
+            "voxels_in_sweep_per_keypoint": sweep[0] / n_kp, "voxels_occupied_per_keypoint": sweep[1] / n_kp, "points_in_sweep_per_keypoint": sweep[2] / n_kp}
+    for key, ms, nl in (("first_iteration", first_ms, first_n), ("later_iterations", later_ms, later_n)):
+        r = req[{"first_iteration": "first", "later_iterations": "later"}[key]] if req is not None else None
+        roof[key] = {"kernel_ms": ms, "launches": nl}
+        if r is not None and ms > 0:
+            g = r["bytes_per_launch"] / (ms * 1e-3) / 1e9
+            roof[key].update({"requested_bytes_per_launch": r["bytes_per_launch"], "requested_bytes_per_keypoint": r["bytes_per_launch"] / n_kp,
+                              "probes_issued_per_keypoint": r["probes_per_keypoint"], "points_streamed_per_keypoint": r["points_per_keypoint"],
+                              "achieved": g, "frac": g / HBM_PEAK_GBS})
+    if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
+        wc = pmc["SQ_WAVE_CYCLES"]
+        roof.update({"wait_frac": pmc["SQ_WAIT_ANY"] / wc, "issue_stall_frac": pmc["SQ_WAIT_INST_ANY"] / wc,
+                     "active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc, "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / wc,
+                     "waves_per_launch": pmc.get("SQ_WAVES")})
+        if "SQ_INSTS_VALU" in pmc:
+            roof["valu_instructions_per_keypoint"] = pmc["SQ_INSTS_VALU"] / n_kp
+    return roof
+
+
+def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_warm, want_steady=True, want_parity=True, want_cpu=True, cpu_seconds=10.0,
+                     world=1, rank=0, pmc_live=False, register_extras=False):
+    """Everything the bench line says about one workload: fresh-solve throughput (the headline definition), first / later iteration
+    split, requested bytes + roofline, steady-state figure, pose parity against the oracle on the timed inputs, CPU baseline."""
     from ct_icp_amd import se3
-    from ct_icp_amd.distributed import home_voxel_order, shard_bounds
-    world0 = se3.ct_transform(pose0, inp["tbe"], inp["t"], inp["raw"])
-    order = home_voxel_order(world0, resolution)
-    lo, hi = shard_bounds(len(order), world, rank)
-    idx = order[lo:hi]
-    return inp["raw"][idx], inp["t"][idx], world0[idx]
+    R = Runner(W, args, cia, torch, dist, sharded)
+    R.upload()
+    n_kp = len(W["t"])
+    timing = R.timed(R.fresh, steps, warmup, clock_warm)
+    dt, summ = timing[0], timing[1]
+    last = steps % W["ipf"] or W["ipf"]
+    assert args.ablate or (summ.success and summ.num_iters == last), summ
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nn = torch.tensor([n_kp], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_kp = int(nn.item())
+    else:
+        total_kp = n_kp
+    timing = (dt,) + tuple(timing[1:])
+    out = {"value": total_kp * steps / dt, "unit": "keypoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "keypoints": n_kp,
+           "keypoints_total": total_kp, "iterations_per_solve": W["ipf"], "solves_timed": (steps + W["ipf"] - 1) // W["ipf"],
+           "n_used_last_iter": int(summ.num_residuals_used), "first_iteration_ms": None, "later_iteration_ms": None,
+           "map_points": int(W["gm"].NumPoints()), "map_voxels": int(W["gm"].NumVoxels(W["level"])), "searched_level_mb": W["level_mb"],
+           "frames_per_sec_equiv": 1.0 / (dt / steps * W["ipf"]) if dt > 0 else None}
+    # ---- steady state: ONE running loop (round 2's headline): every search after the first is bounded, the pose has converged
+    steady = None
+    if want_steady and not args.inner:
+        begun = []
+
+        def running(k):
+            if not begun:
+                R.solver.rewind()
+                R.solver.gn_begin(W["pose0"], W["inp"]["tbe"], R.options(clock_warm + warmup + steps), W["mm"])
+                begun.append(True)
+            R.iterate(k)
+        sdt, ssumm, skern, _, _ = R.timed(running, steps, warmup, clock_warm)
+        if dist is not None:
+            tt = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sdt = float(tt.item())
+        steady = {"value": total_kp * steps / sdt, "ms_per_step": sdt / steps * 1e3, "kernel_ms_avg": skern[0], "kernel_launches": skern[1],
+                  "what": f"iterations {clock_warm + warmup + 1}..{clock_warm + warmup + steps} of ONE running GN loop (round 2's headline): every search bounded by a "
+                          "converged solve's k-th distances — the search kernel's best case, not what a frame pays"}
+    # ---- accounting (untimed)
+    R.solver.rewind()
+    sweep = R.solver.count_traffic()                       # (voxels probed, voxels hit, points inside them) at the uploaded world points
+    alg_all = n_kp * B_KP + sweep[0] * B_SLOT + sweep[2] * B_PT
+    req = None
+    if args.variant == 0 and not args.ablate and not args.inner and W["nb"] in (1, 2):
+        req = R.requested()
+    pmc, pmc_src = ({}, "not collected for this workload (the headline workload's passes: profiles/)")
+    if pmc_live:
+        pmc, pmc_src = collect_pmc(args)
+    traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None
+    roof = roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep, args.variant)
+    out["first_iteration_ms"] = roof["first_iteration"]["kernel_ms"] + (out["ms_per_step"] - roof["kernel_ms_avg"])
+    out["later_iteration_ms"] = roof["later_iterations"]["kernel_ms"] + (out["ms_per_step"] - roof["kernel_ms_avg"])
+    out["iteration_split_note"] = "search-kernel HIP-event time of that kind of iteration + the rest of a mean iteration (residual + solve kernels, hand-overs)"
+    if steady is not None:
+        if req is not None and steady["kernel_ms_avg"] > 0:
+            g = req["steady"]["bytes_per_launch"] / (steady["kernel_ms_avg"] * 1e-3) / 1e9
+            steady.update({"requested_bytes_per_keypoint": req["steady"]["bytes_per_launch"] / n_kp, "achieved": g, "frac": g / HBM_PEAK_GBS})
+        for k_, v_ in steady.items():
+            roof["steady_state_" + k_] = v_
+    out["roofline"] = roof
+    # ---- parity on the very inputs that were timed: one fresh solve of the profile's budget on the GPU and through the oracle
+    om = None
+    if want_parity and not args.inner and not args.ablate:
+        from oracle import oracle as orc
+        R.upload()
+        o = R.options(W["ipf"])
+        pose_g, summ_g = (R.sh.solve(W["pose0"], W["inp"]["tbe"], o, W["mm"]) if R.sh is not None else R.solver.solve(W["pose0"], W["inp"]["tbe"], o, W["mm"]))[:2]
+        if rank == 0:
+            om = oracle_map(W)
+            if world > 1:                                   # the oracle registers the whole scan, the ranks their shards of it
+                o_raw, o_t, o_w0 = W["all_raw"], W["all_t"], W["all_world0"]
+            else:
+                o_raw, o_t, o_w0 = W["raw"], W["t"], W["world0"]
+            op = orc.MotionPrior(previous_begin_tr=W["inp"]["prev_b"], previous_end_tr=W["inp"]["prev_e"])
+            pose_o, _, so = orc.register_gn(om, o_raw, o_w0, o_t, W["pose0"], W["inp"]["tbe"],
+                                            orc.Options(num_iters_icp=W["ipf"], min_number_neighbors=W["min_nb"], threshold_orientation_norm=0.0), op,
+                                            heap_mode=0, num_threads=usable_cores())
+            tr, rot = se3.pose_error(pose_g, pose_o)
+            out["parity_m_rad"] = [tr, rot]
+            out["parity"] = {"gpu_vs_oracle_m_rad": [tr, rot], "iterations": W["ipf"], "n_used_gpu": int(summ_g.num_residuals_used),
+                             "n_used_oracle": int(so.num_residuals_used), "tolerance_m_rad": [1e-4, 1e-4]}
+            assert tr < 1e-4 and rot < 1e-4 and summ_g.num_residuals_used == so.num_residuals_used, out["parity"]
+    if want_cpu and rank == 0 and not args.no_cpu_baseline and world == 1:
+        if om is None:
+            om = oracle_map(W)
+        out["cpu_baseline"] = cpu_baseline_gn(W, om, cpu_seconds)
+        if out["cpu_baseline"]["value"]:
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if register_extras and rank == 0 and world == 1 and not args.ablate and not args.inner:
+        out.update(register_calls(W, cia, om))
+    R.close()
+    return out, om
+
+
+def cpu_baseline_gn(W, om, seconds: float = 10.0):
+    """`cpu_baseline` of a workload: the oracle's GN loop (a port; OpenMP over keypoints) on this box's host cores, on a BOUNDED sample:
+    the first keypoints of the workload, as many as ~`seconds` of CPU work allow, whole solves of the profile's iteration budget."""
+    from oracle import oracle as orc
+    cores = usable_cores()
+    prior = orc.MotionPrior(previous_begin_tr=W["inp"]["prev_b"], previous_end_tr=W["inp"]["prev_e"])
+    o = orc.Options(num_iters_icp=W["ipf"], min_number_neighbors=W["min_nb"], threshold_orientation_norm=0.0)
+    n_all = len(W["t"])
+
+    def timed(n, threads):
+        t0 = time.perf_counter()
+        _, _, s = orc.register_gn(om, W["raw"][:n], W["world0"][:n], W["t"][:n], W["pose0"], W["inp"]["tbe"], o, prior, heap_mode=0, num_threads=threads)
+        return n * max(1, s.num_iters) / (time.perf_counter() - t0), s
+    probe_n = min(n_all, 20_000)
+    rate, _ = timed(probe_n, cores)                         # also warms the OpenMP pool and the caches
+    n = int(min(n_all, max(probe_n, rate * seconds / W["ipf"])))
+    v_n, s = timed(n, cores)
+    n1 = int(min(n, max(2_000, v_n / cores * min(seconds, 5.0) / W["ipf"])))
+    v_1, _ = timed(n1, 1)
+    return {"value": v_n, "unit": "keypoints/s", "cores": cores, "kind": "port", "single_thread_value": v_1,
+            "sample": f"oracle GN loop (OpenMP over keypoints, {cores} threads), the first {n} of the workload's {n_all} keypoints x {W['ipf']} iterations "
+                      f"(one fresh solve; single thread: the first {n1})"}
+
+
+def register_calls(W, cia, om):
+    """Whole `CT_ICP_Registration::Register` calls through the C ABI on this workload's keypoints with the profile's own stop threshold
+    (host WPoint3D buffer in, pose + world points out): GN and the robust-loss route, each next to the oracle on the host."""
+    from oracle import oracle as orc
+    from ct_icp_amd import se3
+    name, inp = W["name"], W["inp"]
+    gn_kw = dict(num_iters_icp=W["ipf"], min_number_neighbors=W["min_nb"], threshold_orientation_norm=0.1)
+    rb_kw = dict(ROBUST_PROFILE) if name != "C" else dict(num_iters_icp=20, ls_max_num_iters=10, max_num_residuals=1500, loss_function="CAUCHY", ls_sigma=0.1,
+                                                          threshold_orientation_norm=0.1, threshold_translation_norm=0.01)       # nclt_config.yaml:69-104
+    rb_kw["min_number_neighbors"] = W["min_nb"]
+    kps = np.zeros(len(W["t"]), dtype=cia.WPOINT3D_DTYPE)
+    kps["raw_point"], kps["t"] = W["raw"], W["t"]
+    res = {}
+    for key, reg in (("frames_per_sec", cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.GN, debug_print=False, **gn_kw))),
+                     ("robust_route", cia.CT_ICP_Registration(cia.CTICPOptions(solver=cia.CERES, debug_print=False, **rb_kw)))):
+        times = []
+        for _ in range(23):
+            kps["world_point"] = W["world0"]
+            frame = cia.TrajectoryFrame.from_pose14(W["pose0"], *inp["tbe"])
+            t0 = time.perf_counter()
+            summ = reg.Register(W["gm"], kps, frame, W["mm"])
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times[3:]))
+        res[key] = {"value": 1.0 / med, "unit": "frames/s", "ms_per_frame": med * 1e3, "keypoints": int(len(kps)), "iterations": int(summ.num_iters),
+                    "residuals": int(summ.num_residuals_used), "includes": "host WPoint3D buffer -> H2D -> all iterations to the stop test -> pose + world points D2H",
+                    "pose": frame.pose14()}
+    prior = orc.MotionPrior(previous_begin_tr=inp["prev_b"], previous_end_tr=inp["prev_e"])
+    cores = usable_cores()
+    for threads in (1, cores):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pose_o, _, so = orc.register_gn(om, W["raw"], W["world0"], W["t"], W["pose0"], inp["tbe"], orc.Options(**gn_kw), prior, heap_mode=0, num_threads=threads)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        res["frames_per_sec"][f"cpu_port_ms_per_frame_{threads}_threads"] = float(np.median(ts))
+    tr, rot = se3.pose_error(res["frames_per_sec"].pop("pose"), pose_o)
+    res["frames_per_sec"]["gpu_vs_oracle_m_rad"] = [tr, rot]
+    rp = orc.RobustPrior(previous_begin_tr=tuple(inp["prev_b"]), previous_end_tr=tuple(inp["prev_e"]))
+    t0 = time.perf_counter()
+    pose_r, _, s_r = orc.register_robust(om, W["raw"], W["t"], W["pose0"], inp["tbe"], orc.RobustOptions(**rb_kw), rp, heap_mode=1)
+    res["robust_route"]["cpu_port_ms_per_frame_1_thread"] = (time.perf_counter() - t0) * 1e3
+    tr, rot = se3.pose_error(res["robust_route"].pop("pose"), pose_r)
+    res["robust_route"]["gpu_vs_oracle_m_rad"] = [tr, rot]
+    res["robust_route"]["gpu_over_cpu_1core"] = res["robust_route"]["cpu_port_ms_per_frame_1_thread"] / res["robust_route"]["ms_per_frame"]
+    return res
 
 
 def main():
@@ -181,16 +617,20 @@ def main():
     ap.add_argument("--map-frames", type=int, default=20, help="B2-small / B1: sweeps accumulated into the street-canyon map")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default=None, choices=["B2", "B2-small", "B1", "D"],
-                    help="B2 (default at --gpus 1): all returns of the HDL-64E sweep as keypoints over the steady-state ~260 MB map; "
+    ap.add_argument("--workload", default=None, choices=["B2", "B2-small", "B1", "C", "D"],
+                    help="B2 (default at --gpus 1): all returns of the HDL-64E sweep as keypoints over the steady-state ~270 MB map; "
                          "B2-small: the same regime over round 1's 20-frame, 5 MB street map; B1: the reference's keypoint count "
-                         "(1.5 m grid of the 0.5 m-subsampled frame, latency regime) over the B2-small map; D (default at --gpus > 1): "
-                         "dense analytic street, 0.5 m x 40-pt map ~0.5 GB, 125 voxels per query, 1 M keypoints (2 M when sharded)")
+                         "(1.5 m grid of the 0.5 m-subsampled frame, latency regime) over the B2-small map; C: NCLT / HDL-32E profile; D (default at "
+                         "--gpus > 1): Ouster-128-style ray-cast scan, 0.05 m grid keypoints, 0.5 m x 40-pt map of everything within 100 m")
+    ap.add_argument("--sub", default=None, help="comma-separated workloads reported as sub-objects of the line (default at --gpus 1 with the default "
+                                               "workload: B1,C,D; 'none' to skip)")
+    ap.add_argument("--d-sweeps", type=int, default=8, help="workload D: accumulated sub-sweeps of the 128 x 2048 pattern (8 = 2.1 M rays)")
+    ap.add_argument("--d-radius", type=float, default=100.0, help="workload D: radius of the sampled map (100 m = the eviction radius; smaller only for rehearsals)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample of B2 (0 = all)")
     ap.add_argument("--ablate", type=int, default=0, help="measurement hook: skip kernel phases (invalid results)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (all-reduce) loop even with one rank")
     ap.add_argument("--torch-collective", action="store_true", help="sharded loop with torch.distributed.all_reduce between stepwise calls "
                                                                    "instead of the library's own ncclAllReduce")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="keypoints in the CPU baseline sample (0 = all)")
     ap.add_argument("--order", default="auto", choices=["auto", "on", "off"],
                     help="home-voxel ordering of the GN kernels' work (ctgn_set_ordering); auto = the library's cost model")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic, wait fractions)")
@@ -204,6 +644,7 @@ def main():
     if args.inner:
         args.no_pmc = args.no_cpu_baseline = args.no_extras = True
         args.clock_warm = min(args.clock_warm, 30)
+        args.sub = "none"
 
     import torch
     import ct_icp_amd as cia
@@ -214,11 +655,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    default_line = args.workload is None and world == 1
     if args.workload is None:
         args.workload = "B2" if world == 1 else "D"
+    if args.sub is None:
+        args.sub = "B1,C,D" if (default_line and not args.ablate and args.variant == 0) else "none"
+    subs = [w for w in args.sub.split(",") if w and w != "none"]
     if args.dist_backend == "gloo":
         args.torch_collective = True
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    args.local_rank = local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_dist
@@ -231,212 +677,47 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # ------------------------------------------------------------------------------------------------ inputs
-    if args.workload == "D":
-        inp = make_inputs_dense(0, n_kp=2_000_000 if world > 1 else 1_000_000)      # ONE scan for all ranks (strong scaling)
-        res_param, radius = cia.ResolutionParam(0.5, 0.03, 40), 0.8          # config D map: {0.5 m, 40 pts, 0.03 m}
-    elif args.workload == "B2":
-        inp = make_inputs_large(rank)
-        res_param, radius = cia.ResolutionParam(0.8, 0.1, 30), 0.75         # driving profile
-    else:
-        inp = make_inputs(rank, args.map_frames)
-        res_param, radius = cia.ResolutionParam(0.8, 0.1, 30), 0.75
-    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[res_param], default_radius=radius, device=local_rank))
-    for s0 in range(0, len(inp["map_points"]), 2_000_000):
-        gm.InsertPointCloud(inp["map_points"][s0:s0 + 2_000_000])
-    gm.Sync()
-    pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.03, seed=4)
-    raw, t = inp["raw"], inp["t"]
-    if args.workload == "B1":                                  # the reference's two-stage grid sampling (odometry.cpp:349,538)
-        sel = syn.grid_sample_indices(raw, 0.5)
-        sel = sel[syn.grid_sample_indices(raw[sel], 1.5)]
-        raw, t = raw[sel], t[sel]
+    # ------------------------------------------------------------------------------------------------ the headline workload
+    W = build_workload(args.workload, rank, world, args, cia, syn, se3)
     if args.workload == "D" and world > 1:
-        raw, t, world0 = shard_of(inp, res_param.resolution, rank, world, pose0)
-    else:
-        world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
-    n_kp = len(t)
-    mm = cia.PreviousFrameMotionModel()
-    mm.previous_frame = cia.TrajectoryFrame.from_pose14(np.concatenate([[0, 0, 0, 1], inp["prev_b"], [0, 0, 0, 1], inp["prev_e"]]), 0, 0)
-
-    def options(iters):   # threshold 0: no early stop, exactly `iters` GN iterations
-        return cia.CTICPOptions(solver=cia.GN, num_iters_icp=iters, threshold_orientation_norm=0.0, debug_print=False)
-
-    sh = None
-    if sharded:
-        from ct_icp_amd.distributed import ShardedGnSolver, allreduce_system
-        sh = ShardedGnSolver(gm, library_collective=not args.torch_collective)
-        solver = sh.solver
-    else:
-        solver = cia.GnSolver(gm)
-    solver.set_variant(args.variant)
-    solver.set_ordering({"auto": -1, "off": 0, "on": 1}[args.order])
-    solver.set_ablation(args.ablate)
-
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def iterate(k):
-        """k GN iterations of the running loop, enqueued without synchronising."""
-        if sh is not None and args.torch_collective:
-            for _ in range(k):
-                solver.gn_accumulate()
-                allreduce_system(sh.system)
-                solver.gn_solve_update()
-        else:
-            solver.gn_iterate(k, sharded=sh is not None)
-
-    # ------------------------------------------------------------------------------------------------ the timed loop
-    # one upload, then ONE running GN loop: CLOCK_WARM iterations (clocks), W warm-up steps (contract), K timed steps — same launch
-    # sequence and resident data throughout, nothing but a barrier + device synchronisation between the three segments
-    total_iters = args.clock_warm + args.warmup + args.steps
-    solver.set_keypoints(raw, world0, t)                       # inputs resident in HBM before the timed region
-    solver.set_profiling(False)
-    solver.gn_begin(pose0, inp["tbe"], options(total_iters), mm)
-    iterate(args.clock_warm)
-    iterate(args.warmup)
-    sync_all()
-    solver.set_profiling(True)                                 # HIP-event pair around every neighbour-search launch from here on
-    solver.kernel_timing(reset=True)
-    sync_all()
-    t0 = time.perf_counter()
-    iterate(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    pose1, summ = solver.gn_end()[:2]
-    kern_ms, kern_launches = solver.kernel_timing(reset=True)
-    solver.set_profiling(False)
-    assert args.ablate or (summ.success and summ.num_iters == total_iters), summ
-
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        nn = torch.tensor([n_kp], dtype=torch.float64, device="cuda")
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        total_kp = int(nn.item())
-    else:
-        total_kp = n_kp
-
-    # ------------------------------------------------------------------------------------------------ accounting (untimed)
-    # algorithmic bytes of one neighbour-search launch (SURVEY.md 8d): B_kp per keypoint + B_slot per hash probe + B_pt per map point.
-    # "all" charges every point of all 27 / 125 sweep voxels (round 1's figure); "requested" charges what the kernel asks the
-    # memory system for — probes of voxels it did not cull, points it streamed — counted by its instrumented instantiation.
-    solver.set_keypoints(raw, world0, t)
-    probed, hit, points = solver.count_traffic()
-    alg_all = n_kp * B_KP + probed * B_SLOT + points * B_PT
-    alg_req, req_probes, req_points = None, None, None
-    if args.variant == 0 and not args.ablate and not args.inner and gm.SearchParamsFromRadiusSearch()[2] in (1, 2):
-        solver.set_variant(3)
-        solver.traffic_counters(reset=True)
-        # counted on an iteration of the steady state the timed loop is in: every search but the first of a solve is bounded by the
-        # previous one's k-th neighbour distance (DESIGN.md section 3.1), which culls most of the sweep
-        solver.gn_begin(pose0, inp["tbe"], options(total_iters), mm)
-        iterate(10)
-        solver.traffic_counters(reset=True)
-        iterate(1)
-        solver.gn_end()
-        req_probes, req_points = solver.traffic_counters(reset=True)
-        solver.set_variant(0)
-        alg_req = n_kp * B_KP + req_probes * B_SLOT + req_points * B_PT
-
-    # parity on the very workload that was timed: 5 GN iterations (the driving profile's budget) on the GPU and through the oracle
-    parity = None
-    if rank == 0 and not args.inner and not args.ablate:
-        from oracle import oracle as orc
-        om = orc.Map(resolutions=[(res_param.resolution, res_param.min_distance_between_points, res_param.max_num_points)], default_radius=radius)
-        for s0 in range(0, len(inp["map_points"]), 2_000_000):
-            om.insert(inp["map_points"][s0:s0 + 2_000_000])
-        solver.set_keypoints(raw, world0, t)
-        if sh is not None and world > 1:
-            pose_g, summ_g = None, None                        # every rank has to take part: done below, collectively
-        else:
-            pose_g, summ_g = (sh.solve(pose0, inp["tbe"], options(5), mm) if sh is not None else solver.solve(pose0, inp["tbe"], options(5), mm))[:2]
-        parity = dict(om=om)
-    if sh is not None and world > 1 and not args.inner and not args.ablate:
-        solver.set_keypoints(raw, world0, t)
-        pose_g, summ_g = sh.solve(pose0, inp["tbe"], options(5), mm)[:2]
-    if parity is not None:
-        om = parity.pop("om")
-        if args.workload == "D" and world > 1:
-            o_raw, o_t = inp["raw"], inp["t"]
-            o_w0 = se3.ct_transform(pose0, inp["tbe"], o_t, o_raw)
-        else:
-            o_raw, o_t, o_w0 = raw, t, world0
-        op = orc.MotionPrior(previous_begin_tr=inp["prev_b"], previous_end_tr=inp["prev_e"])
-        pose_o, _, so = orc.register_gn(om, o_raw, o_w0, o_t, pose0, inp["tbe"], orc.Options(num_iters_icp=5, threshold_orientation_norm=0.0), op,
-                                        heap_mode=0, num_threads=usable_cores())
-        tr, rot = se3.pose_error(pose_g, pose_o)
-        parity = {"gpu_vs_oracle_m_rad": [tr, rot], "iterations": 5, "n_used_gpu": int(summ_g.num_residuals_used),
-                  "n_used_oracle": int(so.num_residuals_used), "tolerance_m_rad": [1e-4, 1e-4]}
-        assert tr < 1e-4 and rot < 1e-4 and summ_g.num_residuals_used == so.num_residuals_used, parity
-        parity["om"] = om
-
+        # config D sharding: global sort of the scan by home voxel, contiguous chunk per rank — done by the
+        # library (ctgn_set_keypoints_sharded) from the WHOLE scan, which every rank holds
+        W["all_raw"], W["all_t"], W["all_world0"] = W["raw"], W["t"], W["world0"]
+        W["shard"] = (rank, world)
+    live_pmc = world == 1 and not args.no_pmc and not args.ablate and dist is None
+    res, om = measure_workload(W, args, cia, torch, dist, sharded, args.steps, args.warmup, args.clock_warm, world=world, rank=rank, pmc_live=live_pmc,
+                               want_cpu=False, want_steady=not args.inner)
     result = None
     if rank == 0:
-        value = total_kp * args.steps / dt
-        t_k = kern_ms * 1e-3
-        pmc, pmc_src = ({}, "skipped")
-        if world == 1 and not args.no_pmc and not args.ablate and dist is None:
-            pmc, pmc_src = collect_pmc(args)
-        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None
-        alg = alg_req if alg_req is not None else alg_all
-        achieved = alg / t_k / 1e9 if t_k > 0 else 0.0
-        level_mb = (gm.NumVoxels(0) * res_param.max_num_points * 24 + (1 << int(np.ceil(np.log2(max(gm.NumVoxels(0), 1) * 4)))) * 16) / 1e6
-        roof = {"bound": "latency/issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": pmc_src,
-                "achieved_definition": "algorithmic bytes the kernel requests per launch (32 B/keypoint + 16 B per hash probe it issues + 24 B per map "
-                                       "point it streams, counted by the instrumented instantiation) / HIP-event launch time; served mostly by "
-                                       "L2 / Infinity Cache, hence the separate HBM counter figure",
-                "hbm_counter_gbs": (traffic / t_k / 1e9) if traffic and t_k > 0 else None,
-                "hbm_counter_frac": (traffic / t_k / 1e9 / HBM_PEAK_GBS) if traffic and t_k > 0 else None,
-                "kernel": "k_accumulate_rows (voxel-hash neighbour search + k-nearest selection)" if args.variant != 1 else "k_accumulate_lane",
-                "kernel_ms_avg": kern_ms, "kernel_launches": kern_launches,
-                "alg_bytes_per_launch": alg, "alg_bytes_per_keypoint": alg / n_kp,
-                "alg_bytes_per_launch_all_sweep_voxels": alg_all,     # SURVEY.md 8d's formula with every voxel of the sweep: what an unculled search reads
-                "probes_issued_per_keypoint": (req_probes / n_kp) if req_probes is not None else None,
-                "points_streamed_per_keypoint": (req_points / n_kp) if req_points is not None else None,
-                "voxels_in_sweep_per_keypoint": probed / n_kp, "voxels_occupied_per_keypoint": hit / n_kp,
-                "points_in_sweep_per_keypoint": points / n_kp}
-        if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
-            wc = pmc["SQ_WAVE_CYCLES"]
-            roof.update({"wait_frac": pmc["SQ_WAIT_ANY"] / wc, "issue_stall_frac": pmc["SQ_WAIT_INST_ANY"] / wc,
-                         "active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc, "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / wc,
-                         "waves_per_launch": pmc.get("SQ_WAVES")})
-        names = {"B2": "config B2: synthetic HDL-64E sweep (KITTI-00-like, every return a keypoint) over the steady-state driving-profile map "
-                       "of an open residential scene: 0.8 m x 30 pts, radius 0.75 (27 voxels), k=20, everything within the 100 m eviction radius",
-                 "B2-small": "config B2-small: the same sweep regime over round 1's street-canyon map of "
-                             f"{args.map_frames} frames (L2-resident best case)",
-                 "B1": "config B1: street-canyon sweep and map, keypoints = 1.5 m grid of the 0.5 m-subsampled frame (the reference's keypoint "
-                       "count; latency regime)",
-                 "D": "config D: dense analytic street, map {0.5 m, 40 pts} ~0.5 GB (> Infinity Cache), keypoints spread over the whole map, "
-                      "radius 0.8 (125 voxels), k=20" + ("; ONE 2 M-keypoint scan sorted by home voxel and cut into contiguous chunks" if world > 1 else "")}
         result = {
-            "metric": "registered keypoints/sec per GN iter", "value": value, "unit": "keypoints/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "registered keypoints/sec per GN iter", "value": res["value"], "unit": "keypoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if (args.workload == "D" and world > 1) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": names[args.workload], "workload_id": args.workload,
-                       "keypoints_per_gpu": n_kp, "keypoints_total": total_kp, "map_points": int(gm.NumPoints()),
-                       "map_voxels": int(gm.NumVoxels(0)), "searched_level_mb": level_mb, "n_used_last_iter": summ.num_residuals_used,
+            "config": {"workload": NAMES[args.workload], "workload_id": args.workload,
+                       "keypoints_per_gpu": res["keypoints"], "keypoints_total": res["keypoints_total"], "map_points": res["map_points"],
+                       "map_voxels": res["map_voxels"], "searched_level_mb": res["searched_level_mb"], "n_used_last_iter": res["n_used_last_iter"],
+                       "iterations_per_solve": res["iterations_per_solve"], "solves_timed": res["solves_timed"],
                        "parallelism": "single GPU" if world == 1 else f"keypoints sharded x{world} (home-voxel sort, contiguous chunks), map replicated, "
                                                                       + ("1 ncclAllReduce(96 f64) per iteration issued by the library" if not args.torch_collective else
                                                                          f"1 torch.distributed all_reduce(96 f64) per iteration, backend {args.dist_backend}"),
                        "kernel_variant": args.variant, "keypoint_ordering": args.order},
+            "step_definition": f"one GN iteration; the K timed steps are FRESH solves of the profile's budget ({res['iterations_per_solve']} iterations each, "
+                               "ct_icp.cpp:745): per solve the uploaded world points are put back on the device, gn_begin, then the iterations — the first search "
+                               "of every solve has no carried-over bound, exactly as a frame pays it",
+            "first_iteration_ms": res["first_iteration_ms"], "later_iteration_ms": res["later_iteration_ms"], "iteration_split_note": res["iteration_split_note"],
             "clock_warmup_iterations": args.clock_warm,
-            "clock_warmup_note": "untimed iterations of the same running GN loop immediately before the W warm-up and K timed steps (no upload in "
+            "clock_warmup_note": "untimed iterations of the same fresh-solve loop immediately before the W warm-up and K timed steps (no upload in "
                                  "between): the GPU leaves its idle clocks only under sustained load",
-            "frames_per_sec_equiv": 1.0 / (dt / args.steps * 5) if dt > 0 else None,   # 5 GN iterations per frame (driving profile)
-            "roofline": roof,
+            "frames_per_sec_equiv": res["frames_per_sec_equiv"],
+            "roofline": res["roofline"],
         }
-        om = None
-        if parity is not None:
-            om = parity.pop("om")
-            result["parity_m_rad"] = parity["gpu_vs_oracle_m_rad"]
-            result["parity"] = parity
+        for k in ("parity_m_rad", "parity"):
+            if k in res:
+                result[k] = res[k]
+        inp = W["inp"]
         if args.workload in ("B2", "B2-small") and world == 1 and not args.ablate and not args.no_extras and args.variant != 1:
+            gm, mm = W["gm"], W["mm"]
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["frame_stages"] = fs = measure_frame_stages(cia, inp, syn, se3, local_rank)
@@ -449,76 +730,78 @@ def main():
             result["frame_pipeline"] = fs.pop("frame_pipeline")
             result["frame_pipeline"]["frames_per_sec"] = 1e3 / result["frame_pipeline"]["frame_ms"]
         if not args.no_cpu_baseline and args.workload in ("B2", "B2-small") and world == 1:      # rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(inp, pose0, world0, args, om)
+            result["cpu_baseline"] = cpu_baseline(inp, W["pose0"], W["world0"], args, om)
             if result["cpu_baseline"]["value"]:
-                result["gpu_over_cpu"] = value / world / result["cpu_baseline"]["value"]
-                result["gpu_over_cpu_reference_shaped"] = value / world / result["cpu_baseline"]["reference_shaped"]["value"]
+                result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+                result["gpu_over_cpu_reference_shaped"] = result["value"] / result["cpu_baseline"]["reference_shaped"]["value"]
             if "robust_route" in result:                   # same frame, same settings: the two poses must agree
                 rr, cr = result["robust_route"], result["cpu_baseline"]["robust_route"]
                 tr, rot = se3.pose_error(np.array(rr.pop("pose")), np.array(cr.pop("pose")))
                 rr["gpu_vs_cpu_pose_m_rad"] = [tr, rot]
                 rr["gpu_over_cpu_1core"] = cr["ms_per_frame"] / rr["ms_per_frame"]
-        elif "robust_route" in result:
+        elif not args.no_cpu_baseline and world == 1 and not args.inner:
+            result["cpu_baseline"] = cpu_baseline_gn(W, om if om is not None else oracle_map(W), 10.0)
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        if "robust_route" in result:
             result["robust_route"].pop("pose", None)
+    del om
+
+    # ------------------------------------------------------------------------------------------------ the other configurations, one GPU
+    if subs and world == 1:
+        W.clear()
+        import gc
+        gc.collect()
+        result["workloads"] = {}
+        for name in subs:
+            t_sub = time.perf_counter()
+            Ws = build_workload(name, rank, world, args, cia, syn, se3)
+            small = name in ("B1", "C")
+            sub_steps = {"B1": 200, "C": 200, "D": 20}.get(name, 50)
+            sres, som = measure_workload(Ws, args, cia, torch, None, False, sub_steps, 10 if small else 5, 100 if small else 10, want_steady=True,
+                                         cpu_seconds=8.0, register_extras=small)
+            sres["config"] = NAMES[name]
+            if name == "D":
+                sres["config_detail"] = {"rays": int(Ws["inp"]["rays"]), "returns": int(Ws["inp"]["returns"])}
+            sres["wall_seconds"] = time.perf_counter() - t_sub
+            result["workloads"][name] = sres
+            del Ws, som
+            gc.collect()
 
     # ------------------------------------------------------------------------------------------------ N > 1 extras
     if world > 1 and not args.inner:
+        from ct_icp_amd.distributed import ShardedGnSolver, allreduce_system
+        gm, mm, pose0, inp = W["gm"], W["mm"], W["pose0"], W["inp"]
         # (a) the same scan on ONE GPU (rank 0, the others wait): the denominator of the strong-scaling efficiency
         single = None
         if rank == 0:
-            s1 = cia.GnSolver(gm)
-            w_all = se3.ct_transform(pose0, inp["tbe"], inp["t"], inp["raw"])
-            s1.set_keypoints(inp["raw"], w_all, inp["t"])
-            s1.gn_begin(pose0, inp["tbe"], options(args.clock_warm + args.steps), mm)
-            s1.gn_iterate(args.clock_warm)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            s1.gn_iterate(args.steps)
-            torch.cuda.synchronize()
-            d1 = time.perf_counter() - t0
-            s1.gn_end()
-            single = {"value": len(inp["t"]) * args.steps / d1, "ms_per_step": d1 / args.steps * 1e3, "keypoints": int(len(inp["t"])),
-                      "note": "the same 2 M-keypoint scan, unsharded, on rank 0's GPU"}
+            W1 = dict(W, raw=W["all_raw"], t=W["all_t"], world0=W["all_world0"])
+            W1.pop("shard", None)
+            R1 = Runner(W1, args, cia, torch, None, False)
+            R1.upload()
+            d1 = R1.timed(R1.fresh, args.steps, args.warmup, args.clock_warm)[0]
+            R1.close()
+            single = {"value": len(W1["t"]) * args.steps / d1, "ms_per_step": d1 / args.steps * 1e3, "keypoints": int(len(W1["t"])),
+                      "note": "the same scan, unsharded, on rank 0's GPU; same fresh-solve loop"}
         dist.barrier()
         # (b) weak-scaling line: one B2-small sweep per rank (its own noise realisation), same sharded loop
-        winp = make_inputs(rank, args.map_frames)
-        gw = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75, device=local_rank))
-        gw.InsertPointCloud(winp["map_points"]); gw.Sync()
-        shw = ShardedGnSolver(gw, library_collective=not args.torch_collective)
-        wp0 = syn.perturb_pose(winp["pose_gt"], 0.003, 0.03, seed=4)
-        shw.set_keypoints(winp["raw"], se3.ct_transform(wp0, winp["tbe"], winp["t"], winp["raw"]), winp["t"])
-        shw.solver.gn_begin(wp0, winp["tbe"], options(args.clock_warm + args.steps), None)
-        def iterate_w(k):
-            if args.torch_collective:
-                for _ in range(k):
-                    shw.solver.gn_accumulate()
-                    allreduce_system(shw.system)
-                    shw.solver.gn_solve_update()
-            else:
-                shw.solver.gn_iterate(k, sharded=True)
-        iterate_w(args.clock_warm)
-        sync_all()
-        t0 = time.perf_counter()
-        iterate_w(args.steps)
-        sync_all()
-        dw = time.perf_counter() - t0
-        shw.solver.gn_end()
+        Ww = build_workload("B2-small", rank, world, args, cia, syn, se3)
+        Rw = Runner(Ww, args, cia, torch, dist, True)
+        Rw.upload()
+        dw = Rw.timed(Rw.fresh, args.steps, args.warmup, args.clock_warm)[0]
+        Rw.close()
         tw = torch.tensor([dw], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        nw = torch.tensor([len(winp["t"])], dtype=torch.float64, device="cuda")
+        nw = torch.tensor([len(Ww["t"])], dtype=torch.float64, device="cuda")
         dist.all_reduce(nw, op=dist.ReduceOp.SUM)
-        shw.close()
         if rank == 0:
             result["strong_scaling_single_gpu_reference"] = single
             if single:
                 result["strong_scaling_efficiency"] = result["value"] / (world * single["value"])
             result["weak_scaling_line"] = {"value": float(nw.item()) * args.steps / float(tw.item()), "ms_per_step": float(tw.item()) / args.steps * 1e3,
-                                           "keypoints_per_gpu": int(len(winp["t"])), "workload": "B2-small sweep per rank, sharded loop", "scaling": "weak"}
+                                           "keypoints_per_gpu": int(len(Ww["t"])), "workload": "B2-small sweep per rank, sharded loop", "scaling": "weak"}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)), flush=True)
     if dist is not None:
-        if sh is not None:
-            sh.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -121,7 +121,10 @@ SYMBOLS = {
     "ctgn_map_sync": (C.c_int, [_H]),
     "ctgn_map_radius_search": (C.c_int, [_H, _dp, C.c_size_t, C.c_double, C.c_int32, _dp, C.POINTER(C.c_int32)]),
     "ctgn_set_keypoints": (C.c_int, [_H, View, View, View, C.c_size_t]),
+    "ctgn_set_rewind": (C.c_int, [_H, C.c_int32]),
+    "ctgn_rewind_keypoints": (C.c_int, [_H]),
     "ctgn_solve": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
+    "ctgn_set_keypoints_sharded": (C.c_int, [_H, View, View, View, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_solve_sharded": (C.c_int, [_H, _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior), C.POINTER(Summary)]),
     "ctgn_dist_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "ctgn_dist_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
@@ -164,6 +167,7 @@ SYMBOLS = {
     "ctgn_count_traffic": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ctgn_set_profiling": (C.c_int, [_H, C.c_int32]),
     "ctgn_kernel_timing": (C.c_int, [_H, _dp, C.POINTER(C.c_int32), C.c_int32]),
+    "ctgn_kernel_timing_split": (C.c_int, [_H, _dp, C.POINTER(C.c_int32), C.c_int32]),
     "ctgn_set_variant": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),

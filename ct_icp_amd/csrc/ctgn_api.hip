@@ -34,6 +34,7 @@ struct DeviceLevel {
 
 struct EventPair {
     hipEvent_t start = nullptr, stop = nullptr;
+    int bounded = 0;         // the launch it brackets had a carried-over bound (not the first search of a solve)
 };
 
 }  // namespace
@@ -61,6 +62,8 @@ struct ctgn_context {
     bool order_valid = false, order_stale = true;
     bool kp_coherent = false;           // the upload's own order is spatially coherent (scan order): consecutive keypoints mostly share or
                                         // neighbour their home voxel; an incoherent one (shuffled, config D) is what ordering is for
+    bool kp_presorted = false;          // the resident keypoints ARE in home-voxel order (ctgn_set_keypoints_sharded): nothing to sort, and
+                                        // the tiles are dealt per XCD like an ordered upload's
     bool dense_ok = false;              // the ordered positions crowd their home voxels: k_search_dense instead of k_accumulate_rows
     int dense_mode = -1;                // -1 automatic (by the run count of the order), 0 never, 1 whenever the upload is ordered
     int planned_iters = 0;              // iteration budget of the running solve (num_iters_icp)
@@ -78,6 +81,10 @@ struct ctgn_context {
     uint32_t *d_res = nullptr;          // [cap_kp][SEL_STRIDE] row-phase -> lane-phase hand-over records
     double *h_kp = nullptr;             // pinned staging, same layout
     double t_min = 0, t_max = 0;
+    bool keep_world0 = false;           // ctgn_set_rewind: every upload leaves a copy of its world arrays in d_world0
+    bool world0_valid = false;          // ... and the copy belongs to the resident keypoints
+    double *d_world0 = nullptr;         // [3][kp_stride]
+    size_t world0_cap = 0;              // in doubles
 
     // undistortion staging (ctgn_transform_points): 7 x tp_cap doubles on the device, 4 x tp_cap pinned
     double *d_tp = nullptr, *h_tp = nullptr;
@@ -91,6 +98,7 @@ struct ctgn_context {
     double *d_partials = nullptr;
     double *d_pose_in = nullptr;
     double *h_pose_in = nullptr;        // pinned
+    bool pose_in_valid = false;         // d_pose_in[0..14) holds (in stream order) what h_pose_in[0..14) holds
     GnParams prm{};
     ctgn_options gn_opts{};
     int launched_iters = 0;
@@ -119,8 +127,11 @@ struct ctgn_context {
     bool profiling = false;
     std::vector<EventPair> events;
     int events_used = 0;
+    int events_base = 0;                // events of earlier solves that were begun but not ended (all their launches did work)
     double acc_ms = 0.0;
     int acc_launches = 0;
+    double acc_ms_split[2] = {0.0, 0.0};      // [0] first search of a solve (radius only), [1] searches with a carried-over bound
+    int acc_launches_split[2] = {0, 0};
 
     // robust-loss route (ctgn_robust.hpp)
     RobustState *d_rstate = nullptr;
@@ -443,13 +454,13 @@ ctgn_status order_keypoints(ctgn_handle h, const MapView &mv) {
     double res;
     search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
     const uint64_t level_points = h->update_mode == 1 ? h->devlevels[map_id].host.num_points : h->levels[map_id].num_points;
-    if (!want_order(h, level_points)) return CTGN_OK;
+    if (h->kp_presorted || !want_order(h, level_points)) return CTGN_OK;
     const size_t c = (size_t) h->kp_stride;
     DMCHK(h, order_by_home_voxel(h->ord, h->d_kp + 4 * c, h->d_kp + 5 * c, h->d_kp + 6 * c, (size_t) h->n_kp, mv.resolution, h->stream));
     ctgn_status rs = order_reserve(h);
     if (rs != CTGN_OK) return rs;
     hipLaunchKernelGGL(k_kp_permute, dim3(grid_for((size_t) h->n_kp)), dim3(256), 0, h->stream, h->d_kp, c, h->ord.order, h->n_kp,
-                       h->d_kp_sorted);
+                       h->d_kp_sorted, c);
     HIPCHK(h, hipGetLastError());
     h->order_valid = true;
     // Which search kernel? k_search_dense (ctgn_dense.hpp) shares one probe + one scalar-fed candidate scan among the positions of a
@@ -566,6 +577,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             h->events.push_back(p);
         }
         ev = &h->events[h->events_used++];
+        ev->bounded = kv.kth_valid;
         HIPCHK(h, hipEventRecord(ev->start, h->stream));
     }
     int grid;
@@ -605,7 +617,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             static const int env_xcd = [] { const char *e = std::getenv("CTGN_XCD_SPLIT"); return e ? std::atoi(e) : -1; }();     // measurement hook
             // one contiguous eighth of the tiles per XCD: +4 % on config D (uniformly spread keypoints), -50 % on a sweep whose density
             // varies along the sort key (the eighths then differ in work: B2 over the 270 MB map 0.145 -> 0.215 ms) -> incoherent uploads only
-            kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : (h->order_valid && !h->kp_coherent)) && g1 >= 64 ? 1 : 0;
+            kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : ((h->order_valid && !h->kp_coherent) || h->kp_presorted)) && g1 >= 64 ? 1 : 0;
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
                                dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
             h->kth_fresh = true;
@@ -675,10 +687,13 @@ void harvest_events(ctgn_handle h, int real_launches) {
             if (hipEventElapsedTime(&ms, h->events[i].start, h->events[i].stop) == hipSuccess) {
                 h->acc_ms += ms;
                 h->acc_launches++;
+                h->acc_ms_split[h->events[i].bounded ? 1 : 0] += ms;
+                h->acc_launches_split[h->events[i].bounded ? 1 : 0]++;
             }
         }
     }
     h->events_used = 0;
+    h->events_base = 0;
 }
 
 }  // namespace
@@ -797,6 +812,7 @@ void ctgn_destroy(ctgn_handle h) {
         devmap_scratch_free(h->dm);
         order_scratch_free(h->ord);
         if (h->d_kp_sorted) hipFree(h->d_kp_sorted);
+        if (h->d_world0) hipFree(h->d_world0);
         if (h->d_kp) hipFree(h->d_kp);
         if (h->d_tp) hipFree(h->d_tp);
         if (h->h_tp) hipHostFree(h->h_tp);
@@ -1034,11 +1050,50 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
     h->kth_fresh = false;               // new keypoints: no search of theirs has left a k-th distance
     h->order_stale = true;
     h->order_valid = false;
+    h->kp_coherent = false;             // probed per upload where the world points pass through the host (ctgn_set_keypoints)
+    h->kp_presorted = false;
+    h->world0_valid = false;
     h->kp_stride = (int) std::min<size_t>((n + 63) & ~(size_t) 63, (size_t) h->cap_kp);
     if (n >= 32768 && h->ordering_mode != 0) {       // this upload may be ordered (want_order): have the buffers ready
         ctgn_status rs = order_reserve(h);
         if (rs != CTGN_OK) return rs;
     }
+    return CTGN_OK;
+}
+
+// ctgn_set_rewind: leave a copy of the freshly uploaded world arrays for ctgn_rewind_keypoints (one device-to-device copy, enqueued)
+static ctgn_status save_world0(ctgn_handle h) {
+    if (!h->keep_world0 || h->n_kp == 0) return CTGN_OK;
+    const size_t c = (size_t) h->kp_stride;
+    if (h->world0_cap < 3 * (size_t) h->cap_kp) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_world0) HIPCHK(h, hipFree(h->d_world0));
+        h->d_world0 = nullptr; h->world0_cap = 0;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_world0), 3 * (size_t) h->cap_kp * sizeof(double)));
+        h->world0_cap = 3 * (size_t) h->cap_kp;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_world0, h->d_kp + 4 * c, (2 * c + (size_t) h->n_kp) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->world0_valid = true;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_rewind(ctgn_handle h, int32_t enable) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    h->keep_world0 = enable != 0;
+    if (!h->keep_world0) h->world0_valid = false;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_rewind_keypoints(ctgn_handle h) {
+    NEED_DEVICE(h);
+    if (!h->world0_valid)
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no saved world points: call ctgn_set_rewind(h, 1) before ctgn_set_keypoints");
+    const size_t c = (size_t) h->kp_stride;
+    if (h->n_kp)
+        HIPCHK(h, hipMemcpyAsync(h->d_kp + 4 * c, h->d_world0, (2 * c + (size_t) h->n_kp) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->kth_fresh = false;               // the k-th distances on the device belong to world points that are gone
+    h->order_stale = !h->kp_presorted;  // the position-ordered working copy (if any) holds the previous solve's world points
+    h->order_valid = false;
     return CTGN_OK;
 }
 
@@ -1064,6 +1119,8 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         if (gs == CTGN_OK) gs = device_minmax(h, h->d_kp + 3 * c, n, &tmin, &tmax);
         if (gs != CTGN_OK) return gs;
         h->t_min = tmin; h->t_max = tmax;
+        gs = save_world0(h);
+        if (gs != CTGN_OK) return gs;
         return ensure_debug(h);
     }
     for (size_t i = 0; i < n; ++i) {
@@ -1106,9 +1163,9 @@ ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw, ctgn_view world, ct
         h->pose_on_device = true;
     }
     if (n) HIPCHK(h, hipMemcpyAsync(h->d_kp, h->h_kp, words * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    ctgn_status st = ensure_debug(h);
+    ctgn_status st = save_world0(h);
     if (st != CTGN_OK) return st;
-    return CTGN_OK;
+    return ensure_debug(h);
 }
 
 static void scatter_world_from_staging(ctgn_handle h, void *world_base, size_t stride, ctgn_dtype dt, size_t n) {
@@ -1162,14 +1219,17 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     fill_params(h, opts, prior);
     // h_pose_in is reused: every other user synchronises before returning, only an unfinished stepwise loop can still
     // have a copy from it in flight
-    if (h->gn_active) HIPCHK(h, hipStreamSynchronize(h->stream));
     const double *d_pose = h->d_pose_in;
     if (h->pose_on_device) {                          // already behind the keypoint arrays (ctgn_register)
         d_pose = h->d_kp + 7 * (size_t) h->kp_stride;
         h->pose_on_device = false;
+    } else if (h->pose_in_valid && std::memcmp(h->h_pose_in, pose, 14 * sizeof(double)) == 0) {
+        // the same initial pose as the last upload (a registration retried / repeated on the same keypoints): it is on the device already
     } else {
+        if (h->gn_active) HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->pose_in_valid = true;
     }
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
     HIPCHK(h, hipGetLastError());
@@ -1177,7 +1237,10 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     h->searches_in_solve = 0;
     h->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
     h->planned_iters = opts->num_iters_icp;
-    h->events_used = 0;
+    // a solve begun while the previous one was never ended (repeated solves enqueued back to back): its launches all did work and
+    // their event pairs are harvested with this solve's
+    if (h->gn_active && h->profiling) h->events_base = h->events_used;
+    else { h->events_used = 0; h->events_base = 0; }
     h->gn_active = true;
     HIPCHK(h, hipEventRecord(h->ev_loop_start, h->stream));
     return CTGN_OK;
@@ -1274,7 +1337,7 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
 static ctgn_status gn_collect(ctgn_handle h, double pose_out[14], ctgn_summary *summary) {
     h->gn_active = false;
     const GnState &s = *h->h_state;
-    if (h->profiling) harvest_events(h, s.iter + (s.failed ? 1 : 0));
+    if (h->profiling) harvest_events(h, h->events_base + s.iter + (s.failed ? 1 : 0));
     if (h->gn_opts.debug_print > 1)
         std::fprintf(stderr, "[ctgn] k_reduce_solve clocks: reduce %llu factorise %llu substitute %llu update %llu\n",
                      s.solve_cycles[0], s.solve_cycles[1], s.solve_cycles[2], s.solve_cycles[3]);
@@ -1384,6 +1447,43 @@ ctgn_status ctgn_dist_shutdown(ctgn_handle h) {
     h->comm = nullptr;
     h->dist_rank = 0; h->dist_world = 1;
     return CTGN_OK;
+}
+
+ctgn_status ctgn_set_keypoints_sharded(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n, int32_t rank, int32_t world_size,
+                                       uint32_t *shard_indices, size_t *shard_n) {
+    NEED_DEVICE(h);
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "bad rank / world size");
+    if (shard_n) *shard_n = 0;
+    const bool keep = h->keep_world0;
+    h->keep_world0 = false;                                    // the copy for ctgn_rewind_keypoints is taken of the shard, below
+    ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n); // the whole scan, resident for a moment; t_min / t_max are the scan's
+    h->keep_world0 = keep;
+    if (st != CTGN_OK || n == 0) return st;
+    int map_id, nb;
+    double res;
+    search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
+    const size_t c = (size_t) h->kp_stride;
+    st = order_reserve(h);
+    if (st != CTGN_OK) return st;
+    DMCHK(h, order_by_home_voxel(h->ord, h->d_kp + 4 * c, h->d_kp + 5 * c, h->d_kp + 6 * c, n, res, h->stream));
+    const size_t base = n / (size_t) world_size, rem = n % (size_t) world_size;        // contiguous, balanced chunks
+    const size_t lo = (size_t) rank * base + std::min<size_t>((size_t) rank, rem), m = base + ((size_t) rank < rem ? 1 : 0);
+    const size_t c2 = std::min((m + 63) & ~(size_t) 63, (size_t) h->cap_kp);
+    if (m) {
+        hipLaunchKernelGGL(k_kp_permute, dim3(grid_for(m)), dim3(256), 0, h->stream, h->d_kp, c, h->ord.order + lo, (int) m, h->d_kp_sorted, c2);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->d_kp, h->d_kp_sorted, 7 * c2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (shard_indices && m) HIPCHK(h, hipMemcpyAsync(shard_indices, h->ord.order + lo, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_kp = (int) m;
+    h->kp_stride = (int) c2;
+    h->pose_on_device = false;
+    h->kp_presorted = true;
+    h->order_stale = false;
+    h->order_valid = false;
+    if (shard_n) *shard_n = m;
+    return save_world0(h);
 }
 
 ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double tbe[2], const ctgn_options *opts,
@@ -1501,6 +1601,7 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         if (!(tbe[0] <= lo && hi <= tbe[1])) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->pose_in_valid = true;
         hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, h->d_tp, h->d_tp + 4 * c, (int) n, c,
                            h->d_pose_in, tbe[0], tbe[1]);
         HIPCHK(h, hipGetLastError());
@@ -1940,6 +2041,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     } else {
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->pose_in_valid = true;
     }
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);    // :476-477
     hipLaunchKernelGGL(k_robust_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate);
@@ -2152,7 +2254,17 @@ ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_ms, int32_t *launches,
     NEED_DEVICE(h);
     if (avg_ms) *avg_ms = h->acc_launches ? h->acc_ms / h->acc_launches : 0.0;
     if (launches) *launches = h->acc_launches;
-    if (reset) { h->acc_ms = 0.0; h->acc_launches = 0; }
+    if (reset) { h->acc_ms = 0.0; h->acc_launches = 0; for (int k = 0; k < 2; ++k) { h->acc_ms_split[k] = 0.0; h->acc_launches_split[k] = 0; } }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t launches[2], int32_t reset) {
+    NEED_DEVICE(h);
+    for (int k = 0; k < 2; ++k) {
+        if (avg_ms) avg_ms[k] = h->acc_launches_split[k] ? h->acc_ms_split[k] / h->acc_launches_split[k] : 0.0;
+        if (launches) launches[k] = h->acc_launches_split[k];
+        if (reset) { h->acc_ms_split[k] = 0.0; h->acc_launches_split[k] = 0; }
+    }
     return CTGN_OK;
 }
 

@@ -62,11 +62,11 @@ struct KpView {
 };
 
 // working copy of the keypoint block in position order (ctgn_api.hip, order_keypoints): dst[a][pos] = src[a][order[pos]]
-__global__ void k_kp_permute(const double *src, size_t stride, const uint32_t *order, int n, double *dst) {
+__global__ void k_kp_permute(const double *src, size_t stride, const uint32_t *order, int n, double *dst, size_t dst_stride) {
     for (int pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
         const size_t i = order[pos];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) dst[a * stride + pos] = src[a * stride + i];
+        for (int a = 0; a < 7; ++a) dst[a * dst_stride + pos] = src[a * stride + i];
     }
 }
 

@@ -97,6 +97,14 @@ class ShardedGnSolver:
     def set_keypoints(self, raw, world, t):
         self.solver.set_keypoints(raw, world, t)
 
+    def set_keypoints_of_scan(self, raw, world, t):
+        """The WHOLE scan on every rank: the library sorts it by home voxel and keeps this rank's contiguous chunk (ctgn_set_keypoints_sharded).
+        Returns the chunk's indices into the scan."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        world_size = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return self.solver.set_keypoints_sharded(raw, world, t, rank, world_size)
+
     def solve(self, pose14, t_begin_end, options, motion_model=None):
         s = self.solver
         if self.library_collective:

@@ -294,6 +294,29 @@ class GnSolver:
                                                    L.View(world.ctypes.data, 24, L.CTGN_F64, 0),
                                                    L.View(t.ctypes.data, 8, L.CTGN_F64, 0), self._n))
 
+    def set_keypoints_sharded(self, raw, world, t, rank: int, world_size: int) -> np.ndarray:
+        """ctgn_set_keypoints_sharded: the WHOLE scan in, this rank's chunk of its home-voxel order resident; returns the indices (into the
+        caller's arrays) of the resident keypoints, in resident order."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+        world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        assert len(raw) == len(world) == len(t)
+        idx = np.zeros(len(t) // max(1, world_size) + 1, dtype=np.uint32)
+        m = C.c_size_t()
+        L.check(self._h, L.lib().ctgn_set_keypoints_sharded(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(world.ctypes.data, 24, L.CTGN_F64, 0),
+                                                           L.View(t.ctypes.data, 8, L.CTGN_F64, 0), len(t), int(rank), int(world_size),
+                                                           idx.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(m)))
+        self._n = int(m.value)
+        return idx[:self._n].copy()
+
+    def set_rewind(self, on=True):
+        """ctgn_set_rewind: later uploads keep a device copy of their world points for rewind()."""
+        L.check(self._h, L.lib().ctgn_set_rewind(self._h, int(on)))
+
+    def rewind(self):
+        """ctgn_rewind_keypoints: world points back to what the last set_keypoints uploaded (enqueued, no synchronisation)."""
+        L.check(self._h, L.lib().ctgn_rewind_keypoints(self._h))
+
     def solve(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
         pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
@@ -444,6 +467,12 @@ class GnSolver:
         ms, n = C.c_double(), C.c_int32()
         L.check(self._h, L.lib().ctgn_kernel_timing(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+    def kernel_timing_split(self, reset=False):
+        """((ms, launches) of the first search of a solve, (ms, launches) of the searches with a carried-over bound)."""
+        ms, n = (C.c_double * 2)(), (C.c_int32 * 2)()
+        L.check(self._h, L.lib().ctgn_kernel_timing_split(self._h, ms, n, int(reset)))
+        return (ms[0], n[0]), (ms[1], n[1])
 
     def phase_cycles(self, reset=False):
         out = (C.c_uint64 * 12)()

@@ -90,6 +90,71 @@ class Scene:
         return best
 
 
+def raycast_torch(scene: Scene, origins: np.ndarray, dirs: np.ndarray, max_range: float, device=None, budget_elems: int = 40_000_000) -> np.ndarray:
+    """Scene.raycast with the (rays x primitives) tests done as broadcast torch float64 operations — on the GPU when there is one.
+    For the dense config-D sweep (2.1 M rays against ~8 k primitives: minutes in the per-primitive NumPy loop, seconds here). Same
+    hit rule per primitive as Scene.raycast; the results agree to rounding."""
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    f64 = torch.float64
+    n = len(origins)
+    eps = 1e-6
+    planes = torch.as_tensor(scene.planes, dtype=f64, device=dev)
+    pb = torch.as_tensor(scene.plane_bounds, dtype=f64, device=dev)
+    boxes = torch.as_tensor(scene.boxes.reshape(-1, 6), dtype=f64, device=dev)
+    cyl = torch.as_tensor(scene.cylinders.reshape(-1, 5), dtype=f64, device=dev)
+    sph = torch.as_tensor(scene.spheres.reshape(-1, 4), dtype=f64, device=dev)
+    nprim = max(1, len(planes), len(boxes), len(cyl), len(sph))
+    chunk = max(1024, budget_elems // nprim)
+    inf = torch.tensor(float("inf"), dtype=f64, device=dev)
+    out = np.empty(n)
+    for s0 in range(0, n, chunk):
+        o = torch.as_tensor(origins[s0:s0 + chunk], dtype=f64, device=dev)
+        d = torch.as_tensor(dirs[s0:s0 + chunk], dtype=f64, device=dev)
+        best = torch.full((len(o),), float("inf"), dtype=f64, device=dev)
+        if len(planes):
+            denom = d @ planes[:, :3].T                                   # (R, P)
+            t = -(o @ planes[:, :3].T + planes[:, 3]) / denom
+            hit = o[:, None, :] + t[:, :, None] * d[:, None, :]
+            ok = (denom.abs() > 1e-12) & (t > eps)
+            for a in range(3):
+                ok &= (hit[:, :, a] >= pb[:, 2 * a]) & (hit[:, :, a] <= pb[:, 2 * a + 1])
+            best = torch.minimum(best, torch.where(ok, t, inf).min(dim=1).values)
+        if len(boxes):
+            inv = 1.0 / d
+            tmin = torch.full((len(o), len(boxes)), -float("inf"), dtype=f64, device=dev)
+            tmax = torch.full((len(o), len(boxes)), float("inf"), dtype=f64, device=dev)
+            for a in range(3):
+                t1 = (boxes[None, :, a] - o[:, a, None]) * inv[:, a, None]
+                t2 = (boxes[None, :, 3 + a] - o[:, a, None]) * inv[:, a, None]
+                tmin = torch.fmax(tmin, torch.fmin(t1, t2))
+                tmax = torch.fmin(tmax, torch.fmax(t1, t2))
+            tmin = torch.where((tmax < tmin) | (tmin <= eps), inf, tmin)
+            best = torch.minimum(best, tmin.min(dim=1).values)
+        if len(cyl):
+            ox, oy = o[:, 0, None] - cyl[None, :, 0], o[:, 1, None] - cyl[None, :, 1]
+            dx, dy = d[:, 0, None], d[:, 1, None]
+            A = dx * dx + dy * dy
+            B = 2 * (ox * dx + oy * dy)
+            Cc = ox * ox + oy * oy - cyl[None, :, 2] ** 2
+            disc = B * B - 4 * A * Cc
+            t = (-B - torch.sqrt(torch.clamp(disc, min=0))) / (2 * A)
+            z = o[:, 2, None] + t * d[:, 2, None]
+            ok = (disc > 0) & (A > 1e-12) & (t > eps) & (z >= cyl[None, :, 3]) & (z <= cyl[None, :, 4])
+            best = torch.minimum(best, torch.where(ok, t, inf).min(dim=1).values)
+        if len(sph):
+            oc = o[:, None, :] - sph[None, :, :3]
+            B = 2 * (oc * d[:, None, :]).sum(-1)
+            Cc = (oc * oc).sum(-1) - sph[None, :, 3] ** 2
+            disc = B * B - 4 * Cc
+            t = (-B - torch.sqrt(torch.clamp(disc, min=0))) / 2
+            ok = (disc > 0) & (t > eps)
+            best = torch.minimum(best, torch.where(ok, t, inf).min(dim=1).values)
+        best = torch.where(best > max_range, inf, best)
+        out[s0:s0 + chunk] = best.cpu().numpy()
+    return out
+
+
 def _inf_bounds():
     return [-np.inf, np.inf, -np.inf, np.inf, -np.inf, np.inf]
 
@@ -308,14 +373,14 @@ class Scan:
 
 def generate_scan(scene: Scene, dirs: np.ndarray, rel_t: np.ndarray, pose14: np.ndarray, t_begin: float,
                   t_end: float, max_range: float = 100.0, min_range: float = 1.0, noise: float = 0.0,
-                  seed: int = 0) -> Scan:
-    """Ray-cast one sweep with the sensor moving continuously from the begin to the end pose."""
+                  seed: int = 0, use_torch: bool = False) -> Scan:
+    """Ray-cast one sweep with the sensor moving continuously from the begin to the end pose (use_torch: raycast_torch)."""
     rng = np.random.default_rng(seed)
     alpha = rel_t
     q = se3.quat_normalize(se3.quat_slerp(pose14[0:4], pose14[7:11], alpha))
     origin = (1 - alpha)[:, None] * pose14[4:7] + alpha[:, None] * pose14[11:14]
     wdirs = se3.quat_rotate(q, dirs)
-    rng_hit = scene.raycast(origin, wdirs, max_range)
+    rng_hit = raycast_torch(scene, origin, wdirs, max_range) if use_torch else scene.raycast(origin, wdirs, max_range)
     ok = np.isfinite(rng_hit) & (rng_hit > min_range)
     r = rng_hit[ok]
     if noise > 0:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define CTGN_ABI_VERSION 4
+#define CTGN_ABI_VERSION 5
 #define CTGN_MAX_RESOLUTIONS 8
 /* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
 #define CTGN_MIN_KEYPOINTS_USED 100
@@ -196,6 +196,15 @@ typedef struct {
 /* Upload a keypoint set (raw xyz, world xyz, timestamp) to the device. */
 ctgn_status ctgn_set_keypoints(ctgn_handle h, ctgn_view raw_xyz, ctgn_view world_xyz, ctgn_view timestamps,
                                size_t n);
+/* Keep a device-side copy of the world points of every later ctgn_set_keypoints so that ctgn_rewind_keypoints can put them back
+ * without another upload: a registration retried on the SAME keypoints from their initial world points — what Odometry::TryRegister
+ * does when it re-registers a frame with more robust settings (the do / while around TryRegister, reference src/ct_icp/odometry.cpp:794-845) — and what bench.py does
+ * to time fresh solves with the inputs resident in HBM. Off by default (it costs one device-to-device copy per upload). */
+ctgn_status ctgn_set_rewind(ctgn_handle h, int32_t enable);
+/* Restore the resident keypoints' world points to what the last ctgn_set_keypoints uploaded (enqueued on the handle's stream, no
+ * synchronisation) and forget everything the previous solve left per keypoint (carried-over search bounds, ordering). Needs
+ * ctgn_set_rewind(h, 1) before that upload. */
+ctgn_status ctgn_rewind_keypoints(ctgn_handle h);
 /* Run the GN loop on the resident keypoints. pose_io = begin(7) | end(7); t_begin_end = dest_timestamp
  * of begin_pose / end_pose. Replaces DoRegisterGaussNewton (ct_icp.cpp:709-996). */
 ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double t_begin_end[2],
@@ -361,6 +370,15 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
 ctgn_status ctgn_dist_unique_id(uint8_t out[CTGN_DIST_ID_BYTES]);
 ctgn_status ctgn_dist_init(ctgn_handle h, int32_t rank, int32_t world_size, const uint8_t id[CTGN_DIST_ID_BYTES]);
 ctgn_status ctgn_dist_shutdown(ctgn_handle h);
+/* Config D's partition done by the library ("keypoints split into G contiguous chunks after the voxel-key sort"): every
+ * rank passes the WHOLE scan (n keypoints; host or device views as for ctgn_set_keypoints); the library sorts it on the device by the home
+ * voxel of the world points at the searched resolution (stable, deterministic: every rank computes the same order) and keeps the rank-th of
+ * world_size contiguous, balanced chunks as this handle's resident keypoints, already in the order the kernels want (no second sort).
+ * shard_indices (host, nullable, >= n / world_size + 1 entries): index in the caller's arrays of resident keypoint j — what
+ * ctgn_get_world_points's j-th row belongs to; *shard_n: how many this rank holds. The timestamp check of the solve uses the whole scan's
+ * range, so every rank accepts or rejects the same scan (no rank is left waiting in the all-reduce). */
+ctgn_status ctgn_set_keypoints_sharded(ctgn_handle h, ctgn_view raw_xyz, ctgn_view world_xyz, ctgn_view timestamps, size_t n,
+                                       int32_t rank, int32_t world_size, uint32_t *shard_indices, size_t *shard_n);
 ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double t_begin_end[2], const ctgn_options *opts,
                                const ctgn_motion_prior *prior, ctgn_summary *summary);
 /* Non-blocking query of the device-side stop flag of the running GN loop (synchronises the stream). */
@@ -449,6 +467,9 @@ ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *voxels_probed, uint64_t 
 ctgn_status ctgn_set_profiling(ctgn_handle h, int32_t enable);
 /* Average HIP-event time (ms) of the accumulate kernel over the launches that did work since the last reset. */
 ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t *launches, int32_t reset);
+/* The same, split by what bounded the search: [0] = the first search of a solve (radius only: nothing carried over), [1] = every later
+ * one (bounded by the previous search's k-th neighbour distance + the keypoint's displacement). */
+ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t launches[2], int32_t reset);
 /* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
  * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection,
  * 3 = variant 0 instrumented with per-phase shader clocks (see ctgn_phase_cycles), 4 = variant 0 compiled for

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ctgn.h but not exported by libctgn.so"
     assert set(declared) == set(L.SYMBOLS), set(declared) ^ set(L.SYMBOLS)
-    assert lib.ctgn_abi_version() == 4
+    assert lib.ctgn_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -1387,3 +1387,98 @@ def test_soft_failure_at_a_later_iteration_returns_the_last_completed_state(box_
     assert tr < 1e-5 and rot < 1e-6                                          # a 40 m jump through a 1e6-weighted prior: conditioning, not parity
     assert np.abs(s.world_points() - world_o).max() < 1e-4
     assert np.abs(s.world_points() - world0).max() > 10.0                    # not the uploaded points: the last completed iteration's
+
+
+# ------------------------------------------------------------------------------------------------- round 3: rewind, library-side sharding
+def test_rewind_restarts_a_solve_from_the_uploaded_world_points(street_case):
+    """ctgn_set_rewind / ctgn_rewind_keypoints (include/ctgn.h): a registration repeated on the resident keypoints from their uploaded world
+    points — the retry loop around TryRegister, reference src/ct_icp/odometry.cpp:794-845 — without another upload. Bit-identical to a
+    fresh upload + solve; without the rewind the second solve starts from the first one's world points and differs."""
+    om, gm = build_maps(street_case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(street_case, 6, 0.4)
+    o = _opts(num_iters_icp=4, threshold_orientation_norm=0.0)
+    mm, _ = _prior(street_case, 6)
+    s = cia.GnSolver(gm)
+    with pytest.raises(L.CtgnError):
+        s.rewind()                                          # nothing saved yet
+    s.set_rewind(True)
+    s.set_keypoints(raw, world0, t)
+    pose_a, summ_a, _ = s.solve(pose0, sc.t_begin_end, o, mm)
+    world_a = s.world_points()
+    pose_n, _, _ = s.solve(pose0, sc.t_begin_end, o, mm)                 # no rewind: iteration 0 searches at the previous solve's world points
+    assert np.abs(pose_n - pose_a).max() > 0
+    s.rewind()
+    pose_b, summ_b, _ = s.solve(pose0, sc.t_begin_end, o, mm)
+    assert np.array_equal(pose_a, pose_b) and summ_a.num_residuals_used == summ_b.num_residuals_used
+    assert np.array_equal(world_a, s.world_points())
+    # back-to-back solves without ending the previous one (what bench.py times): the last one still equals a fresh solve
+    s.set_profiling(True)
+    s.kernel_timing(reset=True)
+    for _ in range(3):
+        s.rewind()
+        s.gn_begin(pose0, sc.t_begin_end, o, mm)
+        s.gn_iterate(4)
+    pose_c, summ_c, _ = s.gn_end()
+    assert np.array_equal(pose_a, pose_c) and summ_c.num_iters == 4
+    (ms0, n0), (ms1, n1) = s.kernel_timing_split(reset=True)
+    assert n0 == 3 and n1 == 9 and ms0 > 0 and ms1 > 0     # 3 first-of-solve searches (radius only), 9 with a carried-over bound
+    s.set_profiling(False)
+
+
+def test_library_side_sharding_on_one_gpu(street_case):
+    """ctgn_set_keypoints_sharded: every rank hands over the whole scan, the library sorts it by home voxel and keeps
+    the rank's contiguous chunk. Two 'ranks' played one after the other on the one GPU: the chunks partition the scan, each chunk is a
+    contiguous run of the voxel-sorted order, the two packed systems add up to the unsharded system, and a timestamp outside the pose
+    interval anywhere in the scan is refused by EVERY rank (no rank left waiting in the all-reduce)."""
+    om, gm = build_maps(street_case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(street_case, 6, 0.3)
+    o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
+    s = cia.GnSolver(gm)
+    s.set_keypoints(raw, world0, t)
+    s.solve(pose0, sc.t_begin_end, o)
+    A, b, n = s.get_system()
+    As, bs, ns, seen = np.zeros_like(A), np.zeros_like(b), 0, []
+    res = street_case["resolutions"][0][0]
+    for rank in (0, 1):
+        idx = s.set_keypoints_sharded(raw, world0, t, rank, 2)
+        seen.append(idx)
+        vox = np.trunc(world0[idx] / res).astype(np.int64)
+        key = ((vox[:, 0] & 4095) << 20) | ((vox[:, 1] & 4095) << 8) | (vox[:, 2] & 255)
+        assert np.all(np.diff(key) >= 0)                    # resident order = home-voxel order
+        s.gn_begin(pose0, sc.t_begin_end, o, None)
+        s.gn_accumulate()
+        Ad, bd, nd = s.get_system()
+        s.gn_solve_update(); s.gn_end()
+        As += Ad; bs += bd; ns += nd
+        w = s.world_points()
+        assert w.shape == (len(idx), 3)
+    both = np.concatenate(seen)
+    assert len(both) == len(t) and np.array_equal(np.sort(both), np.arange(len(t))) and abs(len(seen[0]) - len(seen[1])) <= 1
+    assert ns == n and np.abs(As - A).max() < 1e-12 * np.abs(A).max() and np.abs(bs - b).max() < 1e-12 * np.abs(b).max() + 1e-18
+    # one bad timestamp in the OTHER rank's half: this rank refuses the solve too
+    t_bad = t.copy()
+    t_bad[seen[1][0]] = sc.t_begin_end[1] + 1.0
+    s.set_keypoints_sharded(raw, world0, t_bad, 0, 2)
+    with pytest.raises(L.CtgnError) as e:
+        s.gn_begin(pose0, sc.t_begin_end, o, None)
+    assert e.value.status == L.ERR_TIMESTAMP_RANGE
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+    """The N > 1 path of bench.py where the driver's GPU tier can see it: two gloo ranks sharing the one GPU run config D (reduced: one
+    sub-sweep of the Ouster pattern) through ctgn_set_keypoints_sharded and the sharded loop; the line must carry the strong-scaling
+    fields and the pose parity of the sharded solve against the oracle on the whole scan."""
+    import json, os, subprocess, sys
+    root = ROOT_DIR
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29563",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "0", "--clock-warm", "0", "--workload", "D",
+           "--d-sweeps", "1", "--d-radius", "45", "--no-pmc"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload_id"] == "D"
+    assert d["config"]["keypoints_total"] > 100_000 and abs(d["config"]["keypoints_per_gpu"] * 2 - d["config"]["keypoints_total"]) <= 1
+    assert d["parity_m_rad"][0] < 1e-4 and d["parity_m_rad"][1] < 1e-4 and d["parity"]["n_used_gpu"] == d["parity"]["n_used_oracle"]
+    assert d["strong_scaling_single_gpu_reference"]["keypoints"] == d["config"]["keypoints_total"] and "weak_scaling_line" in d
