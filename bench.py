@@ -1050,7 +1050,9 @@ def cpu_baseline(inp, pose0, world0, args, om=None):
             frames["reference"] = {"ms_per_frame": float(np.median(ts)), "frames_per_sec": 1e3 / float(np.median(ts)), "cores": 1,
                                    "gn_iterations": int(s_ref.num_iters), "map_build_seconds": build_s,
                                    "what": "CT_ICP_Registration::Register of the reference's own sources (oracle/_ref/libctgn_ref.so, "
-                                           "compiled against header shims), its MultipleResolutionVoxelMap holding the same map points"}
+                                           "compiled against header shims), its MultipleResolutionVoxelMap holding the same map points",
+                                   "caveat": "the linear algebra underneath is oracle/shims/mini_eigen.h — a plain-C++ stand-in for Eigen, NOT vectorised "
+                                             "(a stock Eigen build runs SSE2 packets): the reference's own arithmetic would be somewhat faster than this"}
     except Exception as e:        # noqa: BLE001 — the reference build is optional on a box
         frames["reference"] = {"unavailable": f"{type(e).__name__}: {e}"}
     # the steps either side of the path on one core, as the reference runs them (only its undistortion loop is OpenMP)

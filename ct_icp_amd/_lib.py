@@ -174,6 +174,8 @@ SYMBOLS = {
     "ctgn_set_search_kernel": (C.c_int, [_H, C.c_int32]),
     "ctgn_traffic_counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_phase_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
+    "ctgn_test_sort_pairs": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
+    "ctgn_test_compact": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 

@@ -166,7 +166,7 @@ struct ctgn_context {
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
-    uint64_t skipped_points_total = 0;  // insert calls that met points outside the voxel key range / non-finite (skipped, inserted = 0)
+    uint64_t insert_calls_with_skips = 0;  // insert CALLS that met points outside the voxel key range / non-finite (those points: skipped, inserted = 0)
     std::string last_error;
 };
 
@@ -894,7 +894,7 @@ static ctgn_status devmap_insert_staged(ctgn_handle h, size_t n, uint8_t *out) {
         // the batch HAS been inserted (every in-range point) and `out` says 0 for the skipped ones: report it, do not fail the call —
         // a caller that retried after an error would insert the batch twice
         for (auto &DL : h->devlevels) (void) hipMemsetAsync(&DL.counters->range_error, 0, sizeof(unsigned int), h->stream);
-        h->skipped_points_total++;
+        h->insert_calls_with_skips++;
         h->last_error = "a point fell outside the 21-bit voxel key range (or was not finite) and was skipped";
     }
     return CTGN_OK;
@@ -920,7 +920,7 @@ ctgn_status ctgn_map_insert(ctgn_handle h, const void *xyz_base, size_t stride, 
         if (out) out[i] = (uint8_t) any;
     }
     if (range_error) {                              // inserted = 0 for the skipped points; the map holds all the others: not an error
-        h->skipped_points_total++;
+        h->insert_calls_with_skips++;
         h->last_error = "a point fell outside the 21-bit voxel key range (or was not finite) and was skipped";
     }
     return CTGN_OK;
@@ -1736,9 +1736,16 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
     double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     bool has_nan = false, bad_order = false;
+    // `order` must be a permutation: an index out of range or met twice would leave rows of the outputs unwritten (one bit per index)
+    std::vector<uint64_t> seen(order ? (n + 63) / 64 : 0, 0ull);
     auto stage_one = [&](size_t j, int u) {
         const size_t i = order ? (size_t) order[j] : j;
         if (i >= n) { bad_order = true; return; }
+        if (order) {
+            const uint64_t bit = 1ull << (i & 63);
+            if (seen[i >> 6] & bit) { bad_order = true; return; }
+            seen[i >> 6] |= bit;
+        }
         double *q = hs + 4 * j;
         if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
         else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
@@ -2293,6 +2300,23 @@ ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, s
     const size_t n = std::min(max_waves, (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES);
     HIPCHK(h, hipMemcpy(out, h->d_prof + 16, 4 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *n_waves = n;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, int32_t key_bits, int32_t key_bytes, uint32_t *order_out) {
+    NEED_DEVICE(h);
+    if ((n && (!keys || !order_out)) || key_bits < 1 || key_bits > 64 || (key_bytes != 4 && key_bytes != 8) || n > ((size_t) 1 << 30))
+        return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DMCHK(h, devmap_test_sort(keys, n, key_bits, key_bytes, order_out, h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_test_compact(ctgn_handle h, const uint8_t *flags, size_t n, uint32_t *out_indices, size_t *out_count) {
+    NEED_DEVICE(h);
+    if (!out_count || (n && (!flags || !out_indices)) || n > ((size_t) 1 << 30)) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DMCHK(h, devmap_test_compact(flags, n, out_indices, out_count, h->stream));
     return CTGN_OK;
 }
 

@@ -1,8 +1,8 @@
-// ctgn_devmap.hip — device-resident voxel-map maintenance (see ctgn_devmap.hpp). Separate translation unit because of
-// hipcub (rocPRIM radix sort).
+// ctgn_devmap.hip — device-resident voxel-map maintenance, the samplers and the keypoint ordering (see ctgn_devmap.hpp). Sorting
+// and compaction are the kernels of ctgn_sort.hpp (stable radix sort in one launch for a frame's batch, three kernels per executed
+// pass beyond 16 k keys; ordered compaction without a scan kernel) — no library underneath.
 #include "ctgn_devmap.hpp"
-
-#include <hipcub/hipcub.hpp>
+#include "ctgn_sort.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -349,14 +349,7 @@ hipError_t devmap_scratch_reserve(DevMapScratch &S, size_t n) {
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_keys), gs_cap * sizeof(unsigned long long)));
     DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.gs_first), gs_cap * sizeof(uint32_t)));
     S.gs_cap = gs_cap;
-    size_t tmp = 0, tmp2 = 0, tmp3 = 0;
-    DM_CHK(hipcub::DeviceSelect::Flagged(nullptr, tmp3, hipcub::CountingInputIterator<uint32_t>(0u), S.inserted, S.sel_out, S.sel_count,
-                                         (int) cap, (hipStream_t) 0));
-    DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) cap, 0, 64, (hipStream_t) 0));
-    DM_CHK(hipcub::DeviceSelect::Flagged(nullptr, tmp2, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) cap, (hipStream_t) 0));
-    tmp = std::max(std::max(tmp, tmp2), tmp3);
-    DM_CHK(hipMalloc(&S.cub_temp, tmp));
-    S.cub_temp_bytes = tmp;
+    DM_CHK(sort_scratch_reserve(S.sort, cap));
     S.cap = cap;
     return hipSuccess;
 }
@@ -370,7 +363,7 @@ void devmap_scratch_free(DevMapScratch &S) {
     if (S.inserted) (void) hipFree(S.inserted);
     if (S.sel_out) (void) hipFree(S.sel_out);
     if (S.sel_count) (void) hipFree(S.sel_count);
-    if (S.cub_temp) (void) hipFree(S.cub_temp);
+    sort_scratch_free(S.sort);
     if (S.h_pts) (void) hipHostFree(S.h_pts);
     if (S.h_inserted) (void) hipHostFree(S.h_inserted);
     if (S.h_count) (void) hipHostFree(S.h_count);
@@ -424,8 +417,8 @@ hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStrea
     const unsigned grid = (unsigned) ((n + 255) / 256);
     hipLaunchKernelGGL(k_dm_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, L.resolution, S.keys, S.idx, L.counters);
     DM_CHK(hipGetLastError());
-    size_t tmp = S.cub_temp_bytes;
-    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 64, stream));
+    // stable: the points of a voxel stay in batch order, which is what the insert rule walks (map.h:261-293)
+    DM_CHK(sort_pairs<uint64_t>(S.sort, S.keys, S.keys_alt, S.idx, S.idx_alt, n, 64, true, stream));
     hipLaunchKernelGGL(k_dm_insert, dim3(grid), dim3(256), 0, stream, L.slots, (uint32_t) (L.slots_cap - 1), L.blocks, L.blk, L.nblocks_cap,
                        L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.stride, L.min_distance * L.min_distance, S.inserted);
     DM_CHK(hipGetLastError());
@@ -446,9 +439,7 @@ hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, u
                        S.idx, (const uint8_t *) nullptr);
     hipLaunchKernelGGL(k_gs_first_flags, dim3(grid), dim3(256), 0, stream, S.gs_first, S.idx, n, S.inserted, (const uint8_t *) nullptr);
     DM_CHK(hipGetLastError());
-    size_t tmp = S.cub_temp_bytes;
-    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, hipcub::CountingInputIterator<uint32_t>(0u), S.inserted, S.sel_out, S.sel_count,
-                                         (int) n, stream));
+    DM_CHK(compact_flags(S.inserted, nullptr, n, S.idx_alt, S.sel_out, S.sel_count, stream));      // ascending indices of the kept points
     DM_CHK(hipMemcpyAsync(S.h_count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     DM_CHK(hipStreamSynchronize(stream));
     const int count = *S.h_count;
@@ -503,14 +494,12 @@ hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBa
     const unsigned grid = (unsigned) ((n + 255) / 256);
     hipLaunchKernelGGL(k_as_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, bands, S.keys, S.idx);
     DM_CHK(hipGetLastError());
-    size_t tmp = S.cub_temp_bytes;
     // stable sort on (band, z, y, x): indices stay ascending inside a voxel, so its first k positions are the k indices the
     // reference's loop pushes (sampling.h:80-85)
-    DM_CHK(hipcub::DeviceRadixSort::SortPairs(S.cub_temp, tmp, S.keys, S.keys_alt, S.idx, S.idx_alt, (int) n, 0, 64, stream));
+    DM_CHK(sort_pairs<uint64_t>(S.sort, S.keys, S.keys_alt, S.idx, S.idx_alt, n, 64, true, stream));
     hipLaunchKernelGGL(k_as_flags, dim3(grid), dim3(256), 0, stream, S.keys_alt, n, (uint32_t) bands.num_points_per_voxel, S.inserted);
     DM_CHK(hipGetLastError());
-    tmp = S.cub_temp_bytes;
-    DM_CHK(hipcub::DeviceSelect::Flagged(S.cub_temp, tmp, S.idx_alt, S.inserted, S.sel_out, S.sel_count, (int) n, stream));
+    DM_CHK(compact_flags(S.inserted, S.idx_alt, n, S.idx, S.sel_out, S.sel_count, stream));        // S.idx: free again after the sort
     DM_CHK(hipMemcpyAsync(S.h_count, S.sel_count, sizeof(int), hipMemcpyDeviceToHost, stream));
     DM_CHK(hipStreamSynchronize(stream));
     size_t count = (size_t) *S.h_count;
@@ -529,10 +518,7 @@ hipError_t order_scratch_reserve(OrderScratch &S, size_t n) {
         DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.keys_alt), cap * sizeof(uint32_t)));
         DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.idx), cap * sizeof(uint32_t)));
         DM_CHK(hipMalloc(reinterpret_cast<void **>(&S.order), cap * sizeof(uint32_t)));
-        size_t tmp = 0;
-        DM_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, S.keys, S.keys_alt, S.idx, S.order, (int) cap, 0, 32, (hipStream_t) 0));
-        DM_CHK(hipMalloc(&S.temp, tmp));
-        S.temp_bytes = tmp;
+        DM_CHK(sort_scratch_reserve(S.sort, cap));
         S.cap = cap;
     }
     return hipSuccess;
@@ -543,8 +529,7 @@ hipError_t order_by_home_voxel(OrderScratch &S, const double *wx, const double *
     DM_CHK(order_scratch_reserve(S, n));
     hipLaunchKernelGGL(k_order_keys, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, wx, wy, wz, n, resolution, S.keys, S.idx);
     DM_CHK(hipGetLastError());
-    size_t tmp = S.temp_bytes;
-    return hipcub::DeviceRadixSort::SortPairs(S.temp, tmp, S.keys, S.keys_alt, S.idx, S.order, (int) n, 0, 32, stream);
+    return sort_pairs<uint32_t>(S.sort, S.keys, S.keys_alt, S.idx, S.order, n, 32, true, stream);
 }
 
 void order_scratch_free(OrderScratch &S) {
@@ -552,8 +537,67 @@ void order_scratch_free(OrderScratch &S) {
     if (S.keys_alt) (void) hipFree(S.keys_alt);
     if (S.idx) (void) hipFree(S.idx);
     if (S.order) (void) hipFree(S.order);
-    if (S.temp) (void) hipFree(S.temp);
+    sort_scratch_free(S.sort);
     S = OrderScratch{};
+}
+
+hipError_t devmap_test_sort(const uint64_t *keys_host, size_t n, int key_bits, int key_bytes, uint32_t *order_host, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    SortScratch S;
+    void *k0 = nullptr, *k1 = nullptr;
+    uint32_t *v0 = nullptr, *v1 = nullptr;
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t r) {
+        if (k0) (void) hipFree(k0);
+        if (k1) (void) hipFree(k1);
+        if (v0) (void) hipFree(v0);
+        if (v1) (void) hipFree(v1);
+        sort_scratch_free(S);
+        return r;
+    };
+    if ((e = hipMalloc(&k0, n * 8)) != hipSuccess || (e = hipMalloc(&k1, n * 8)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&v0), n * 4)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void **>(&v1), n * 4)) != hipSuccess)
+        return done(e);
+    if (key_bytes == 4) {
+        std::vector<uint32_t> k32(n);
+        for (size_t i = 0; i < n; ++i) k32[i] = (uint32_t) keys_host[i];
+        if ((e = hipMemcpy(k0, k32.data(), n * 4, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+        e = sort_pairs<uint32_t>(S, static_cast<uint32_t *>(k0), static_cast<uint32_t *>(k1), v0, v1, n, key_bits, true, stream);
+    } else {
+        if ((e = hipMemcpy(k0, keys_host, n * 8, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+        e = sort_pairs<uint64_t>(S, static_cast<uint64_t *>(k0), static_cast<uint64_t *>(k1), v0, v1, n, key_bits, true, stream);
+    }
+    if (e != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+    e = hipMemcpy(order_host, v1, n * 4, hipMemcpyDeviceToHost);
+    return done(e);
+}
+
+hipError_t devmap_test_compact(const uint8_t *flags_host, size_t n, uint32_t *out_host, size_t *count, hipStream_t stream) {
+    *count = 0;
+    if (n == 0) return hipSuccess;
+    uint8_t *f = nullptr;
+    uint32_t *cnt = nullptr, *out = nullptr;
+    int *tot = nullptr;
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t r) {
+        if (f) (void) hipFree(f);
+        if (cnt) (void) hipFree(cnt);
+        if (out) (void) hipFree(out);
+        if (tot) (void) hipFree(tot);
+        return r;
+    };
+    if ((e = hipMalloc(reinterpret_cast<void **>(&f), n)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void **>(&cnt), ((n + 255) / 256) * 4)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&out), n * 4)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void **>(&tot), sizeof(int))) != hipSuccess)
+        return done(e);
+    if ((e = hipMemcpy(f, flags_host, n, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+    if ((e = compact_flags(f, nullptr, n, cnt, out, tot, stream)) != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+    int t = 0;
+    if ((e = hipMemcpy(&t, tot, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return done(e);
+    *count = (size_t) t;
+    e = hipMemcpy(out_host, out, (size_t) t * 4, hipMemcpyDeviceToHost);
+    return done(e);
 }
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {

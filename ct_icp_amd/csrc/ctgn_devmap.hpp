@@ -4,7 +4,7 @@
 // kernels do not care which side maintains the map. Opt-in per handle (ctgn_map_set_update_mode).
 //
 // Why the result is identical to the reference's sequential insertion: a point only interacts with the points of its own
-// voxel, so voxels are independent; the batch is stably sorted by voxel key (hipcub radix sort, values = original
+// voxel, so voxels are independent; the batch is stably sorted by voxel key (ctgn_sort.hpp: hand-written LSD radix sort, values = original
 // index) and ONE thread walks a voxel's run in original order applying the reference's rule against the points already
 // in the block. Only block ids differ from a host-maintained map, and those are not observable.
 #pragma once
@@ -15,6 +15,13 @@
 #include "ctgn_map.hpp"
 
 namespace ctgn {
+
+// scratch of the multi-block radix sort (kernels: ctgn_sort.hpp, included by ctgn_devmap.hip only)
+struct SortScratch {
+    uint32_t *hist = nullptr;                  // [256][columns] digit counts -> exclusive offsets
+    unsigned long long *bits = nullptr;        // [2]: OR of all keys, AND of all keys
+    size_t cap = 0;
+};
 
 struct DevCounters {
     unsigned long long num_voxels, num_tombs, num_points;
@@ -45,8 +52,7 @@ struct DevMapScratch {                   // per handle, shared by the levels
     uint8_t *inserted = nullptr;
     uint32_t *sel_out = nullptr;         // grid sampling: selected indices
     int *sel_count = nullptr;
-    void *cub_temp = nullptr;
-    size_t cub_temp_bytes = 0;
+    SortScratch sort;                    // histogram matrix + key-bit words of the multi-block radix sort (ctgn_sort.hpp)
     size_t cap = 0;
     size_t stride = 0;                   // distance between the x / y / z planes of the staged batch (<= cap; set by the stager)
     double *h_pts = nullptr;             // pinned
@@ -102,13 +108,16 @@ hipError_t devmap_adaptive_sampling(DevMapScratch &S, size_t n, const AdaptiveBa
 // results do not depend on it. `order` stays valid until the next call.
 struct OrderScratch {
     uint32_t *keys = nullptr, *keys_alt = nullptr, *idx = nullptr, *order = nullptr;
-    void *temp = nullptr;
-    size_t temp_bytes = 0, cap = 0;
+    SortScratch sort;
+    size_t cap = 0;
 };
 hipError_t order_scratch_reserve(OrderScratch &S, size_t n);       // allocations only (kept out of the solve)
 hipError_t order_by_home_voxel(OrderScratch &S, const double *wx, const double *wy, const double *wz, size_t n, double resolution,
                                hipStream_t stream);
 void order_scratch_free(OrderScratch &S);
+// test hooks (ctgn_test_sort_pairs / ctgn_test_compact): the primitives of ctgn_sort.hpp on host arrays
+hipError_t devmap_test_sort(const uint64_t *keys_host, size_t n, int key_bits, int key_bytes, uint32_t *order_host, hipStream_t stream);
+hipError_t devmap_test_compact(const uint8_t *flags_host, size_t n, uint32_t *out_host, size_t *count, hipStream_t stream);
 hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream);
 
 }  // namespace ctgn

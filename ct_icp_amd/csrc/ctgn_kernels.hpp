@@ -221,15 +221,68 @@ __device__ __forceinline__ double sys_entry(const double *rec, int e) {
 // ================================================================================================
 constexpr int LANE_BLOCK = 128;
 
-// Sequential neighbour search with a sorted insertion list kept in LDS (column `tid` of d2s/ids).
-// Candidates are visited in the reference's order (x-major voxel sweep, insertion order inside a voxel), so
-// "insert after equal keys, replace only if strictly smaller" realises the total order (d2, visit index).
+// ---- libstdc++'s std::priority_queue on (distance, payload) with the reference's comparator `a.distance < b.distance`
+// (include/ct_icp/map.h:595-601), restated: push = push_back + std::push_heap, pop = std::pop_heap (+ pop_back) of bits/stl_heap.h.
+// Which of two EQUAL distances a full queue keeps, and in which order it drains them, is decided by this layout and nothing else, so
+// reproducing the reference on exact ties means replaying exactly these moves (oracle: heap_mode 0, oracle/ctgn_oracle.c).
+// `ld(i)` / `st(i, item)` access slot i of the heap's storage (LDS here).
+struct HeapItem {
+    double d;          // the key: Euclidean distance (map.h:491)
+    double s;          // its square (what the kernels carry around)
+    uint32_t v;        // payload: visit index or point id
+};
+template <typename LD, typename ST>
+__device__ __forceinline__ void heap_push_hole(LD ld, ST st, int hole, int top, const HeapItem &value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && ld(parent).d < value.d) {
+        st(hole, ld(parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    st(hole, value);
+}
+template <typename LD, typename ST>
+__device__ __forceinline__ void heap_push(LD ld, ST st, int &size, const HeapItem &value) {
+    ++size;
+    heap_push_hole(ld, st, size - 1, 0, value);
+}
+// std::pop_heap: the top moves to slot size-1, the rest is re-heaped; `size` shrinks by one. Draining a heap this way leaves the
+// storage sorted ascending, equal keys in exactly the order the reference's drain loop (map.h:508-513) meets them, reversed.
+template <typename LD, typename ST>
+__device__ __forceinline__ void heap_pop(LD ld, ST st, int &size) {
+    if (size > 1) {
+        const HeapItem value = ld(size - 1);
+        st(size - 1, ld(0));
+        const int len = size - 1;
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (ld(child).d < ld(child - 1).d) child--;
+            st(hole, ld(child));
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            st(hole, ld(child - 1));
+            hole = child - 1;
+        }
+        heap_push_hole(ld, st, hole, 0, value);
+    }
+    --size;
+}
+
+// One lane, one query: the reference's RadiusSearchInPlace verbatim (map.h:449-514) — x-major voxel sweep, insertion order inside a
+// voxel, `distance > radius` skip, bounded std::priority_queue with strict-< replacement, drain. The queue lives in LDS (column `tid`
+// of d2s / ids; d2s holds DISTANCES, as the reference compares them). On return the n kept entries are sorted ascending in place
+// ([0] nearest ... [n-1] farthest), ties in the reference's drain order: its neighbour j (farthest first) is entry n-1-j.
 __device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, double *d2s, uint32_t *ids, int stride,
                                            Counters *cnt_out) {
     int kx = voxel_coord(p.x, m.resolution), ky = voxel_coord(p.y, m.resolution), kz = voxel_coord(p.z, m.resolution);
     if (!(sweep_in_short_range(kx, m.nb) && sweep_in_short_range(ky, m.nb) && sweep_in_short_range(kz, m.nb))) return 0;
     int n = 0;
     unsigned long long c_probe = 0, c_hit = 0, c_pts = 0;
+    auto ld = [&](int i) { return HeapItem{d2s[i * stride], 0.0, ids[i * stride]}; };
+    auto st = [&](int i, const HeapItem &it) { d2s[i * stride] = it.d; ids[i * stride] = it.v; };
     for (int vx = kx - m.nb; vx <= kx + m.nb; ++vx)
         for (int vy = ky - m.nb; vy <= ky + m.nb; ++vy)
             for (int vz = kz - m.nb; vz <= kz + m.nb; ++vz) {
@@ -243,26 +296,23 @@ __device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, doub
                 for (uint32_t i = 0; i < count; ++i) {
                     double dx = bx[i] - p.x, dy = bx[m.blk + i] - p.y, dz = bx[2 * m.blk + i] - p.z;
                     double d2 = sq_norm3(dx, dy, dz);
-                    if (d2 > m.r2thr) continue;                       // map.h:491-493
-                    int pos;
-                    if (n < k) pos = n++;                             // map.h:494-500
-                    else if (d2 < d2s[(k - 1) * stride]) pos = k - 1;
-                    else continue;
-                    while (pos > 0 && d2s[(pos - 1) * stride] > d2) {
-                        d2s[pos * stride] = d2s[(pos - 1) * stride];
-                        ids[pos * stride] = ids[(pos - 1) * stride];
-                        --pos;
+                    if (d2 > m.r2thr) continue;                       // map.h:491-493: sqrt(d2) > radius
+                    const HeapItem it{__dsqrt_rn(d2), d2, block * (uint32_t) m.blk + i};
+                    if (n == k) {                                     // map.h:494-500
+                        if (it.d < d2s[0]) { heap_pop(ld, st, n); heap_push(ld, st, n, it); }
+                    } else {
+                        heap_push(ld, st, n, it);
                     }
-                    d2s[pos * stride] = d2;
-                    ids[pos * stride] = block * (uint32_t) m.blk + i;
                 }
             }
+    const int kept = n;
+    for (int sz = kept; sz > 1;) heap_pop(ld, st, sz);                // map.h:508-513
     if (cnt_out) {
         atomicAdd(&cnt_out->probed, c_probe);
         atomicAdd(&cnt_out->hit, c_hit);
         atomicAdd(&cnt_out->points, c_pts);
     }
-    return n;
+    return kept;
 }
 
 __device__ __forceinline__ Vec3 map_point(const MapView &m, uint32_t id) {
@@ -301,12 +351,12 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
             int n = lane_search(map, p, k, d2s + tid, ids + tid, LANE_BLOCK, nullptr);
             Vec3 S{0, 0, 0}, q{0, 0, 0};
             Sym3 SS{0, 0, 0, 0, 0, 0};
-            for (int j = 0; j < n; ++j) {
-                Vec3 c = map_point(map, ids[j * LANE_BLOCK + tid]);
-                S = S + c;
+            for (int j = n - 1; j >= 0; --j) {                              // farthest first: the reference's neighbour order (map.h:508-513),
+                Vec3 c = map_point(map, ids[j * LANE_BLOCK + tid]);         // which is the order ComputeNeighborhood sums in (neighborhood.h:236-240)
+                S.x += c.x; S.y += c.y; S.z += c.z;
                 SS.xx += c.x * c.x; SS.xy += c.x * c.y; SS.xz += c.x * c.z;
                 SS.yy += c.y * c.y; SS.yz += c.y * c.z; SS.zz += c.z * c.z;
-                if (j == n - 1) q = c;                                      // farthest kept (map.h:508-513)
+                if (j == n - 1) q = c;                                      // points[0]: the farthest kept (ct_icp.cpp:791)
             }
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
@@ -500,8 +550,17 @@ struct WaveScratch {
 // (one bin per lane): only the bins up to the one in which the running count reaches k can hold winners.
 // All loops run to the wave-uniform maximum over the 4 rows; loads are unconditional (indices stay inside the
 // arrays) and masked afterwards, so the code is branch-light.
+// near_tie (out, row-uniform): some entry that is kept — or is the first one dropped — lies within a few ulps of another entry's
+// squared distance. The total order (d2, visit index) and the reference's std::priority_queue keyed by sqrt(d2) (map.h:491-500) can
+// then disagree on which entry is kept and on the order of the kept ones; the caller replays the reference's queue for that keypoint
+// (replay_reference_queue). Only the exact rank below can see such a pair: two float32 keys that differ are no near-tie.
+constexpr double NEAR_TIE_REL = 0x1p-49;       // sqrt maps at most three adjacent doubles to one: |a - b| <= 3 ulp; 2^-49 is 8-16 ulp
+// bound that admits everything the reference could treat as tying the current k-th best: candidates up to a few ulps ABOVE its
+// squared distance may have the same sqrt, and one the reference visited EARLIER than the current k-th would have been kept by it
+__device__ __forceinline__ double kth_bound(double kth_sq, double r2thr) { return fmin(r2thr, kth_sq * (1.0 + 0x1p-48)); }
+
 template <bool HIST>
-__device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, int row, double hi) {
+__device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, int row, double hi, bool &near_tie) {
     int maxLn = max_over_rows(Ln);
     if (maxLn == 0) return 0;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
@@ -528,7 +587,8 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
             const int e = sub + 16 * m;
             const double d = R.d2[e];
             const uint32_t vv = R.vis[e];
-            const bool keep = (e < Ln) && (!cut || min(15, (int) (d * scale)) <= bb);
+            // (entries a hair above the last kept bin stay too: a near-tie of the k-th best must not be cut away unseen)
+            const bool keep = (e < Ln) && (!cut || min(15, (int) (d * (1.0 - 0x1p-40) * scale)) <= bb);
             const uint32_t km = row_bits(__ballot(keep), row);
             if (keep) {
                 const int pos = base + __popc(km & lt_mask);
@@ -572,6 +632,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
     double od2[MAXOWN];
     uint32_t ovis[MAXOWN];
     int rank[MAXOWN];
+    uint32_t near = 0u;                 // bit m: owned entry m has another entry within NEAR_TIE_REL of its squared distance
 #pragma unroll
     for (int m = 0; m < MAXOWN; ++m) {
         const int e = sub + 16 * m;
@@ -592,8 +653,17 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         const uint32_t fvis = fv ? fvr : 0xffffffffu;
 #pragma unroll
         for (int m = 0; m < MAXOWN; ++m) {
-            if (m < mcount) rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
+            if (m < mcount) {
+                rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
+                near |= (fv && fvis != ovis[m] && od2[m] < INF && fabs(fd2 - od2[m]) <= od2[m] * NEAR_TIE_REL) ? (1u << m) : 0u;
+            }
         }
+    }
+    {
+        bool mine = false;
+#pragma unroll
+        for (int m = 0; m < MAXOWN; ++m) mine = mine || (((near >> m) & 1u) && sub + 16 * m < Ln && rank[m] <= k);
+        near_tie = near_tie || row_bits(__ballot(mine), row) != 0u;
     }
     // every row is written back sorted (rows with <= k entries keep them all)
 #pragma unroll
@@ -602,6 +672,47 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         if (e < Ln && rank[m] < k) { R.d2[rank[m]] = od2[m]; R.vis[rank[m]] = ovis[m]; }
     }
     return Ln < k ? Ln : k;
+}
+
+// The reference's RadiusSearchInPlace replayed literally for ONE keypoint by ONE lane (map.h:449-514: x-major sweep of all (2 NB + 1)^3
+// voxels, insertion order inside a voxel, `distance > radius` skip, bounded std::priority_queue keyed by the distance, drain) — the
+// fallback of the row kernel for a keypoint whose candidates tie (row_select: near_tie). The queue lives in the row's own list storage;
+// on return the list holds the kept entries sorted nearest first with SQUARED distances, ties in the reference's drain order, and
+// occ[v] the block of every sweep voxel (the hand-over turns visit indices into offsets with it). Slow (27 / 125 dependent probes by
+// one lane) and rare: real scans never tie; a lattice map does at every query.
+template <int NB>
+__device__ __forceinline__ int replay_reference_queue(const MapView &m, double qx, double qy, double qz, int kx, int ky, int kz, int k, RowList &R,
+                                                      uint32_t *occ) {
+    constexpr int S = 2 * NB + 1, V = S * S * S;
+    static_assert(LCAP >= 2 * KMAX, "queue keys and their squares share the row's list");
+    double *hd = R.d2, *hs = R.d2 + KMAX;
+    uint32_t *hv = R.vis;
+    auto ld = [&](int i) { return HeapItem{hd[i], hs[i], hv[i]}; };
+    auto st = [&](int i, const HeapItem &it) { hd[i] = it.d; hs[i] = it.s; hv[i] = it.v; };
+    int n = 0;
+    for (int v = 0; v < V; ++v) {                                      // v IS the reference's sweep order (x outermost, z innermost)
+        const int ox = v / (S * S) - NB, oy = (v / S) % S - NB, oz = v % S - NB;
+        const uint32_t bc = map_lookup(m, kx + ox, ky + oy, kz + oz);
+        occ[v] = bc;
+        if (!bc) continue;
+        const uint32_t count = bc & 127u;
+        const double *bx = m.blocks + (size_t) (bc >> 7) * 3 * m.blk;
+        for (uint32_t i = 0; i < count; ++i) {
+            const double dx = bx[i] - qx, dy = bx[m.blk + i] - qy, dz = bx[2 * m.blk + i] - qz;
+            const double d2 = sq_norm3(dx, dy, dz);
+            if (d2 > m.r2thr) continue;                                // map.h:491-493
+            const HeapItem it{__dsqrt_rn(d2), d2, ((uint32_t) v << 6) | i};
+            if (n == k) {                                              // map.h:494-500
+                if (it.d < hd[0]) { heap_pop(ld, st, n); heap_push(ld, st, n, it); }
+            } else {
+                heap_push(ld, st, n, it);
+            }
+        }
+    }
+    const int kept = n;
+    for (int sz = kept; sz > 1;) heap_pop(ld, st, sz);                 // map.h:508-513: [kept-1] is drained first ... [0] last
+    for (int e = 0; e < kept; ++e) hd[e] = hs[e];
+    return kept;
 }
 
 // true iff the four rows of the wave hold the same, valid voxel (kx, ky, kz are row-uniform values)
@@ -763,7 +874,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
-            const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
+            uint32_t *occ_tab = RP.occ;           // where B4 finds a candidate's voxel block
+            bool tie_seen = false;                // some selection of this round met candidates whose distances (nearly) tie
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
             if (uniform_home) {
@@ -859,8 +971,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                             max(L[2] + (int) __popcll(pm[2]), L[3] + (int) __popcll(pm[3]))) > LCAP) {
                         CTGN_TICK(2)
                         Ln = row == 0 ? L[0] : row == 1 ? L[1] : row == 2 ? L[2] : L[3];
-                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
-                        if (Ln >= k) kth_d2 = R.d2[k - 1];
+                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
+                        if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             L[j] = __builtin_amdgcn_readlane(Ln, 16 * j);
@@ -985,8 +1097,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                     if (__any(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
-                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
-                        if (Ln >= k) kth_d2 = R.d2[k - 1];
+                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
+                        if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
                         CTGN_TICK(3)
                     }
                 }
@@ -996,8 +1108,8 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
                 if (NB == 2 && it + 1 < VIT && __any(Ln >= k && !(kth_d2 < map.r2thr))) {
-                    Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
-                    if (Ln >= k) kth_d2 = R.d2[k - 1];
+                    Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
+                    if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
                     CTGN_TICK(3)
                 }
             }
@@ -1022,7 +1134,16 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // candidates was never pruned (Ln < k throughout), so Ln already is its exact neighbour count, and the residual kernel
             // drops it on that count alone: when no row of the wave can be used, skip the selection and hand over counts only.
             const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr;
-            if (!(ablate & 2) && __any(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2);
+            if (!(ablate & 2) && __any(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
+            // a keypoint whose candidates (nearly) tie in distance: only the reference's own queue says which of them it keeps and in
+            // which order (map.h:491-513) — replay it for that keypoint, one lane, all sweep voxels, radius only
+            if (__any(tie_seen && searching && row_needed) && !ablate) {
+                int n_replayed = Ln;
+                if (tie_seen && searching && row_needed && sub == 0)
+                    n_replayed = replay_reference_queue<NB>(map, qx, qy, qz, kx, ky, kz, k, R, occ_tab);
+                asm volatile("" ::: "memory");
+                if (tie_seen && searching && row_needed) Ln = __shfl(n_replayed, row * 16);
+            }
             const int n = (ablate & 2) ? min(Ln, k) : Ln;
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST

@@ -29,11 +29,24 @@ def deal_sequences(lengths, world_size: int):
     return order, [order[r::world_size] for r in range(world_size)]
 
 
-def constant_velocity_guess(prev_pose14: np.ndarray) -> np.ndarray:
-    """begin = previous end, end = previous end advanced by the previous frame's motion (odometry.cpp:276-330)."""
+def _se3_advance(a7: np.ndarray, b7: np.ndarray) -> np.ndarray:
+    """The SE(3) product a * b^-1 * a of two poses (quat xyzw | translation): `a` advanced once more by the motion b -> a."""
+    rel_q = se3.quat_mul(a7[0:4], se3.quat_conj(b7[0:4]))                       # R_a R_b^T
+    q = se3.quat_normalize(se3.quat_mul(rel_q, a7[0:4]))
+    t = a7[4:7] + se3.quat_rotate(se3.quat_normalize(rel_q), a7[4:7] - b7[4:7])    # R_a R_b^T (t_a - t_b) + t_a
+    return np.concatenate([q, t])
+
+
+def constant_velocity_guess(prev_pose14: np.ndarray, prev_prev_pose14: np.ndarray | None = None) -> np.ndarray:
+    """Odometry::InitializeMotion with INIT_CONSTANT_VELOCITY and CONTINUOUS motion compensation (odometry.cpp:293-325):
+    end = T_end(k-1) T_end(k-2)^-1 T_end(k-1) (a full SE(3) product: the previous translation increment is ROTATED by the relative
+    rotation); begin = T_end(k-1) for the second registered frame (:294-300), T_begin(k-1) T_begin(k-2)^-1 T_begin(k-1) afterwards
+    (:311-316). Without the frame before the previous one, the previous frame's own begin pose stands in for T_end(k-2)."""
     pb, pe = prev_pose14[0:7], prev_pose14[7:14]
-    rel_q = se3.quat_mul(pe[0:4], se3.quat_conj(pb[0:4]))
-    return np.concatenate([pe, se3.quat_normalize(se3.quat_mul(rel_q, pe[0:4])), pe[4:7] + (pe[4:7] - pb[4:7])])
+    if prev_prev_pose14 is None:
+        return np.concatenate([pe, _se3_advance(pe, pb)])
+    ppb, ppe = prev_prev_pose14[0:7], prev_prev_pose14[7:14]
+    return np.concatenate([_se3_advance(pb, ppb), _se3_advance(pe, ppe)])
 
 
 def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sample_voxel_size: float = 1.5,
@@ -57,23 +70,28 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
     no_registration = CTICPOptions(solver=GN, num_iters_icp=0, debug_print=False)
     mm = PreviousFrameMotionModel()
     poses, success, n_kp, n_sampled = [], [], [], []
-    prev = None
+    prev, prev2 = None, None
     t_start = time.perf_counter()
     for j, (raw, t, tbe) in enumerate(scans):
         order = None if orders is None else orders[j]
+        # the first two registered frames carry the frame's end timestamp on every point: "no elastic ICP for first frame because no
+        # initialization of ego-motion" (odometry.cpp:354-359)
+        override = float(tbe[1]) if j <= 1 else None
         if j < init_frames:
             pose0 = np.asarray(init_poses[j], dtype=np.float64) if init_poses is not None else se3.identity_pose14()
-            r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, want_all=False)
+            r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, override_timestamp=override, want_all=False)
         else:
-            guess = constant_velocity_guess(prev)
+            # odometry.cpp:293-300: the frame right after the bootstrap starts at the previous end pose; later ones extrapolate both ends
+            guess = constant_velocity_guess(prev, prev2 if j >= init_frames + 1 and j >= 3 else None)
             mm.previous_frame = TrajectoryFrame.from_pose14(prev, tbe[0] - frame_period, tbe[0])
             r = fp.frame(raw, t, guess, tbe, options, max_distance, motion_model=mm if use_motion_model else None, order=order,
-                         want_all=False)
+                         override_timestamp=override, want_all=False)
         poses.append(r["pose"])
         success.append(bool(r["summary"].success))
         n_kp.append(len(r["keypoint_indices"]))
         n_sampled.append(len(r["sampled_indices"]))
-        prev = r["pose"] if r["summary"].success or prev is None else constant_velocity_guess(prev)
+        new = r["pose"] if r["summary"].success or prev is None else constant_velocity_guess(prev, prev2)
+        prev2, prev = prev, new
     seconds = time.perf_counter() - t_start
     return dict(poses=np.array(poses), success=np.array(success), seconds=seconds, frames=len(poses), keypoints=np.array(n_kp),
                 sampled=np.array(n_sampled), map_points=int(gm.NumPoints()))
@@ -84,18 +102,29 @@ def run_batch(sequences: dict, lengths, rank: int = 0, world_size: int = 1, grou
     per-sequence results are gathered on every rank afterwards (torch.distributed, any backend) and the aggregate frames/s is
     frames / the slowest rank's wall time. `sequences` needs only this rank's ids."""
     order, shares = deal_sequences(lengths, world_size)
+    if "device" not in kw:                  # one GPU per rank (config E); ranks beyond the visible devices share them
+        try:
+            import torch
+            kw["device"] = rank % max(1, torch.cuda.device_count())
+        except ImportError:
+            kw["device"] = 0
     results = []
+    t_job = time.perf_counter()
     for sid in shares[rank]:
         r = run_sequence(sequences[sid], **kw)
+        r["device"] = kw["device"]
         r["sequence"] = sid
         results.append(r)
+    job_seconds = time.perf_counter() - t_job              # this rank's wall time over its whole share (maps built, frames run)
+    for r in results:
+        r["rank_job_seconds"] = job_seconds
     if world_size > 1:
         import torch.distributed as dist
         gathered = [None] * world_size
         dist.all_gather_object(gathered, results, group=group)
     else:
         gathered = [results]
-    per_rank_seconds = [sum(r["seconds"] for r in g) for g in gathered]
+    per_rank_seconds = [max(r["rank_job_seconds"] for r in g) if g else 0.0 for g in gathered]
     frames = sum(r["frames"] for g in gathered for r in g)
     wall = max(per_rank_seconds) if per_rank_seconds else 0.0
     return dict(frames=frames, wall_seconds=wall, frames_per_sec=frames / wall if wall > 0 else 0.0, shares=shares,

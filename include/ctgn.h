@@ -512,6 +512,13 @@ ctgn_status ctgn_traffic_counters(ctgn_handle h, uint64_t out[2], int32_t reset)
  * rounds); slots of waves that did not run keep their previous content (zero initially). */
 ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves);
 
+/* Test hooks for the library's own sort / compaction kernels (ctgn_sort.hpp; they replace a vendor sort library on the frame path: the
+ * map-update batch, the adaptive sampler, the home-voxel ordering): order_out[j] = index of the j-th smallest key under a STABLE sort on
+ * the low key_bits bits (key_bytes 4: the keys are narrowed to 32 bits first); out_indices = ascending indices whose flag is non-zero.
+ * Host arrays in and out. */
+ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, int32_t key_bits, int32_t key_bytes, uint32_t *order_out);
+ctgn_status ctgn_test_compact(ctgn_handle h, const uint8_t *flags, size_t n, uint32_t *out_indices, size_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,7 +100,11 @@ def _batch_worker(rank, world, port, tmpdir):
     lengths = [40, 10, 41, 8, 3, 25, 10]
     ran = []
 
-    def fake_run_sequence(scans, **kw):                       # stands in for the GPU loop: one "second" per frame
+    def fake_run_sequence(scans, **kw):                       # stands in for the GPU loop: one millisecond per frame
+        import time
+        import torch
+        assert kw["device"] == rank % max(1, torch.cuda.device_count())       # run_batch maps the rank to its own device
+        time.sleep(1e-3 * len(scans))
         ran.append(len(scans))
         return dict(poses=np.zeros((len(scans), 14)), success=np.ones(len(scans), bool), seconds=float(len(scans)), frames=len(scans),
                     keypoints=np.zeros(len(scans)), sampled=np.zeros(len(scans)), map_points=0)
@@ -128,4 +132,5 @@ def test_config_e_sequences_are_dealt_longest_first_and_aggregated(tmp_path):
     r0, r1 = np.load(tmp_path / "batch_0.npy"), np.load(tmp_path / "batch_1.npy")
     assert r0[0] == r1[0] == sum(lengths) and r0[3] == r1[3] == 7
     assert r0[2] == 41 + 25 + 10 + 3 and r1[2] == 40 + 10 + 8
-    assert r0[1] == r1[1] == max(41 + 25 + 10 + 3, 40 + 10 + 8)
+    # the job's wall time is the slowest rank's measured wall time over its whole share (1 ms per frame in the stand-in)
+    assert r0[1] == r1[1] and 1e-3 * max(41 + 25 + 10 + 3, 40 + 10 + 8) <= r0[1] < 5.0

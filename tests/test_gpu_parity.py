@@ -783,6 +783,10 @@ def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
         fp.register(sc.raw, sc.t + 10.0, sc.pose_gt, sc.t_begin_end, o)
     with pytest.raises(cia.CtgnError):
         fp.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o, order=np.full(len(sc.t), len(sc.t), dtype=np.uint32))
+    dup = np.arange(len(sc.t), dtype=np.uint32)
+    dup[5] = dup[4]                                           # in range, but not a permutation: index 4 twice, index 5 never
+    with pytest.raises(cia.CtgnError):
+        fp.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o, order=dup)
     with pytest.raises(cia.CtgnError):
         cia.FramePipeline(mk()).update_map(np.zeros(3), 10.0, True)
     # the first frames of a sequence: every point takes the end timestamp (odometry.cpp:357-361)
@@ -1112,13 +1116,15 @@ def test_dense_search_kernel_small_and_sparse_inputs(box_case, nclt_case):
         assert tr < 1e-7 and rot < 1e-7
 
 
-@pytest.mark.parametrize("mode", ["rows", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "rows_plain_rank", "lane", "dense"])
 def test_exact_distance_ties_on_a_lattice_map(mode):
-    """map.h:491-500 keeps candidates in a std::priority_queue keyed by distance only: which of two EQUAL distances survives is
-    decided by libstdc++'s heap. The GPU uses the total order (d2, visit index). On a lattice (dozens of candidates at exactly
-    equal distances) the kept SET can differ between the two where a tie straddles the k-th place, but the count, the farthest
-    kept DISTANCE and every strictly-closer neighbour cannot; the total-order restatement of the oracle (heap_mode 1) must match
-    bit for bit. The dense kernel meets its crowded-pivot-bin fallback here."""
+    """map.h:491-500 keeps candidates in a std::priority_queue keyed by the distance only: which of two EQUAL distances survives, and in
+    which order equal ones are drained, is decided by libstdc++'s heap layout. Round 3: the product reproduces that. The lane kernel and
+    the batched RadiusSearch ARE the reference's queue (heap restated move for move); the row kernel detects (near-)tied candidates in its
+    exact rank and replays the reference's queue for that keypoint. On a lattice — dozens of candidates at exactly equal distances around
+    every query — neighbour lists, farthest neighbours, gate decisions and normals must equal the oracle's heap_mode 0 (= the reference:
+    tests/test_oracle_vs_ref.py pins that bit for bit) and, where oracle/_ref is built, the reference's own RadiusSearch. The experimental
+    dense kernel keeps the total order (d2, visit index) and is held to heap_mode 1."""
     g = np.arange(-8, 9) * 0.25
     lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
     lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
@@ -1129,16 +1135,24 @@ def test_exact_distance_ties_on_a_lattice_map(mode):
     rng = np.random.default_rng(6)
     core = lattice[np.abs(lattice).max(axis=1) <= 1.0]
     qs = np.concatenate([core[:150], core[:150] + 0.125, core[150:300] + [0.125, 0.0, 0.0], core[:100] + rng.normal(0, 1e-3, (100, 3))])
-    # batched RadiusSearch (lane kernel, total order)
-    for k in (20, 8):
-        got = gm.ComputeNeighborhoods(qs, k)
-        for q, gq in zip(qs, got):
-            want = om.radius_search(q, 0.0, k, heap_mode=1)
-            assert np.array_equal(gq, want)
-            ref_heap = om.radius_search(q, 0.0, k, heap_mode=0)
-            assert len(ref_heap) == len(want)
-            d_w, d_h = np.linalg.norm(want - q, axis=1), np.linalg.norm(ref_heap - q, axis=1)
-            assert np.array_equal(np.sort(d_w), np.sort(d_h))          # same multiset of distances either way
+    if mode == "rows":
+        # batched RadiusSearch (ISlamMap::RadiusSearch / ComputeNeighborhoods): the reference's queue
+        from oracle import ref as oref
+        rmap = None
+        if oref.available():
+            rmap = oref.Map(resolutions=res, default_radius=0.8)
+            rmap.insert(lattice)
+        differs_from_total_order = 0
+        for k in (20, 8):
+            got = gm.ComputeNeighborhoods(qs, k)
+            rc, rx = rmap.radius_search(qs, 0.0, k) if rmap is not None else (None, None)
+            for j, (q, gq) in enumerate(zip(qs, got)):
+                want = om.radius_search(q, 0.0, k, heap_mode=0)
+                assert np.array_equal(gq, want)
+                if rmap is not None:
+                    assert rc[j] == len(gq) and np.array_equal(rx[j, :rc[j]], gq)
+                differs_from_total_order += not np.array_equal(want, om.radius_search(q, 0.0, k, heap_mode=1))
+        assert differs_from_total_order > 100               # the lattice does separate the two orders
     # the GN kernels on the same queries as keypoints (identity pose, raw = world)
     n = len(qs)
     pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], float)
@@ -1147,16 +1161,27 @@ def test_exact_distance_ties_on_a_lattice_map(mode):
     s = cia.GnSolver(gm)
     s.set_ordering(1 if mode == "dense" else 0)
     s.set_search_kernel(1 if mode == "dense" else 0)
+    s.set_variant({"rows": 0, "rows_plain_rank": 2, "lane": 1, "dense": 0}[mode])
     s.set_debug(True)
     s.set_keypoints(qs, qs, tt)
     s.solve(pose, (0.0, 1.0), o)
     dbg = s.get_debug()
-    Ao, bo, no, info = orc.gn_accumulate(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o), heap_mode=1, debug=True)
+    heap_mode = 1 if mode == "dense" else 0
+    Ao, bo, no, info = orc.gn_accumulate(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o), heap_mode=heap_mode, debug=True)
     assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"]) and (info["n_neighbors"] == 20).all()
     assert np.array_equal(dbg["farthest"], info["farthest"])
     assert np.array_equal(dbg["used"], info["used"])
+    if mode in ("rows", "rows_plain_rank"):
+        assert np.array_equal(dbg["normal"], info["normal"]) and np.array_equal(dbg["a2d"], info["a2d"])     # same neighbours in the same order
     A, b, n_used = s.get_system()
     assert n_used == no and np.abs(A - Ao).max() <= 1e-10 * max(np.abs(Ao).max(), 1e-300)
+    if mode == "rows":
+        # a second iteration searches with a carried-over bound: the replay still sees the whole radius
+        o2 = _opts(num_iters_icp=3, threshold_orientation_norm=0.0)
+        s.set_keypoints(qs, qs, tt)
+        pose_g, summ, _ = s.solve(pose, (0.0, 1.0), o2)
+        pose_o, _, so = orc.register_gn(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o2), None, heap_mode=0)
+        assert summ.num_residuals_used == so.num_residuals_used and np.abs(pose_g - pose_o).max() < 1e-9
 
 
 @pytest.mark.parametrize("mode", ["rows", "dense"])
@@ -1482,3 +1507,36 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     assert d["config"]["keypoints_total"] > 100_000 and abs(d["config"]["keypoints_per_gpu"] * 2 - d["config"]["keypoints_total"]) <= 1
     assert d["parity_m_rad"][0] < 1e-4 and d["parity_m_rad"][1] < 1e-4 and d["parity"]["n_used_gpu"] == d["parity"]["n_used_oracle"]
     assert d["strong_scaling_single_gpu_reference"]["keypoints"] == d["config"]["keypoints_total"] and "weak_scaling_line" in d
+
+
+@pytest.mark.parametrize("key_bytes", [8, 4])
+def test_hand_written_radix_sort_and_compaction(box_case, key_bytes):
+    """ctgn_sort.hpp (no sort library underneath since round 3): stable LSD radix sort of (key, index) pairs — one launch up to 16 k keys,
+    three kernels per executed pass beyond — against NumPy's stable argsort, on sizes around every boundary (round of 64, the one-block
+    limit, a column tile), keys whose bytes partly never vary (skipped passes) or never vary at all; ordered compaction against
+    np.flatnonzero."""
+    import ctypes as C
+    om, gm = build_maps(box_case, 1, with_gpu=True)
+    h = gm.handle
+    rng = np.random.default_rng(5)
+    bits = 64 if key_bytes == 8 else 32
+    for n in (1, 2, 63, 64, 65, 1000, 7731, 16384, 16385, 70_000, 1_300_000):
+        for kind in ("random", "few", "constant", "voxel"):
+            if kind == "random":
+                keys = rng.integers(0, 2 ** bits, n, dtype=np.uint64)
+            elif kind == "few":                                     # many duplicates: stability is what is tested
+                keys = rng.integers(0, 37, n, dtype=np.uint64) << np.uint64(8 if key_bytes == 4 else 40)
+            elif kind == "constant":
+                keys = np.full(n, 0x0123456789ABCDEF & (2 ** bits - 1), dtype=np.uint64)
+            else:                                                   # packed voxel keys of a frame: three 21-bit biased coordinates
+                v = rng.integers(-120, 121, (n, 3)).astype(np.int64) + (1 << 20)
+                keys = (v[:, 0] | (v[:, 1] << 21) | (v[:, 2] << 42)).astype(np.uint64) & np.uint64(2 ** bits - 1)
+            order = np.zeros(n, dtype=np.uint32)
+            L.check(h, L.lib().ctgn_test_sort_pairs(h, keys.ctypes.data_as(C.POINTER(C.c_uint64)), n, bits, key_bytes,
+                                                   order.ctypes.data_as(C.POINTER(C.c_uint32))))
+            assert np.array_equal(order, np.argsort(keys, kind="stable").astype(np.uint32)), (n, kind)
+        flags = (rng.random(n) < 0.3).astype(np.uint8)
+        out = np.zeros(n, dtype=np.uint32)
+        cnt = C.c_size_t()
+        L.check(h, L.lib().ctgn_test_compact(h, flags.ctypes.data_as(C.POINTER(C.c_uint8)), n, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
+        assert np.array_equal(out[:cnt.value], np.flatnonzero(flags).astype(np.uint32)), n
