@@ -632,7 +632,6 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
     double od2[MAXOWN];
     uint32_t ovis[MAXOWN];
     int rank[MAXOWN];
-    uint32_t near = 0u;                 // bit m: owned entry m has another entry within NEAR_TIE_REL of its squared distance
 #pragma unroll
     for (int m = 0; m < MAXOWN; ++m) {
         const int e = sub + 16 * m;
@@ -653,66 +652,86 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         const uint32_t fvis = fv ? fvr : 0xffffffffu;
 #pragma unroll
         for (int m = 0; m < MAXOWN; ++m) {
-            if (m < mcount) {
-                rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
-                near |= (fv && fvis != ovis[m] && od2[m] < INF && fabs(fd2 - od2[m]) <= od2[m] * NEAR_TIE_REL) ? (1u << m) : 0u;
-            }
+            if (m < mcount) rank[m] += (fd2 < od2[m] || (fd2 == od2[m] && fvis < ovis[m])) ? 1 : 0;
         }
     }
-    {
-        bool mine = false;
-#pragma unroll
-        for (int m = 0; m < MAXOWN; ++m) mine = mine || (((near >> m) & 1u) && sub + 16 * m < Ln && rank[m] <= k);
-        near_tie = near_tie || row_bits(__ballot(mine), row) != 0u;
-    }
-    // every row is written back sorted (rows with <= k entries keep them all)
+    // every row is written back sorted (rows with <= k entries keep them all); the first entry that is DROPPED (rank k) goes right
+    // behind the kept ones (slot k: outside the list the caller sees) so that the tie check below can look at it
 #pragma unroll
     for (int m = 0; m < MAXOWN; ++m) {
         const int e = sub + 16 * m;
-        if (e < Ln && rank[m] < k) { R.d2[rank[m]] = od2[m]; R.vis[rank[m]] = ovis[m]; }
+        if (e < Ln && rank[m] <= k) { R.d2[rank[m]] = od2[m]; R.vis[rank[m]] = ovis[m]; }
+    }
+    {
+        // (near-)ties: adjacent entries of the sorted run [0 .. min(Ln, k + 1)) within NEAR_TIE_REL of each other — a pair of kept
+        // entries, or the k-th kept and the first dropped one. Two pairs per lane cover k <= 32.
+        const int lim = min(Ln, k + 1);
+        const double a0 = R.d2[sub], b0 = R.d2[sub + 1], a1 = R.d2[sub + 16], b1 = R.d2[sub + 17];
+        const bool mine = (sub + 1 < lim && b0 - a0 <= b0 * NEAR_TIE_REL) || (sub + 17 < lim && b1 - a1 <= b1 * NEAR_TIE_REL);
+        near_tie = near_tie || row_bits(__ballot(mine), row) != 0u;
     }
     return Ln < k ? Ln : k;
 }
 
-// The reference's RadiusSearchInPlace replayed literally for ONE keypoint by ONE lane (map.h:449-514: x-major sweep of all (2 NB + 1)^3
-// voxels, insertion order inside a voxel, `distance > radius` skip, bounded std::priority_queue keyed by the distance, drain) — the
-// fallback of the row kernel for a keypoint whose candidates tie (row_select: near_tie). The queue lives in the row's own list storage;
-// on return the list holds the kept entries sorted nearest first with SQUARED distances, ties in the reference's drain order, and
-// occ[v] the block of every sweep voxel (the hand-over turns visit indices into offsets with it). Slow (27 / 125 dependent probes by
-// one lane) and rare: real scans never tie; a lattice map does at every query.
-template <int NB>
-__device__ __forceinline__ int replay_reference_queue(const MapView &m, double qx, double qy, double qz, int kx, int ky, int kz, int k, RowList &R,
-                                                      uint32_t *occ) {
-    constexpr int S = 2 * NB + 1, V = S * S * S;
-    static_assert(LCAP >= 2 * KMAX, "queue keys and their squares share the row's list");
-    double *hd = R.d2, *hs = R.d2 + KMAX;
-    uint32_t *hv = R.vis;
-    auto ld = [&](int i) { return HeapItem{hd[i], hs[i], hv[i]}; };
-    auto st = [&](int i, const HeapItem &it) { hd[i] = it.d; hs[i] = it.s; hv[i] = it.v; };
+// ---- keypoints whose candidates (nearly) tie: the reference's queue decides, so it is replayed — by the kernels that CONSUME the
+// neighbour records (k_residual_reduce, k_robust_prepare), not by the search kernel, whose registers and instruction stream stay as
+// they are (an inlined replay cost the search kernel 4 % on the B2 sweep). The search kernel only sets TIE_FLAG in the record's count.
+constexpr uint32_t TIE_FLAG = 0x80000000u;
+struct TieScratch {            // one per wave: the queue of the lane being replayed (keys, their squares, payload = point byte offset)
+    double d[KMAX], s[KMAX];
+    uint32_t v[KMAX];
+};
+// The reference's RadiusSearchInPlace replayed literally for ONE keypoint by ONE lane (map.h:449-514: x-major sweep of all
+// (2 nb + 1)^3 voxels, insertion order inside a voxel, `distance > radius` skip, bounded std::priority_queue keyed by the distance,
+// drain). On return T.v[0 .. n) are the byte offsets of the kept points nearest first, ties in the reference's drain order (its
+// neighbour j, farthest first, is entry n-1-j). Slow (27 / 125 dependent probes by one lane) and rare: real scans never tie; a lattice
+// map does at every query.
+__device__ __forceinline__ int replay_reference_queue(const MapView &m, Vec3 q, int k, TieScratch &T) {
+    const int kx = voxel_coord(q.x, m.resolution), ky = voxel_coord(q.y, m.resolution), kz = voxel_coord(q.z, m.resolution);
+    if (!(sweep_in_short_range(kx, m.nb) && sweep_in_short_range(ky, m.nb) && sweep_in_short_range(kz, m.nb))) return 0;
+    auto ld = [&](int i) { return HeapItem{T.d[i], T.s[i], T.v[i]}; };
+    auto st = [&](int i, const HeapItem &it) { T.d[i] = it.d; T.s[i] = it.s; T.v[i] = it.v; };
+    const uint32_t blk8 = (uint32_t) m.blk * 8u, stride3 = 3u * blk8;
     int n = 0;
-    for (int v = 0; v < V; ++v) {                                      // v IS the reference's sweep order (x outermost, z innermost)
-        const int ox = v / (S * S) - NB, oy = (v / S) % S - NB, oz = v % S - NB;
-        const uint32_t bc = map_lookup(m, kx + ox, ky + oy, kz + oz);
-        occ[v] = bc;
-        if (!bc) continue;
-        const uint32_t count = bc & 127u;
-        const double *bx = m.blocks + (size_t) (bc >> 7) * 3 * m.blk;
-        for (uint32_t i = 0; i < count; ++i) {
-            const double dx = bx[i] - qx, dy = bx[m.blk + i] - qy, dz = bx[2 * m.blk + i] - qz;
-            const double d2 = sq_norm3(dx, dy, dz);
-            if (d2 > m.r2thr) continue;                                // map.h:491-493
-            const HeapItem it{__dsqrt_rn(d2), d2, ((uint32_t) v << 6) | i};
-            if (n == k) {                                              // map.h:494-500
-                if (it.d < hd[0]) { heap_pop(ld, st, n); heap_push(ld, st, n, it); }
-            } else {
-                heap_push(ld, st, n, it);
+    for (int vx = kx - m.nb; vx <= kx + m.nb; ++vx)
+        for (int vy = ky - m.nb; vy <= ky + m.nb; ++vy)
+            for (int vz = kz - m.nb; vz <= kz + m.nb; ++vz) {
+                const uint32_t bc = map_lookup(m, vx, vy, vz);
+                if (!bc) continue;
+                const uint32_t count = bc & 127u, base = (bc >> 7) * stride3;
+                const double *bx = m.blocks + (size_t) (bc >> 7) * 3 * m.blk;
+                for (uint32_t i = 0; i < count; ++i) {
+                    const double dx = bx[i] - q.x, dy = bx[m.blk + i] - q.y, dz = bx[2 * m.blk + i] - q.z;
+                    const double d2 = sq_norm3(dx, dy, dz);
+                    if (d2 > m.r2thr) continue;                        // map.h:491-493
+                    const HeapItem it{__dsqrt_rn(d2), d2, base + i * 8u};
+                    if (n == k) {                                      // map.h:494-500
+                        if (it.d < T.d[0]) { heap_pop(ld, st, n); heap_push(ld, st, n, it); }
+                    } else {
+                        heap_push(ld, st, n, it);
+                    }
+                }
             }
-        }
-    }
     const int kept = n;
     for (int sz = kept; sz > 1;) heap_pop(ld, st, sz);                 // map.h:508-513: [kept-1] is drained first ... [0] last
-    for (int e = 0; e < kept; ++e) hd[e] = hs[e];
     return kept;
+}
+// All (active) lanes of a wave call this right after loading their keypoint's record into rec32 (count | TIE_FLAG, then the byte
+// offsets farthest first). Flagged lanes are replayed one after the other through the wave's TieScratch and their record replaced.
+__device__ __forceinline__ void resolve_ties(const MapView &map, const KpView &kp, int my_kp, bool wanted, uint32_t (&rec32)[SEL_STRIDE],
+                                             TieScratch &T, int lane, int k) {
+    unsigned long long todo = __ballot(wanted && (rec32[0] & TIE_FLAG) != 0u);
+    while (todo) {
+        const int L = __ffsll((long long) todo) - 1;
+        todo &= todo - 1ull;
+        if (lane == L) {
+            const int n = replay_reference_queue(map, Vec3{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]}, k, T);
+            rec32[0] = (uint32_t) n;
+#pragma unroll
+            for (int q = 0; q < KMAX; ++q) rec32[1 + q] = q < n ? T.v[n - 1 - q] : 0u;
+        }
+    }
+    rec32[0] &= ~TIE_FLAG;
 }
 
 // true iff the four rows of the wave hold the same, valid voxel (kx, ky, kz are row-uniform values)
@@ -732,14 +751,14 @@ __device__ __forceinline__ bool rows_share_home(int kx, int ky, int kz) {
 //   4 final selection | 5 covariance sums | 6 phase C (normal, residual, u) | 7 phase D (u u^T accumulation)
 // SHARED: compile the shared-home-voxel path (NB = 1). Off in the default instantiation since round 2: with the carried-over bound
 // and the slab-gated probes the generic path runs a B2 launch in 0.098 ms against 0.108 ms with the shared path (B2-small 0.071 / 0.075).
-template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false>
-__global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                               double *partials, DebugView dbg, int first_iter, int rounds,
-                                                               unsigned long long *prof = nullptr, int ablate = 0) {
+// The tile loop of the row search: the body of k_accumulate_rows, and — with `after_tile`, called by the whole wave when a tile's
+// rounds are done, while W.id[] still names the tile's keypoints — of the persistent small-frame kernel (k_gn_persistent), which runs
+// the residual part for the same keypoints right there.
+template <int NB, bool HIST, bool PROF, bool SHARED, typename AfterTile>
+__device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
+                                           int first_iter, int rounds, unsigned long long *prof, int ablate, char *smem, int tile_first, int tile_end,
+                                           int tile_step, AfterTile after_tile) {
     constexpr int S = 2 * NB + 1, V = S * S * S, VIT = (V + 15) / 16, OCC = (V + 3) & ~3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (st->done && !ablate) return;                  // an ablated run starves the solve: keep timing the search anyway
-    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
     WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
     RowList &R = W.list[row];
@@ -763,18 +782,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
     }
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
-    // Tile hand-out. Default: wave w of block b starts at tile 4 b + w and strides by the grid. With kp.xcd_split (sorted
-    // positions over a map larger than the caches) the tiles are cut into eight contiguous ranges and the blocks that land on
-    // XCD x (workgroups are dealt round-robin to the 8 XCDs) stay inside range x, so each XCD's L2 holds an eighth of the
-    // map region in flight instead of all eight holding the same lines.
-    int tile_first = blockIdx.x * ROW_WAVES + wave, tile_end = ntiles, tile_step = gridDim.x * ROW_WAVES;
-    if (kp.xcd_split) {
-        const int x = blockIdx.x & 7, per = (ntiles + 7) >> 3;
-        const int blocks_on_x = ((int) gridDim.x - x + 7) >> 3;
-        tile_first = x * per + (blockIdx.x >> 3) * ROW_WAVES + wave;
-        tile_end = min(ntiles, (x + 1) * per);
-        tile_step = blocks_on_x * ROW_WAVES;
-    }
     for (int tile = tile_first; tile < tile_end; tile += tile_step) {
         // ---------------- phase A: lane (row, sub < rounds) owns keypoint (sub * ntiles + tile) * 4 + row: round r of a
         // tile works on four CONSECUTIVE keypoints (neighbours in the scan usually share their home voxel), while the
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
-            uint32_t *occ_tab = RP.occ;           // where B4 finds a candidate's voxel block
+            const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             bool tie_seen = false;                // some selection of this round met candidates whose distances (nearly) tie
             if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
 
@@ -1135,15 +1142,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             // drops it on that count alone: when no row of the wave can be used, skip the selection and hand over counts only.
             const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr;
             if (!(ablate & 2) && __any(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
-            // a keypoint whose candidates (nearly) tie in distance: only the reference's own queue says which of them it keeps and in
-            // which order (map.h:491-513) — replay it for that keypoint, one lane, all sweep voxels, radius only
-            if (__any(tie_seen && searching && row_needed) && !ablate) {
-                int n_replayed = Ln;
-                if (tie_seen && searching && row_needed && sub == 0)
-                    n_replayed = replay_reference_queue<NB>(map, qx, qy, qz, kx, ky, kz, k, R, occ_tab);
-                asm volatile("" ::: "memory");
-                if (tie_seen && searching && row_needed) Ln = __shfl(n_replayed, row * 16);
-            }
             const int n = (ablate & 2) ? min(Ln, k) : Ln;
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST
@@ -1154,7 +1152,10 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                 if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
                     if (sub == 0) {
-                        o[0] = (uint32_t) n; kp.cnt[kp_r] = (uint32_t) n;
+                        // (nearly) tied candidates: which of them the reference keeps, and in which order, only its own queue says
+                        // (map.h:491-513) — the kernels that read this record replay it for this keypoint (resolve_ties)
+                        const uint32_t flagged = (uint32_t) n | ((tie_seen && row_needed) ? TIE_FLAG : 0u);
+                        o[0] = flagged; kp.cnt[kp_r] = flagged;
                         // a full, sorted list (Ln >= k implies the selection ran): its last entry is the k-th neighbour
                         if (kp.kth) kp.kth[kp_r] = (n >= k && !(ablate & 2)) ? __double2float_ru(R.d2[k - 1]) : __int_as_float(0x7f800000);
                     }
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
             }
             CTGN_TICK(5)
         }
-
+        after_tile(tile);
     }
     if (PROF && lane == 0) {
         unsigned long long tot_ = 0;
@@ -1185,6 +1186,31 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         wrec[0] = t_wave_start; wrec[1] = __builtin_readcyclecounter(); wrec[2] = pc[8]; wrec[3] = pc[9];
     }
 #undef CTGN_TICK
+}
+
+// NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles.
+template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false>
+__global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
+                                                               double *partials, DebugView dbg, int first_iter, int rounds,
+                                                               unsigned long long *prof = nullptr, int ablate = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done && !ablate) return;                  // an ablated run starves the solve: keep timing the search anyway
+    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = (kp.n + 4 * rounds - 1) / (4 * rounds);
+    // Tile hand-out. Default: wave w of block b starts at tile 4 b + w and strides by the grid. With kp.xcd_split (sorted
+    // positions over a map larger than the caches) the tiles are cut into eight contiguous ranges and the blocks that land on
+    // XCD x (workgroups are dealt round-robin to the 8 XCDs) stay inside range x, so each XCD's L2 holds an eighth of the
+    // map region in flight instead of all eight holding the same lines.
+    int tile_first = blockIdx.x * ROW_WAVES + wave, tile_end = ntiles, tile_step = gridDim.x * ROW_WAVES;
+    if (kp.xcd_split) {
+        const int x = blockIdx.x & 7, per = (ntiles + 7) >> 3;
+        const int blocks_on_x = ((int) gridDim.x - x + 7) >> 3;
+        tile_first = x * per + (blockIdx.x >> 3) * ROW_WAVES + wave;
+        tile_end = min(ntiles, (x + 1) * per);
+        tile_step = blocks_on_x * ROW_WAVES;
+    }
+    rows_tiles<NB, HIST, PROF, SHARED>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
 }
 
 template <int NB>
@@ -1217,7 +1243,8 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // One wave, one keypoint per lane (position my_pos): neighbour set -> sums -> normal, gates, residual, u -> the wave's 13 x 13 product
 // U^T U added to accm (FP64 MFMA, fixed order). `rec` is this wave's 64 x 13 LDS staging area.
 __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
-                                              int ablate, const NbSums &sums, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave) {
+                                              int ablate, const NbSums &sums, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave,
+                                              TieScratch &tie) {
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
     const uint32_t blk8 = (uint32_t) map.blk * 8u;
     const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
@@ -1245,10 +1272,11 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             } else {
             // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
             // record in nine independent 16-byte loads
-            const int cnt_n = min((int) kp.cnt[my_kp], KMAX);
+            const uint32_t cnt_raw = kp.cnt[my_kp];
+            const int cnt_n = min((int) (cnt_raw & ~TIE_FLAG), KMAX);
             fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
             uint32_t rec32[SEL_STRIDE];
-            rec32[0] = (uint32_t) cnt_n;
+            rec32[0] = (uint32_t) cnt_n | (cnt_raw & TIE_FLAG);
             if (fetch_rec) {
                 const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
 #pragma unroll
@@ -1257,6 +1285,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
                     rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
                 }
             }
+            resolve_ties(map, kp, my_kp, fetch_rec, rec32, tie, lane, prm.max_nb);      // rare: see TIE_FLAG
             res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
             // a keypoint with fewer than min_number_neighbors (or 5) neighbours is dropped by the gates below whatever its
             // sums are (ct_icp.cpp:769, neighborhood.h:227): do not gather for it, unless debug capture wants its farthest
@@ -1347,6 +1376,7 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
                                                             double *partials, DebugView dbg, int ablate, NbSums sums) {
     __shared__ double s_rec[BLK / 64][64 * 13];
     __shared__ double s_comb[BLK / 64][SYS_N];
+    __shared__ TieScratch s_tie[BLK / 64];
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     d4_t accm = {0.0, 0.0, 0.0, 0.0};
@@ -1364,7 +1394,7 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
         tile_step = ((int) gridDim.x - x + 7) >> 3;
     }
     for (; tile < tile_end; tile += tile_step)
-        residual_tile(map, kp, st, prm, dbg, ablate, sums, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave);
+        residual_tile(map, kp, st, prm, dbg, ablate, sums, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave, s_tie[wave]);
     unpack_wave_sums(lane, accm, n_used_wave, s_comb[wave]);
     __syncthreads();
     for (int e = tid; e < SYS_N; e += BLK) {

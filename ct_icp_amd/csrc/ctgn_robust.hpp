@@ -179,6 +179,7 @@ __device__ __forceinline__ double ct_residual(const PoseCtx &c, double alpha, Ve
 // k_robust_prepare — lane per keypoint (ct_icp.cpp:548-596 without the solver bookkeeping)
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, const GnState *st, RobustParams prm, RobustBuf rb) {
+    __shared__ TieScratch s_tie[4];
     if (st->done) return;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
     const uint32_t blk8 = (uint32_t) map.blk * 8u;
@@ -191,6 +192,8 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
             const uint4 v4 = in4[q];
             rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
         }
+        // (nearly) tied candidates: the reference's own queue is replayed for this keypoint (resolve_ties, ctgn_kernels.hpp)
+        resolve_ties(map, kp, k, true, rec32, s_tie[threadIdx.x >> 6], (int) (threadIdx.x & 63), prm.max_nb);
         const int n_all = min((int) rec32[0], KMAX);
         const int n = (n_all >= prm.min_nb && n_all >= 5) ? n_all : 0;          // invalid below (:566-567): nothing to gather, and the search kernel hands over no offsets
         Vec3 S{0, 0, 0}, q0{0, 0, 0};

@@ -75,8 +75,9 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
     for j, (raw, t, tbe) in enumerate(scans):
         order = None if orders is None else orders[j]
         # the first two registered frames carry the frame's end timestamp on every point: "no elastic ICP for first frame because no
-        # initialization of ego-motion" (odometry.cpp:354-359)
-        override = float(tbe[1]) if j <= 1 else None
+        # initialization of ego-motion" (odometry.cpp:354-359) — unless the caller supplies their begin / end poses (a bootstrap from
+        # ground truth, which the reference does not have): those frames are then inserted undistorted with the poses given
+        override = float(tbe[1]) if (j <= 1 and init_poses is None) else None
         if j < init_frames:
             pose0 = np.asarray(init_poses[j], dtype=np.float64) if init_poses is not None else se3.identity_pose14()
             r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, override_timestamp=override, want_all=False)

@@ -1171,10 +1171,31 @@ def test_exact_distance_ties_on_a_lattice_map(mode):
     assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"]) and (info["n_neighbors"] == 20).all()
     assert np.array_equal(dbg["farthest"], info["farthest"])
     assert np.array_equal(dbg["used"], info["used"])
-    if mode in ("rows", "rows_plain_rank"):
-        assert np.array_equal(dbg["normal"], info["normal"]) and np.array_equal(dbg["a2d"], info["a2d"])     # same neighbours in the same order
+    # (no bit-comparison of the GN normals here: every lattice neighbourhood is symmetric, two singular values tie exactly and the normal is
+    # then whatever the eigen-solver's roundings make of it — a2D = 0 gives such a keypoint weight zero; the robust route below, which
+    # runs Eigen's JacobiSVD restated operation for operation, IS compared bit for bit)
     A, b, n_used = s.get_system()
     assert n_used == no and np.abs(A - Ao).max() <= 1e-10 * max(np.abs(Ao).max(), 1e-300)
+    if mode in ("rows", "rows_plain_rank"):
+        # the robust route reads the same neighbour records (k_robust_prepare): its blocks carry the first THREE neighbours of the
+        # reference's order (num_closest_neighbors 3) and the normal of the exactly restated JacobiSVD — on a lattice the sums are exact,
+        # so the normals are bit-identical iff the kept SETS are
+        ro = cia.CTICPOptions(solver=cia.CERES, debug_print=False, min_number_neighbors=20, num_iters_icp=1, ls_max_num_iters=0, num_closest_neighbors=3)
+        oro = orc.RobustOptions(ro.num_iters_icp, ro.min_number_neighbors, ro.max_number_neighbors, False, ro.max_num_residuals, ro.loss_function,
+                                ro.ls_max_num_iters, ro.num_closest_neighbors, ro.weight_alpha, ro.weight_neighborhood, ro.power_planarity,
+                                ro.max_dist_to_plane_ct_icp, ro.ls_sigma, ro.ls_tolerant_min_threshold, ro.threshold_orientation_norm,
+                                ro.threshold_translation_norm)
+        s.set_debug(False)
+        s.set_keypoints(qs, np.zeros_like(qs), tt)
+        s.solve_robust(pose, (0.0, 1.0), ro)
+        want = orc.robust_build(om, qs, qs, tt, (0.0, 1.0), oro, heap_mode=0)
+        got = s.robust_blocks()
+        kpi = want["keypoint"][::3]
+        assert len(kpi) == n and np.array_equal(kpi, np.arange(n))
+        assert np.array_equal(got["normal"], want["normal"][::3])
+        gref = got["ref"]                                    # (n, 3): the first reference point; robust_blocks returns block 0 of each keypoint
+        assert np.array_equal(gref, want["ref"][::3])
+        s.set_debug(True)
     if mode == "rows":
         # a second iteration searches with a carried-over bound: the replay still sees the whole radius
         o2 = _opts(num_iters_icp=3, threshold_orientation_norm=0.0)
@@ -1256,15 +1277,18 @@ def test_k32_neighbours_and_64_point_voxels(box_case, mode):
         assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=1))
 
 
-def test_config_d_dense_scan_one_iteration_matches_oracle():
-    """BASELINE.json configs[3] (dense scan, sharded across GPUs in production; here the single-GPU kernel instantiation it uses):
-    the 125-voxel sweep (0.5 m x 40-point map, radius 0.8) on >= 1 M keypoints, one accumulation against the oracle running OpenMP
-    over keypoints — neighbour counts, farthest neighbours and gate decisions identical, packed system <= 1e-10 relative, pose of
-    the following solve <= 1e-8. Same generator as `bench.py --workload D`, on a 600 m stretch (4.4 M map points) so that the CPU
-    side finishes in about a minute."""
+def test_config_d_ouster_scan_matches_oracle():
+    """BASELINE.json configs[3] as SURVEY.md section 8d defines it (sharded across GPUs in production; here the single-GPU kernel instantiation
+    it uses): an Ouster-128-style scan — 128 beams x 2048 columns x 8 accumulated sub-sweeps = 2.1 M rays RAY-CAST against the residential
+    scene — keypoints = the 0.05 m grid of the returns (~0.9 M), the 125-voxel sweep over a 0.5 m x 40-point map (radius 0.8) of every
+    surface within 70 m (the bench uses 100 m; 70 keeps the CPU side of this test around half a minute). One accumulation against the
+    oracle running OpenMP over keypoints — neighbour counts, farthest neighbours and gate decisions identical, packed system <= 1e-10
+    relative — and then the driving profile's FIVE iterations: same iteration count, same residual count, pose <= 1e-8. Same generator
+    as `bench.py --workload D`."""
     import os
     import bench
-    inp = bench.make_inputs_dense(0, length=600.0)
+    inp = bench.make_inputs_ouster(sweeps=8, radius=70.0)
+    assert inp["rays"] == 128 * 2048 * 8
     res = [(0.5, 0.03, 40)]
     om = orc.Map(resolutions=res, default_radius=0.8)
     gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*res[0])], default_radius=0.8))
@@ -1275,27 +1299,32 @@ def test_config_d_dense_scan_one_iteration_matches_oracle():
     assert gm.SearchParamsFromRadiusSearch() == (0, 0.5, 2)
     raw, t = inp["raw"], inp["t"]
     n = len(t)
-    assert n >= 1_000_000
+    assert n >= 800_000
     pose0 = syn.perturb_pose(inp["pose_gt"], 0.003, 0.02, seed=5)
     world0 = se3.ct_transform(pose0, inp["tbe"], t, raw)
     threads = max(1, min(16, os.cpu_count() or 1))
     o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
     Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, inp["tbe"], _oopts(o), heap_mode=0, num_threads=threads, debug=True)
-    pose_o, _, _ = orc.gn_solve_update(Ao, bo, no, None, pose0)
+    o5 = _opts(num_iters_icp=5, threshold_orientation_norm=0.0)
+    pose_o5, _, so5 = orc.register_gn(om, raw, world0, t, pose0, inp["tbe"], _oopts(o5), None, heap_mode=0, num_threads=threads)
     for ordering in (0, 1):                                        # caller order; home-voxel order (what the library picks for this size)
         s = cia.GnSolver(gm)
         s.set_ordering(ordering)
         s.set_debug(True)
         s.set_keypoints(raw, world0, t)
-        pose1, summ, _ = s.solve(pose0, inp["tbe"], o)
+        s.solve(pose0, inp["tbe"], o)
         dbg = s.get_debug()
         A, b, n_used = s.get_system()
         assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
         has = info["n_neighbors"] >= 20
-        assert has.sum() > 700_000 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
-        assert np.array_equal(dbg["used"], info["used"]) and n_used == no == summ.num_residuals_used
+        assert has.sum() > 500_000 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
+        assert np.array_equal(dbg["used"], info["used"]) and n_used == no
         assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max() and np.abs(b - bo).max() < 1e-10 * np.abs(bo).max() + 1e-14
-        tr, rot = se3.pose_error(pose1, pose_o)
+        s.set_debug(False)
+        s.set_keypoints(raw, world0, t)
+        pose5, summ5, _ = s.solve(pose0, inp["tbe"], o5)
+        assert summ5.num_iters == so5.num_iters == 5 and summ5.num_residuals_used == so5.num_residuals_used
+        tr, rot = se3.pose_error(pose5, pose_o5)
         assert tr < TIGHT and rot < TIGHT, (tr, rot)
 
 
