@@ -102,6 +102,16 @@ struct ctgn_context {
     GnParams prm{};
     ctgn_options gn_opts{};
     int launched_iters = 0;
+    // persistent small-frame kernel (k_gn_persistent): barrier counters (two slots, alternating per launch), enabled unless a barrier timed out
+    unsigned int *d_bar = nullptr;
+    int persist_slot = 0;
+    bool persist_disabled = false;
+    int persist_mode = -1;              // ctgn_set_persistent
+    bool world_final_done = false;      // the running solve's last launch already re-transformed the keypoints and mirrored the state
+    // state initialisation of a solve is deferred to its first launch (the persistent kernel does it in its prologue)
+    bool init_pending = false;
+    const double *init_pose = nullptr;
+    double init_tbe[2] = {0.0, 0.0};
     bool kth_fresh = false;             // the k-th distances on the device were written by the previous search of this solve
     int searches_in_solve = 0;          // neighbour searches launched since the solve began (the first one has no carried-over bound)
     int last_grid = 0;
@@ -556,7 +566,13 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
     return grid;
 }
 
+ctgn_status flush_state_init(ctgn_handle h);
+
 ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter, bool search_only = false) {
+    {
+        ctgn_status fs = flush_state_init(h);
+        if (fs != CTGN_OK) return fs;
+    }
     if (h->order_stale) {
         ctgn_status os = order_keypoints(h, mv);
         if (os != CTGN_OK) return os;
@@ -649,10 +665,72 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     return CTGN_OK;
 }
 
+// the state initialisation gn_begin deferred: launched in front of the first kernel that needs d_state (the persistent kernel does it itself)
+ctgn_status flush_state_init(ctgn_handle h) {
+    if (!h->init_pending) return CTGN_OK;
+    h->init_pending = false;
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, h->init_pose, h->init_tbe[0], h->init_tbe[1]);
+    HIPCHK(h, hipGetLastError());
+    return CTGN_OK;
+}
+
+// Is this solve one for the persistent kernel? Small frames on the default row kernel, nothing that needs per-launch events, per-position
+// ordering or kernel variants; never after a barrier of it has timed out on this handle.
+bool persistent_ok(ctgn_handle h, const MapView &mv) {
+    static const int env = [] { const char *e = std::getenv("CTGN_PERSISTENT"); return e ? std::atoi(e) : 1; }();
+    if (!env || h->persist_mode == 0 || h->persist_disabled || h->n_kp < 1 || h->n_kp > 4096) return false;
+    if (h->variant != 0 || h->profiling || h->ablate || h->ordering_mode == 1 || h->order_valid || h->kp_presorted) return false;
+    if (!((mv.nb == 1 || mv.nb == 2) && mv.blk <= 64)) return false;
+    // every keypoint must get its own row in ONE round on the one XCD (2 blocks of 4 waves per CU, 32 CUs: 1024 keypoints): with a
+    // second round per wave the three-launch loop, which spreads the rounds over all eight XCDs, is the faster one (measured on the
+    // NCLT profile, 1500 keypoints x 125 voxels: 55 us per iteration persistent against 43 us)
+    return (h->n_kp + 3) / 4 <= 2 * std::max(1, h->num_cus / 8) * ROW_WAVES;
+}
+
+// `iters` whole GN iterations in ONE launch (k_gn_persistent). final_transform: also the re-transform of gn_end and the state mirror.
+ctgn_status launch_persistent(ctgn_handle h, const MapView &mv, int iters, bool final_transform, double *state_copy) {
+    if (h->order_stale) {                       // n <= 4096 is never ordered automatically; the call settles the flags
+        ctgn_status os = order_keypoints(h, mv);
+        if (os != CTGN_OK) return os;
+    }
+    static const bool env_times = std::getenv("CTGN_PERSIST_TIMES") != nullptr;      // measurement hook: per-block timeline -> ctgn_wave_timeline
+    auto launch = [&](auto kernel, size_t smem) -> ctgn_status {
+        static int per_cu_cached[2] = {0, 0};
+        int &per_cu = per_cu_cached[mv.nb == 1 ? 0 : 1];
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, ROW_BLOCK, smem) != hipSuccess || per_cu < 1)) per_cu = 1;
+        const int mmax = std::min(per_cu * std::max(1, h->num_cus / 8), MAX_PARTIAL_BLOCKS);       // co-resident blocks on one XCD
+        int rounds = 1;
+        if ((h->n_kp + 3) / 4 > mmax * ROW_WAVES) rounds = pick_rounds(h->n_kp, mmax * ROW_WAVES);
+        const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
+        const int nblk = std::max(1, std::min(mmax, (ntiles + ROW_WAVES - 1) / ROW_WAVES));
+        KpView kv = kp_view(h, false);
+        const int kth_valid0 = (h->launched_iters > 0 && h->searches_in_solve > 0 && h->kth_fresh) ? 1 : 0;
+        const int init = h->init_pending ? 1 : 0;
+        h->init_pending = false;
+        hipLaunchKernelGGL(kernel, dim3(8 * nblk), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->init_pose ? h->init_pose : h->d_pose_in,
+                           h->init_tbe[0], h->init_tbe[1], init, h->prm, h->d_partials, dbg_view(h), iters, h->launched_iters, kth_valid0, rounds, nblk,
+                           h->d_bar, h->persist_slot, state_copy, CTGN_MIN_KEYPOINTS_USED, final_transform ? 1 : 0, h->d_sys,
+                           env_times ? h->d_prof + 16 : (unsigned long long *) nullptr);
+        HIPCHK(h, hipGetLastError());
+        h->persist_slot ^= 1;
+        h->searches_in_solve += iters;
+        h->launched_iters += iters;
+        h->kth_fresh = true;
+        h->last_grid = nblk;
+        h->world_final_done = final_transform;
+        return CTGN_OK;
+    };
+    return mv.nb == 1 ? launch(k_gn_persistent<1>, persistent_kernel_smem<1>()) : launch(k_gn_persistent<2>, persistent_kernel_smem<2>());
+}
+
 ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
     // measurement hook (CTGN_SOLVE_SMALL=1): a 4-wave block for <= 128 partial columns. Slower on the B1 frame (0.0425 vs 0.0404 ms per
     // iteration: the reduce is one trip to 96 freshly written lines, and four waves have a quarter of the loads in flight), so off.
     static const int env_small = [] { const char *e = std::getenv("CTGN_SOLVE_SMALL"); return e ? std::atoi(e) : 0; }();
+    {
+        ctgn_status fs = flush_state_init(h);
+        if (fs != CTGN_OK) return fs;
+    }
     if (env_small == 1 && h->last_grid <= 128)
         hipLaunchKernelGGL(k_reduce_solve<256>, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state, h->prm, mode,
                            CTGN_MIN_KEYPOINTS_USED);
@@ -767,6 +845,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_bar), 4 * sizeof(unsigned int)) == hipSuccess &&           // 2 arrival counters | 2 XCC masks
+             hipMemsetAsync(h->d_bar, 0, 4 * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_prof), PROF_WORDS * sizeof(unsigned long long)) == hipSuccess &&
              hipMemsetAsync(h->d_prof, 0, PROF_WORDS * sizeof(unsigned long long), h->stream) == hipSuccess &&
              hipEventCreate(&h->ev_loop_start) == hipSuccess && hipEventCreate(&h->ev_loop_stop) == hipSuccess &&
@@ -778,6 +858,10 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radius_search),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_persistent<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) persistent_kernel_smem<1>()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_persistent<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) persistent_kernel_smem<2>()) == hipSuccess;
         if (!ok) { ctgn_destroy(h); return CTGN_ERR_HIP; }
     }
     *out = h;
@@ -825,6 +909,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_pose_in) hipFree(h->d_pose_in);
         if (h->h_pose_in) hipHostFree(h->h_pose_in);
         if (h->d_counters) hipFree(h->d_counters);
+        if (h->d_bar) hipFree(h->d_bar);
         if (h->d_prof) hipFree(h->d_prof);
         if (h->d_rstate) hipFree(h->d_rstate);
         if (h->h_rstate) hipHostFree(h->h_rstate);
@@ -1231,8 +1316,11 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->pose_in_valid = true;
     }
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, h->stream, h->d_state, d_pose, tbe[0], tbe[1]);
-    HIPCHK(h, hipGetLastError());
+    // the state initialisation rides with the solve's first launch (flush_state_init / the persistent kernel's prologue)
+    h->init_pending = true;
+    h->init_pose = d_pose;
+    h->init_tbe[0] = tbe[0]; h->init_tbe[1] = tbe[1];
+    h->world_final_done = false;
     h->launched_iters = 0;
     h->searches_in_solve = 0;
     h->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
@@ -1266,6 +1354,8 @@ ctgn_status ctgn_gn_iterate(ctgn_handle h, int32_t iterations, int32_t sharded) 
     if (sharded && !h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
     MapView mv;
     ctgn_status st = make_map_view(h, -1.0, &mv);
+    if (st == CTGN_OK && !sharded && iterations > 0 && persistent_ok(h, mv))
+        return launch_persistent(h, mv, iterations, false, nullptr);        // a small frame: the whole batch of iterations in one launch
     for (int it = 0; st == CTGN_OK && it < iterations; ++it) {
         st = launch_accumulate(h, mv, h->launched_iters == 0);
         if (st != CTGN_OK) break;
@@ -1303,6 +1393,10 @@ ctgn_status ctgn_gn_solve_update(ctgn_handle h) {
 ctgn_status ctgn_gn_done(ctgn_handle h, int32_t *done) {
     NEED_DEVICE(h);
     if (!done) return CTGN_ERR_INVALID_ARGUMENT;
+    {
+        ctgn_status fs = flush_state_init(h);
+        if (fs != CTGN_OK) return fs;
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *done = h->h_state->done;
@@ -1315,7 +1409,11 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
     if (!h->gn_active) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_gn_begin was not called");
     const bool merged = h->prefetch_world && h->n_kp > 0;      // world points + state in ONE device-to-host copy
     const size_t c = (size_t) h->kp_stride;
-    if (h->n_kp > 0) {
+    {
+        ctgn_status fs = flush_state_init(h);
+        if (fs != CTGN_OK) return fs;
+    }
+    if (h->n_kp > 0 && !h->world_final_done) {                 // (the persistent kernel's epilogue has done both already)
         const int grid = std::max(1, std::min((h->n_kp + 255) / 256, 2048));
         hipLaunchKernelGGL(k_transform, dim3(grid), dim3(256), 0, h->stream, kp_view(h), h->d_state,
                            merged ? h->d_kp + 7 * c + 16 : nullptr);
@@ -1341,6 +1439,13 @@ static ctgn_status gn_collect(ctgn_handle h, double pose_out[14], ctgn_summary *
     if (h->gn_opts.debug_print > 1)
         std::fprintf(stderr, "[ctgn] k_reduce_solve clocks: reduce %llu factorise %llu substitute %llu update %llu\n",
                      s.solve_cycles[0], s.solve_cycles[1], s.solve_cycles[2], s.solve_cycles[3]);
+    if (s.failed == GN_FAILED_BARRIER) {
+        // the persistent kernel's blocks were not all running (the device is shared with something that holds its compute units): the
+        // registration was abandoned before the pose changed; this handle goes back to the three-launch loop
+        h->persist_disabled = true;
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "[HIP] in-kernel barrier timed out; retry"); }
+        return fail(h, CTGN_ERR_HIP, "[HIP] the persistent small-frame kernel's barrier timed out (device shared?); the handle now uses the three-launch loop — retry the call");
+    }
     if (pose_out) for (int i = 0; i < 14; ++i) pose_out[i] = s.pose[i];
     if (summary) {
         std::memset(summary, 0, sizeof(*summary));
@@ -1385,6 +1490,11 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
     hipGraph_t graph = nullptr;
     if (capture && hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
         return fail(h, CTGN_ERR_HIP, "[HIP] hipStreamBeginCapture");
+    if (st == CTGN_OK && !capture && opts->num_iters_icp > 0 && persistent_ok(h, mv)) {
+        // a small frame (the reference's own keypoint count): state init, all iterations and the final re-transform in ONE launch
+        const bool merged = h->prefetch_world && h->n_kp > 0;
+        st = launch_persistent(h, mv, opts->num_iters_icp, true, merged ? h->d_kp + 7 * (size_t) h->kp_stride + 16 : nullptr);
+    } else
     for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {       // ct_icp.cpp:745
         st = launch_accumulate(h, mv, it == 0);
         if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
@@ -1830,10 +1940,14 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
         st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
         MapView mv;
         if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
+        if (st == CTGN_OK && opts->num_iters_icp > 0 && persistent_ok(h, mv)) {
+            st = launch_persistent(h, mv, opts->num_iters_icp, false, nullptr);        // the keypoints' world points are not an output here
+        } else
         for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {           // ct_icp.cpp:745
             st = launch_accumulate(h, mv, it == 0);
             if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
         }
+        if (st == CTGN_OK) st = flush_state_init(h);                                 // num_iters_icp 0: the state is still to be written
         if (st != CTGN_OK) {
             h->gn_active = false;
             hipStreamSynchronize(h->stream);
@@ -2041,6 +2155,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     h->prm.max_nb = o->max_number_neighbors;
 
     if (h->gn_active) { HIPCHK(h, hipStreamSynchronize(h->stream)); h->gn_active = false; }
+    h->init_pending = false;                          // this route initialises the state itself, below
     const double *d_pose = h->d_pose_in;
     if (h->pose_on_device) {                          // already behind the keypoint arrays (ctgn_register_robust)
         d_pose = h->d_kp + 7 * (size_t) h->kp_stride;
@@ -2323,6 +2438,12 @@ ctgn_status ctgn_test_compact(ctgn_handle h, const uint8_t *flags, size_t n, uin
 ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return CTGN_ERR_INVALID_ARGUMENT;
     h->ordering_mode = mode;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
+    if (!h || (mode != -1 && mode != 0)) return CTGN_ERR_INVALID_ARGUMENT;
+    h->persist_mode = mode;
     return CTGN_OK;
 }
 

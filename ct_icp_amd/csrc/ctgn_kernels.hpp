@@ -224,7 +224,7 @@ constexpr int LANE_BLOCK = 128;
 // ---- libstdc++'s std::priority_queue on (distance, payload) with the reference's comparator `a.distance < b.distance`
 // (include/ct_icp/map.h:595-601), restated: push = push_back + std::push_heap, pop = std::pop_heap (+ pop_back) of bits/stl_heap.h.
 // Which of two EQUAL distances a full queue keeps, and in which order it drains them, is decided by this layout and nothing else, so
-// reproducing the reference on exact ties means replaying exactly these moves (oracle: heap_mode 0, oracle/ctgn_oracle.c).
+// reproducing the reference on exact ties means replaying exactly these moves (the test oracle restates the same queue as its heap_mode 0).
 // `ld(i)` / `st(i, item)` access slot i of the heap's storage (LDS here).
 struct HeapItem {
     double d;          // the key: Euclidean distance (map.h:491)
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
 }
 
 template <int NB>
-inline size_t rows_kernel_smem() {
+__host__ __device__ constexpr size_t rows_kernel_smem() {
     constexpr int S = 2 * NB + 1, V = S * S * S, OCC = (V + 3) & ~3;
     return sizeof(WaveScratch<OCC>) * ROW_WAVES;
 }
@@ -1673,6 +1673,183 @@ __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, i
 }
 
 #undef WSYNC
+
+// ================================================================================================
+// k_gn_persistent — ONE launch per registration for small frames (the reference's own regime: 1-3 k keypoints x 5 iterations,
+// config/odometry/driving_config.yaml): state init, every GN iteration (search -> residual -> sums -> 12 x 12 solve -> pose
+// update -> stop test, ct_icp.cpp:745-981) and the final re-transform, instead of three dependent launches per iteration.
+//
+// Why it can be cheap on this part: the blocks that do the work all sit on ONE XCD (workgroup b is dealt to XCD b % 8: the grid is
+// 8 x nblk blocks and the seven blocks of every eight that land elsewhere leave at once), so the one exchange per iteration — the
+// per-block packed sums, 96 doubles each — is served by that XCD's L2, the point of coherence of its 32 CUs: publishers store plainly
+// (write-through L1, the line STAYS in this L2), drain their stores (s_waitcnt vmcnt(0)) and arrive on a counter; readers poll the
+// counter and read the sums with sc1 loads (their own L1 bypassed, L2 hit). No agent-scope release / acquire fence, hence no L2
+// write-back or invalidate — what made the "last block reduces" variants of rounds 1-2 slower than a launch boundary — and no sc1
+// (write-through-to-memory) stores either, which drop the line from L2 and made every reader wait for the fabric (measured: 24 us
+// per iteration in barrier + reduce + solve against 9.5 us for the separate solve kernel).
+// Placement is then a correctness matter, so it is CHECKED, not assumed: every working block ORs the XCC it runs on (HW_REG_XCC_ID)
+// into a mask with its first arrival; more than one bit set means the dispatcher spread the blocks over several L2s, the kernel
+// stops before anything is read through the wrong cache and the host falls back to the three-launch loop for good.
+// Every block then reduces ALL published sums in the same fixed order and runs the same solve on its own copy of the state (LDS):
+// identical arithmetic on identical input, so no pose broadcast and no second barrier. The search and the residual part of a
+// keypoint run in the same wave back to back (rows_tiles' after_tile hook), so the neighbour records never change hands between
+// CUs. Deterministic like the three-launch loop, with its own (fixed) summation order: per wave, per block, blocks in index order.
+// A barrier that does not complete (blocks not co-resident: another process holding the CUs) times out, flags the state
+// (failed = 3) and the host falls back to the three-launch loop for good.
+// ================================================================================================
+struct PersistShared {
+    GnState state;                       // this block's copy of the solver state — identical in every block
+    SolveScratch solve;
+    double comb[ROW_WAVES][SYS_N];
+    TieScratch tie[ROW_WAVES];
+    int timeout;
+};
+constexpr int GN_FAILED_BARRIER = 3;     // GnState::failed: the in-kernel barrier timed out (host falls back)
+
+template <int NB>
+inline size_t persistent_kernel_smem() { return rows_kernel_smem<NB>() + sizeof(PersistShared); }
+
+__device__ __forceinline__ void sc1_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sc1_load(const double *p) {
+    return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int NB>
+__global__ __launch_bounds__(ROW_BLOCK, 2) void k_gn_persistent(MapView map, KpView kp, GnState *st_out, const double *pose_in, double tb, double te,
+                                                                int init_state, GnParams prm, double *partials, DebugView dbg, int iters,
+                                                                int iters_before, int kth_valid0, int rounds, int nblk, unsigned int *bar, int slot,
+                                                                double *state_copy, int min_used, int final_transform, double *sys_out,
+                                                                unsigned long long *times) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((blockIdx.x & 7u) != 0u) {                    // not on the working XCD: nothing to do ...
+        if (blockIdx.x == 1 && tid == 0) { bar[slot ^ 1] = 0u; bar[2 + (slot ^ 1)] = 0u; }      // ... but to zero the NEXT launch's counter and XCC mask (stream order makes it safe)
+        return;
+    }
+    const int b = (int) (blockIdx.x >> 3);
+    PersistShared &P = *reinterpret_cast<PersistShared *>(smem + rows_kernel_smem<NB>());
+    // ---- prologue: every block builds the same state
+    if (tid == 0) {
+        if (init_state) {                             // what k_state_init does (pose normalisation ct_icp.cpp:716-717 + slerp constants)
+            GnState &S = P.state;
+            const Quat qb = quat_normalized(Quat{pose_in[0], pose_in[1], pose_in[2], pose_in[3]});
+            const Quat qe = quat_normalized(Quat{pose_in[7], pose_in[8], pose_in[9], pose_in[10]});
+            S.pose[0] = qb.x; S.pose[1] = qb.y; S.pose[2] = qb.z; S.pose[3] = qb.w;
+            S.pose[7] = qe.x; S.pose[8] = qe.y; S.pose[9] = qe.z; S.pose[10] = qe.w;
+            for (int c = 0; c < 3; ++c) { S.pose[4 + c] = pose_in[4 + c]; S.pose[11 + c] = pose_in[11 + c]; }
+            S.tbe[0] = tb; S.tbe[1] = te;
+            const SlerpPair sp = slerp_prepare(qb, qe);
+            S.slerp_theta = sp.theta; S.slerp_sin = sp.sin_theta; S.slerp_linear = sp.linear; S.slerp_negate = sp.negate;
+            for (int i = 0; i < 12; ++i) S.x[i] = 0.0;
+            S.step_norm = 0.0;
+            S.iter = 0; S.done = 0; S.failed = 0; S.n_used = 0;
+            for (int i = 0; i < 4; ++i) S.solve_cycles[i] = 0ull;
+            S.clk_iter_start = 0ull; S.ticks_neighborhood = 0ull; S.ticks_solve = 0ull; S.ticks_iter = 0ull;
+        } else {
+            P.state = *st_out;                        // a running solve: written by an earlier launch on this stream
+        }
+        P.timeout = 0;
+    }
+    __syncthreads();
+    const int ntiles = (kp.n + 4 * rounds - 1) / (4 * rounds);
+    const unsigned int my_xcc = (unsigned int) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+    int it = 0;
+    for (; it < iters; ++it) {
+        if (P.state.done) break;                      // the same decision in every block
+        if (tid == 0) P.state.clk_iter_start = wall_clock64();
+        KpView kv = kp;
+        kv.kth_valid = it > 0 ? 1 : kth_valid0;
+        d4_t accm = {0.0, 0.0, 0.0, 0.0};
+        int n_used_wave = 0;
+        WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> &W =
+            reinterpret_cast<WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> *>(smem)[wave];
+        // search of a tile, then — same wave, keypoints still named by W.id — its residual part: lane l takes keypoint W.id[l]
+        rows_tiles<NB, true, false, false>(map, kv, &P.state, prm, dbg, (iters_before + it) == 0 ? 1 : 0, rounds, nullptr, 0, smem,
+                                           b * ROW_WAVES + wave, ntiles, nblk * ROW_WAVES, [&](int) {
+            const int id = W.id[lane];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2
+            residual_tile(map, kv, &P.state, prm, dbg, 0, NbSums{nullptr, nullptr, 0}, id < 0 ? kv.n : id, lane, W.rec, accm, n_used_wave, P.tie[wave]);
+        });
+        unpack_wave_sums(lane, accm, n_used_wave, P.comb[wave]);
+        __syncthreads();
+        // ---- publish this block's packed sums write-through, drain, arrive
+        for (int e = tid; e < SYS_N; e += ROW_BLOCK) {
+            double sum = 0.0;
+            for (int w = 0; w < ROW_WAVES; ++w) sum += P.comb[w][e];
+            partials[(size_t) b * SYS_N + e] = sum;           // plain: write-through L1, kept in this XCD's L2. Block-major here (the
+                                                              // three-launch loop stores entry-major, 16 KB apart: one L2 channel)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned long long tc0 = __builtin_readcyclecounter();
+        const unsigned long long wall0 = wall_clock64();
+        if (tid == 0 && times) { times[4 * b] = P.state.clk_iter_start; times[4 * b + 1] = wall0; }     // measurement hook: block timeline of the last iteration
+        if (tid == 0) {
+            const unsigned int target = (unsigned int) nblk * (unsigned int) (it + 1);
+            if (it == 0) __hip_atomic_fetch_or(bar + 2 + slot, 1u << my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // before the arrival
+            __hip_atomic_fetch_add(bar + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(bar + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 18)) { P.timeout = 1; break; }   // ~0.1 s: the other blocks are not running — give up, do not hang the GPU
+            }
+            // every block has arrived, so every block's XCC bit is in the mask: one bit = one L2 = the plain stores above are visible here
+            const unsigned int xccs = __hip_atomic_load(bar + 2 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (it == 0 && (xccs & (xccs - 1u)) != 0u) P.timeout = 1;
+        }
+        __syncthreads();
+        if (tid == 0 && times) times[4 * b + 2] = wall_clock64();
+        if (P.timeout) {
+            if (tid == 0) { P.state.failed = GN_FAILED_BARRIER; P.state.done = 1; }
+            __syncthreads();
+            break;
+        }
+        // ---- every block: the same fixed-order sum over the blocks (two halves of the blocks in parallel, 16 loads in flight per
+        // thread, then half 0 + half 1), then the same solve
+        if (tid < 2 * SYS_N) {
+            const int e = tid % SYS_N, half = tid / SYS_N;
+            const int j0 = half == 0 ? 0 : nblk / 2, j1 = half == 0 ? nblk / 2 : nblk;
+            const double *col = partials + e;                          // entry e of block j: coalesced across the lanes
+            double sum = 0.0;
+            int j = j0;
+            for (; j + 16 <= j1; j += 16) {
+                double v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = sc1_load(col + (size_t) (j + q) * SYS_N);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sum += v[q];
+            }
+            for (; j < j1; ++j) sum += sc1_load(col + (size_t) j * SYS_N);
+            P.comb[half][e] = sum;
+        }
+        __syncthreads();
+        for (int e = tid; e < SYS_N; e += ROW_BLOCK) {
+            const double sum = e < SYS_USED ? P.comb[0][e] + P.comb[1][e] : 0.0;
+            P.solve.sys[e] = sum;
+            if (b == 0) sys_out[e] = sum;                             // the packed system of the last accumulation (ctgn_get_system)
+        }
+        if (tid == 0 && times) times[4 * b + 3] = wall_clock64();
+        __syncthreads();
+        if (wave == 0) solve_wave0(P.solve, &P.state, prm, min_used, lane, tc0, wall0);
+        __syncthreads();
+    }
+    // ---- epilogue: the final re-transform (ct_icp.cpp:964-966 of the last executed iteration; k_transform's rule) and the state
+    if (final_transform && P.state.iter > 0 && P.state.failed != GN_FAILED_BARRIER) {
+        for (int i = b * ROW_BLOCK + tid; i < kp.n; i += nblk * ROW_BLOCK) {
+            const Vec3 raw{kp.rx[i], kp.ry[i], kp.rz[i]};
+            const double alpha = alpha_timestamp(kp.t[i], P.state.tbe[0], P.state.tbe[1]);
+            const Vec3 p = ct_transform(&P.state, alpha, raw);
+            kp.wx[i] = p.x; kp.wy[i] = p.y; kp.wz[i] = p.z;
+        }
+    }
+    if (b == 0 && tid < (int) (sizeof(GnState) / 8)) {
+        const double v = reinterpret_cast<const double *>(&P.state)[tid];
+        reinterpret_cast<double *>(st_out)[tid] = v;
+        if (state_copy) state_copy[tid] = v;
+    }
+}
 
 // Re-transform every keypoint with the final pose (ct_icp.cpp:964-966 of the last executed iteration).
 // state_copy (optional): the GnState is mirrored right behind the world arrays so that one device-to-host copy brings

@@ -113,28 +113,33 @@ CTGN_HD void quat_to_matrix(Quat q, double R[9]) {
 
 // Eigen Quaterniond(Matrix3d).
 CTGN_HD Quat matrix_to_quat(const double R[9]) {
-    double q[4];
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
+        const double w = 0.5 * t;
         t = 0.5 / t;
-        q[0] = (R[7] - R[5]) * t;
-        q[1] = (R[2] - R[6]) * t;
-        q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        return {(R[7] - R[5]) * t, (R[2] - R[6]) * t, (R[3] - R[1]) * t, w};
     }
-    return {q[0], q[1], q[2], q[3]};
+    // largest diagonal entry, first maximum wins (i = 0; if R11 > R00: i = 1; if R22 > R_ii: i = 2), then j, k cyclic. The three cases
+    // are spelled out with constant indices: a run-time index into R[] or q[] puts both arrays into scratch memory on the device.
+    const bool i1 = R[4] > R[0];
+    const bool i2 = R[8] > (i1 ? R[4] : R[0]);
+    if (i2) {                       // i = 2, j = 0, k = 1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        const double qi = 0.5 * t;
+        t = 0.5 / t;
+        return {(R[2] + R[6]) * t, (R[5] + R[7]) * t, qi, (R[3] - R[1]) * t};
+    }
+    if (i1) {                       // i = 1, j = 2, k = 0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        const double qi = 0.5 * t;
+        t = 0.5 / t;
+        return {(R[1] + R[3]) * t, qi, (R[7] + R[5]) * t, (R[2] - R[6]) * t};
+    }
+    t = sqrt(R[0] - R[4] - R[8] + 1.0);   // i = 0, j = 1, k = 2
+    const double qi = 0.5 * t;
+    t = 0.5 / t;
+    return {qi, (R[3] + R[1]) * t, (R[6] + R[2]) * t, (R[7] - R[5]) * t};
 }
 
 // Rz(gamma) Ry(beta) Rx(alpha) exactly as spelled at reference src/ct_icp/ct_icp.cpp:919-932.

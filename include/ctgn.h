@@ -490,6 +490,10 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * costs at 132 k keypoints (num_iters_icp >= 13 there); never below 32 k keypoints. Takes effect at the
  * next ctgn_set_keypoints. Debug capture and the robust route keep caller-order records and read through the order instead. */
 ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
+/* The persistent small-frame kernel: -1 = automatic (default: solves of at most 4096 keypoints on the default row kernel run as ONE
+ * launch — state init, every GN iteration with an in-kernel barrier on one XCD, final re-transform), 0 = never
+ * (always the three launches per iteration). Same results up to the (fixed) order of the block sums. */
+ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode);
 /* Neighbour-search kernel of an ORDERED upload: -1 / 0 = k_accumulate_rows (16 lanes per keypoint; the default), 1 =
  * k_search_dense (ctgn_dense.hpp: 64 keypoints of consecutive sorted positions per wave; the positions that share a home voxel
  * share one probe of the 27 / 125 sweep voxels and one scalar-fed scan of their candidates; k-selection by histogram; the

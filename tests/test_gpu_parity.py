@@ -249,40 +249,52 @@ def test_incremental_map_updates_reach_the_device(street_case):
 
 
 def test_stepwise_api_equals_fused_loop(box_case):
+    """The three spellings of the GN loop: stepwise entry points (gn_accumulate / gn_solve_update), the fused three-launch loop, and —
+    round 3, automatic for small frames — the ONE-launch persistent kernel (ctgn_set_persistent). The first two give identical bits
+    (same kernels, deterministic reductions); the persistent kernel sums the same per-keypoint terms in its own fixed order (per wave,
+    per block, blocks in index order): identical discrete results, pose / world points / system equal to 1e-12, and bit-identical to
+    itself from run to run."""
     om, gm = build_maps(box_case, 5, with_gpu=True)
     sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.5)
     o = _opts(num_iters_icp=4, threshold_orientation_norm=0.0)
     s = cia.GnSolver(gm)
-    s.set_keypoints(raw, world0, t)
-    pose_f, summ_f, _ = s.solve(pose0, sc.t_begin_end, o)
-    w_f = s.world_points()
-    s.set_keypoints(raw, world0, t)
-    s.gn_begin(pose0, sc.t_begin_end, o)
-    for _ in range(4):
-        s.gn_accumulate()
-        s.gn_solve_update()
-    assert not s.gn_done()
-    pose_s, summ_s, _ = s.gn_end()
-    assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, s.world_points())       # deterministic reductions
-    assert summ_s.num_iters == summ_f.num_iters == 4
-    # small frames take 64-thread residual blocks (more CUs for the scattered gathers), large ones 256-thread blocks; either way the
-    # fused loop and the stepwise entry points give identical bits — odd block counts, ragged last groups, soft failure (< 100 used)
-    for n in (2048, 2047, 1300, 1025, 1024, 777, 256, 65, 64, 40):
+
+    def stepwise(r, w, tt, prior=None):
+        s.set_keypoints(r, w, tt)
+        s.gn_begin(pose0, sc.t_begin_end, o, prior)
+        for _ in range(4):
+            s.gn_accumulate()
+            s.gn_solve_update()
+        done = s.gn_done()
+        pose, summ, _ = s.gn_end()
+        return pose, summ, s.world_points(), s.get_system(), done
+
+    def fused(r, w, tt, prior=None, persistent=-1):
+        s.set_persistent(persistent)
+        s.set_keypoints(r, w, tt)
+        pose, summ, _ = s.solve(pose0, sc.t_begin_end, o, prior)
+        out = pose, summ, s.world_points(), s.get_system()
+        s.set_persistent(-1)
+        return out
+
+    pose_s, summ_s, w_s, sys_s, done = stepwise(raw, world0, t)
+    assert not done and summ_s.num_iters == 4
+    # small frames take 64-thread residual blocks (more CUs for the scattered gathers), large ones 256-thread blocks; odd block counts,
+    # ragged last groups, soft failure (< 100 used)
+    for n in (5000, 2048, 2047, 1300, 1025, 1024, 777, 256, 65, 64, 40):
         idx = np.arange(n) % len(t)
         for prior in (None, _prior(box_case, 5)[0]):
-            s.set_keypoints(raw[idx], world0[idx], t[idx])
-            pose_f, summ_f, _ = s.solve(pose0, sc.t_begin_end, o, prior)
-            w_f, sys_f = s.world_points(), s.get_system()
-            s.set_keypoints(raw[idx], world0[idx], t[idx])
-            s.gn_begin(pose0, sc.t_begin_end, o, prior)
-            for _ in range(4):
-                s.gn_accumulate()
-                s.gn_solve_update()
-            pose_s, summ_s, _ = s.gn_end()
-            assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, s.world_points()), n
+            pose_s, summ_s, w_s, sys_s, _ = stepwise(raw[idx], world0[idx], t[idx], prior)
+            pose_f, summ_f, w_f, sys_f = fused(raw[idx], world0[idx], t[idx], prior, persistent=0)
+            assert np.array_equal(pose_f, pose_s) and np.array_equal(w_f, w_s), n
             assert summ_s.success == summ_f.success and summ_s.num_iters == summ_f.num_iters and summ_s.num_residuals_used == summ_f.num_residuals_used
-            sys_s = s.get_system()
             assert np.array_equal(sys_f[0], sys_s[0]) and np.array_equal(sys_f[1], sys_s[1]) and sys_f[2] == sys_s[2]
+            pose_p, summ_p, w_p, sys_p = fused(raw[idx], world0[idx], t[idx], prior)            # one persistent launch when n <= 4096
+            assert summ_p.success == summ_s.success and summ_p.num_iters == summ_s.num_iters and summ_p.num_residuals_used == summ_s.num_residuals_used, n
+            assert np.abs(pose_p - pose_s).max() < 1e-12 and np.abs(w_p - w_s).max() < 1e-11, n
+            assert sys_p[2] == sys_s[2] and np.abs(sys_p[0] - sys_s[0]).max() <= 1e-12 * max(np.abs(sys_s[0]).max(), 1e-300)
+            pose_q, summ_q, w_q, sys_q = fused(raw[idx], world0[idx], t[idx], prior)
+            assert np.array_equal(pose_p, pose_q) and np.array_equal(w_p, w_q) and np.array_equal(sys_p[0], sys_q[0])
 
 
 # ------------------------------------------------------------------------------------------------- full-size properties
