@@ -117,33 +117,6 @@ def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, 
     return out
 
 
-def make_inputs_dense(rank: int, length: float = 2400.0, seed: int = 3, n_kp: int = 1_000_000):
-    """Config-D-like dense workload built analytically (no ray casting): a 2.4 km street whose ground and two facades are
-    sampled densely enough to fill the 0.5 m x 40-point voxels, so the device map is ~0.5 GB (>> 256 MB Infinity Cache), and
-    ~1 M keypoints spread over the WHOLE map, so one accumulate launch touches the whole working set."""
-    rng = np.random.default_rng(seed)
-    def plane(n, fixed_axis, fixed_val, r0, r1):
-        p = np.empty((n, 3))
-        free = [a for a in range(3) if a != fixed_axis]
-        p[:, free[0]] = rng.uniform(r0[0], r0[1], n)
-        p[:, free[1]] = rng.uniform(r1[0], r1[1], n)
-        p[:, fixed_axis] = fixed_val + rng.normal(0, 0.01, n)
-        return p
-    dens = 260                                                  # points / m^2: ~65 per 0.5 m voxel face before the min-distance rule
-    ground = plane(int(length * 24 * dens), 2, 0.0, (0, length), (-12, 12))
-    wall_l = plane(int(length * 8 * dens), 1, 12.0, (0, length), (0, 8))
-    wall_r = plane(int(length * 8 * dens), 1, -12.0, (0, length), (0, 8))
-    map_points = np.concatenate([ground, wall_l, wall_r])
-    kp = np.concatenate([plane(n_kp // 2, 2, 0.0, (5, length - 5), (-11.5, 11.5)),
-                         plane(n_kp // 4, 1, 12.0, (5, length - 5), (0.3, 7.7)),
-                         plane(n_kp // 4, 1, -12.0, (5, length - 5), (0.3, 7.7))])
-    kp = kp[np.random.default_rng(seed + 17 * rank + 1).permutation(len(kp))]
-    # identity begin/end pose at the origin: raw == world, the solver then estimates a small correction
-    pose = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], float)
-    t = np.linspace(0.0, 1.0, len(kp))
-    return dict(map_points=map_points, raw=kp, t=t, pose_gt=pose, tbe=np.array([0.0, 1.0]), prev_b=np.zeros(3), prev_e=np.zeros(3))
-
-
 def make_inputs_large(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
     """Workload B2: an open residential scene (ct_icp_amd.synthetic.suburb_scene) whose steady-state local map — every surface within
     the driving profile's 100 m eviction radius, sampled directly instead of ray-casting the few hundred sweeps that would have

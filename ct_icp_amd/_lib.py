@@ -171,7 +171,6 @@ SYMBOLS = {
     "ctgn_set_variant": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),
-    "ctgn_set_search_kernel": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_persistent": (C.c_int, [_H, C.c_int32]),
     "ctgn_traffic_counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_phase_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),

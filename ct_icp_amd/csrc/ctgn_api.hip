@@ -17,7 +17,6 @@
 
 #include "ctgn_devmap.hpp"
 #include "ctgn_kernels.hpp"
-#include "ctgn_dense.hpp"
 #include "ctgn_robust.hpp"
 
 using namespace ctgn;
@@ -64,8 +63,6 @@ struct ctgn_context {
                                         // neighbour their home voxel; an incoherent one (shuffled, config D) is what ordering is for
     bool kp_presorted = false;          // the resident keypoints ARE in home-voxel order (ctgn_set_keypoints_sharded): nothing to sort, and
                                         // the tiles are dealt per XCD like an ordered upload's
-    bool dense_ok = false;              // the ordered positions crowd their home voxels: k_search_dense instead of k_accumulate_rows
-    int dense_mode = -1;                // -1 automatic (by the run count of the order), 0 never, 1 whenever the upload is ordered
     int planned_iters = 0;              // iteration budget of the running solve (num_iters_icp)
     int ordering_mode = -1;             // ctgn_set_ordering: -1 automatic, 0 never, 1 always
     double *d_kp_sorted = nullptr;      // the 7 keypoint arrays in position order (working copy of the GN kernels when ordered)
@@ -370,7 +367,7 @@ ctgn_status sync_level(ctgn_handle h, int li) {
         for (size_t i = 0; i < np; ++i) {
             const PointEdit &e = L.point_edits[i];
             const double *bx = L.bx(e.block);
-            hp[i] = PointEdit{e.block, e.index, bx[e.index], bx[L.blk + e.index], bx[2 * L.blk + e.index]};
+            hp[i] = PointEdit{e.block, e.index, bx[3 * e.index], bx[3 * e.index + 1], bx[3 * e.index + 2]};
         }
         HIPCHK(h, hipMemcpyAsync(h->d_edit, h->h_edit, bytes, hipMemcpyHostToDevice, h->stream));
         SlotEdit *ds = static_cast<SlotEdit *>(h->d_edit);
@@ -459,7 +456,6 @@ ctgn_status order_reserve(ctgn_handle h) {
 ctgn_status order_keypoints(ctgn_handle h, const MapView &mv) {
     h->order_stale = false;
     h->order_valid = false;
-    h->dense_ok = false;
     int map_id, nb;
     double res;
     search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
@@ -473,15 +469,6 @@ ctgn_status order_keypoints(ctgn_handle h, const MapView &mv) {
                        h->d_kp_sorted, c);
     HIPCHK(h, hipGetLastError());
     h->order_valid = true;
-    // Which search kernel? k_search_dense (ctgn_dense.hpp) shares one probe + one scalar-fed candidate scan among the positions of a
-    // 64-position tile that live in the same home voxel. Measured on B2 (132 k keypoints, 45 per home voxel on average, but a median
-    // of 9): 2.9 runs per tile, every run pays the full two-pass scan of its ~180 candidates whatever its size, ~7.7 k vector
-    // instructions per run against ~10 k per 64 keypoints for the row kernel -> 1.1 ms per launch against 0.10 ms, the tiles of the
-    // sparse far range (64 runs of one keypoint) setting the kernel time. It stays an opt-in (ctgn_set_search_kernel(h, 1) or
-    // CTGN_DENSE=1), parity-tested like the row kernel; automatic mode never selects it. DESIGN.md section 7.
-    static const int env_dense = [] { const char *e = std::getenv("CTGN_DENSE"); return e ? std::atoi(e) : -1; }();
-    const int dm = h->dense_mode >= 0 ? h->dense_mode : env_dense;
-    h->dense_ok = dm > 0;
     return CTGN_OK;
 }
 
@@ -552,17 +539,17 @@ int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
 
 // k_residual_reduce: 256-thread blocks for throughput, 64-thread blocks for small frames (the scattered gathers are bound by the
 // per-CU texture path, so a small frame wants MORE CUs, not fuller ones). Returns the grid = number of per-block partials.
-int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const DebugView &dv, const NbSums &sums) {
+int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const DebugView &dv) {
     static const int env_small = [] { const char *e = std::getenv("CTGN_RES_SMALL"); return e ? std::atoi(e) : -1; }();      // measurement hook
     const bool small = env_small >= 0 ? env_small != 0 : h->n_kp <= 8192;
     if (small) {
         const int grid = std::max(1, std::min((h->n_kp + 63) / 64, h->res_grid_cap));
-        hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate, sums);
+        hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
     }
     const int grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
     hipLaunchKernelGGL(k_residual_reduce<RES_BLOCK>, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
-                       h->ablate, sums);
+                       h->ablate);
     return grid;
 }
 
@@ -600,25 +587,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
     if (search_only && (h->variant == 1 || !rows_ok))
         return fail(h, CTGN_ERR_UNSUPPORTED, "the robust route needs the row kernel: voxel_neighborhood 1 or 2, <= 64 points per voxel");
-    const bool dense = rows_ok && !search_only && h->order_valid && h->dense_ok && (h->variant == 0 || h->variant == 3) && h->n_kp > 0;
-    if (dense) {
-        // home-voxel runs: one wave per 64 consecutive positions, neighbourhood sums handed to the residual kernel by position
-        NbSums sums{reinterpret_cast<double *>(h->d_res), h->d_res + (size_t) h->cap_kp * SEL_STRIDE, (size_t) h->cap_kp};
-        const int ntiles = (h->n_kp + 63) / 64;
-        const int g1 = std::min(((ntiles + 7) / 8) * 8, 1 << 16);
-        if (h->variant == 3 && mv.nb == 1)
-            hipLaunchKernelGGL((k_search_dense<1, true>), dim3(g1), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, sums, first_iter ? 1 : 0,
-                               ntiles, h->debug ? 1 : 0, h->d_prof, h->ablate);
-        else if (mv.nb == 1)
-            hipLaunchKernelGGL((k_search_dense<1, false>), dim3(g1), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, sums, first_iter ? 1 : 0,
-                               ntiles, h->debug ? 1 : 0, nullptr, h->ablate);
-        else
-            hipLaunchKernelGGL((k_search_dense<2, false>), dim3(g1), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, sums, first_iter ? 1 : 0,
-                               ntiles, h->debug ? 1 : 0, nullptr, h->ablate);
-        if (ev) (void) hipEventRecord(ev->stop, h->stream);
-        ev = nullptr;
-        grid = launch_residual(h, mv, kv, dv, sums);
-    } else if (h->variant == 1 || !rows_ok) {
+    if (h->variant == 1 || !rows_ok) {
         const int ntiles = (h->n_kp + LANE_BLOCK - 1) / LANE_BLOCK;
         grid = std::max(1, std::min(ntiles, MAX_PARTIAL_BLOCKS));
         hipLaunchKernelGGL(k_accumulate_lane, dim3(grid), dim3(LANE_BLOCK), lane_kernel_smem(), h->stream, mv, kv,
@@ -641,7 +610,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             ev = nullptr;
             if (search_only) { grid = g1; return; }
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
-            grid = launch_residual(h, mv, kv, dv, NbSums{nullptr, nullptr, 0});
+            grid = launch_residual(h, mv, kv, dv);
         };
         if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();
@@ -2394,7 +2363,7 @@ ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset) {
     NEED_DEVICE(h);
     if (!out) return CTGN_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->d_prof, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));      // [12] (dense: runs) stays on the device
+    HIPCHK(h, hipMemcpy(out, h->d_prof, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(h, hipMemset(h->d_prof, 0, 12 * sizeof(unsigned long long)));
     return CTGN_OK;
 }
@@ -2444,13 +2413,6 @@ ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode) {
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
     if (!h || (mode != -1 && mode != 0)) return CTGN_ERR_INVALID_ARGUMENT;
     h->persist_mode = mode;
-    return CTGN_OK;
-}
-
-ctgn_status ctgn_set_search_kernel(ctgn_handle h, int32_t mode) {
-    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
-    if (mode < -1 || mode > 1) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "search kernel mode must be -1, 0 or 1");
-    h->dense_mode = mode;
     return CTGN_OK;
 }
 

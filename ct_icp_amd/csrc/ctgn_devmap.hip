@@ -80,7 +80,7 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
         block = slots[s].block;
         count = slots[s].count;
     }
-    double *bx = blocks + (size_t) block * 3 * blk, *by = bx + blk, *bz = by + blk;
+    double *bx = blocks + (size_t) block * 3 * blk;              // points of the voxel: x y z | x y z | ... (ctgn_map.hpp)
     unsigned long long added = 0;
     for (size_t j = i; j < n && keys[j] == key; ++j) {
         const uint32_t pi = idx[j];
@@ -91,14 +91,14 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
         } else if ((int) count < blk) {                                      // map.h:275-291
             double sq_min = 1.7976931348623157e308;
             for (uint32_t q = 0; q < count; ++q) {
-                const double dx = bx[q] - px, dy = by[q] - py, dz = bz[q] - pz;
+                const double dx = bx[3 * q] - px, dy = bx[3 * q + 1] - py, dz = bx[3 * q + 2] - pz;
                 const double sq = sq_norm3(dx, dy, dz);
                 if (sq < sq_min) sq_min = sq;
             }
             take = sq_min > min_dist_sq;
         }
         if (take) {
-            bx[count] = px; by[count] = py; bz[count] = pz;
+            bx[3 * count] = px; bx[3 * count + 1] = py; bx[3 * count + 2] = pz;
             ++count;
             ++added;
             inserted[pi] = 1;
@@ -131,7 +131,7 @@ __global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *bloc
             if (sqrt(far2) * (1.0 + 1e-9) < distance) continue;
         }
         const double *bx = blocks + (size_t) s.block * 3 * blk;
-        const double dx = bx[0] - lx, dy = bx[blk] - ly, dz = bx[2 * blk] - lz;
+        const double dx = bx[0] - lx, dy = bx[1] - ly, dz = bx[2] - lz;
         if (sqrt(sq_norm3(dx, dy, dz)) > distance) {
             slots[i] = Slot{KEY_TOMB, 0u, 0u};
             const int t = atomicAdd(&cnt->free_top, 1);
@@ -621,7 +621,7 @@ hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points
         if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
         const double *bx = &blocks[(size_t) s.block * 3 * L.blk];
         for (uint32_t j = 0; j < s.count; ++j, ++k)
-            if (k < cap_points) { out_xyz[3 * k] = bx[j]; out_xyz[3 * k + 1] = bx[L.blk + j]; out_xyz[3 * k + 2] = bx[2 * L.blk + j]; }
+            if (k < cap_points) { out_xyz[3 * k] = bx[3 * j]; out_xyz[3 * k + 1] = bx[3 * j + 1]; out_xyz[3 * k + 2] = bx[3 * j + 2]; }
     }
     return hipSuccess;
 }

@@ -144,6 +144,16 @@ __device__ __forceinline__ uint32_t map_lookup(const MapView &m, int vx, int vy,
     }
 }
 
+// A map point = 24 contiguous bytes (x y z, ctgn_map.hpp), 8-byte aligned: x and y come as ONE 16-byte load, z as an 8-byte one.
+// `base + off` must address the point's x.
+typedef double d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void load_point(const char *base, uint32_t off, double &x, double &y, double &z) {
+    const d2_a8 xy = *reinterpret_cast<const d2_a8 *>(base + off);
+    x = xy.x; y = xy.y;
+    z = *reinterpret_cast<const double *>(base + off + 16u);
+}
+constexpr uint32_t POINT_BYTES = 24u;
+
 // Split lookup for software pipelining: probe_issue starts the first slot load of a voxel, probe_resolve finishes
 // the probe sequence later (the load latency is covered by whatever runs in between).
 struct Probe {
@@ -294,7 +304,7 @@ __device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, doub
                 c_pts += count;
                 const double *bx = m.blocks + (size_t) block * 3 * m.blk;
                 for (uint32_t i = 0; i < count; ++i) {
-                    double dx = bx[i] - p.x, dy = bx[m.blk + i] - p.y, dz = bx[2 * m.blk + i] - p.z;
+                    double dx = bx[3 * i] - p.x, dy = bx[3 * i + 1] - p.y, dz = bx[3 * i + 2] - p.z;
                     double d2 = sq_norm3(dx, dy, dz);
                     if (d2 > m.r2thr) continue;                       // map.h:491-493: sqrt(d2) > radius
                     const HeapItem it{__dsqrt_rn(d2), d2, block * (uint32_t) m.blk + i};
@@ -318,7 +328,7 @@ __device__ __forceinline__ int lane_search(const MapView &m, Vec3 p, int k, doub
 __device__ __forceinline__ Vec3 map_point(const MapView &m, uint32_t id) {
     uint32_t block = id / (uint32_t) m.blk, i = id - block * (uint32_t) m.blk;
     const double *bx = m.blocks + (size_t) block * 3 * m.blk;
-    return {bx[i], bx[m.blk + i], bx[2 * m.blk + i]};
+    return {bx[3 * i], bx[3 * i + 1], bx[3 * i + 2]};
 }
 
 __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpView kp, const GnState *st, GnParams prm,
@@ -691,7 +701,7 @@ __device__ __forceinline__ int replay_reference_queue(const MapView &m, Vec3 q, 
     if (!(sweep_in_short_range(kx, m.nb) && sweep_in_short_range(ky, m.nb) && sweep_in_short_range(kz, m.nb))) return 0;
     auto ld = [&](int i) { return HeapItem{T.d[i], T.s[i], T.v[i]}; };
     auto st = [&](int i, const HeapItem &it) { T.d[i] = it.d; T.s[i] = it.s; T.v[i] = it.v; };
-    const uint32_t blk8 = (uint32_t) m.blk * 8u, stride3 = 3u * blk8;
+    const uint32_t stride3 = 3u * (uint32_t) m.blk * 8u;
     int n = 0;
     for (int vx = kx - m.nb; vx <= kx + m.nb; ++vx)
         for (int vy = ky - m.nb; vy <= ky + m.nb; ++vy)
@@ -701,10 +711,10 @@ __device__ __forceinline__ int replay_reference_queue(const MapView &m, Vec3 q, 
                 const uint32_t count = bc & 127u, base = (bc >> 7) * stride3;
                 const double *bx = m.blocks + (size_t) (bc >> 7) * 3 * m.blk;
                 for (uint32_t i = 0; i < count; ++i) {
-                    const double dx = bx[i] - q.x, dy = bx[m.blk + i] - q.y, dz = bx[2 * m.blk + i] - q.z;
+                    const double dx = bx[3 * i] - q.x, dy = bx[3 * i + 1] - q.y, dz = bx[3 * i + 2] - q.z;
                     const double d2 = sq_norm3(dx, dy, dz);
                     if (d2 > m.r2thr) continue;                        // map.h:491-493
-                    const HeapItem it{__dsqrt_rn(d2), d2, base + i * 8u};
+                    const HeapItem it{__dsqrt_rn(d2), d2, base + i * POINT_BYTES};
                     if (n == k) {                                      // map.h:494-500
                         if (it.d < T.d[0]) { heap_pop(ld, st, n); heap_push(ld, st, n, it); }
                     } else {
@@ -767,8 +777,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     const int k = prm.max_nb;
     const int blk = map.blk;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
-    const uint32_t blk8 = (uint32_t) blk * 8u, stride3 = 3u * blk8;
-    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;      // uniform bases: scalar-base + 32-bit lane offset loads
+    const uint32_t stride3 = 3u * (uint32_t) blk * 8u;                     // bytes per block; uniform base + 32-bit lane offset loads
 
     unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds, 10: hash probes issued, 11: map points streamed
     unsigned long long tprev = 0;
@@ -911,7 +920,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         const unsigned long long hb = __ballot(has);
                         if (!hb) break;
                         if (has) SH.chunk[nchunk + __popcll(hb & ((1ull << lane) - 1ull))] =
-                                make_uint2((bc >> 7) * stride3 + 128u * hh,
+                                make_uint2((bc >> 7) * stride3 + 16u * POINT_BYTES * hh,
                                            ((((uint32_t) sv << 6) | (16u * hh)) << 15) | ((uint32_t) (pre + 16 * hh) << 5) | (uint32_t) min(left, 16));
                         nchunk += __popcll(hb);
                     }
@@ -955,10 +964,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     o.vis = SH.vis[cc];
                     // the candidate's byte offset from its visit index: block of its sweep voxel + slot (no offset table in LDS: the
                     // 3.4 KB it took per wave are what kept the block under the CU's LDS at three blocks)
-                    const uint32_t off = o.valid ? (SH.occ[o.vis >> 6] >> 7) * stride3 + (o.vis & 63u) * 8u : 0u;   // masked lanes read the start of the block storage
-                    o.x = *reinterpret_cast<const double *>(pbase + off);
-                    o.y = *reinterpret_cast<const double *>(pbase_y + off);
-                    o.z = *reinterpret_cast<const double *>(pbase_z + off);
+                    const uint32_t off = o.valid ? (SH.occ[o.vis >> 6] >> 7) * stride3 + (o.vis & 63u) * POINT_BYTES : 0u;   // masked lanes read the start of the block storage
+                    load_point(pbase, off, o.x, o.y, o.z);
                 };
                 auto test = [&](const Cand &cnd) {
                     if (PROF) pc[11] += 4ull * (unsigned long long) __popcll(__ballot(cnd.valid));   // per keypoint, as the row path counts
@@ -1064,7 +1071,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     if (!hb) break;
                     const uint32_t hm = row_bits(hb, row);
                     if (has) RP.chunk[nchunk + __popc(hm & lt_mask)] =
-                            make_uint2(off_mine + 128u * hh, ((((uint32_t) cur_v << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
+                            make_uint2(off_mine + 16u * POINT_BYTES * hh, ((((uint32_t) cur_v << 6) | (16u * hh)) << 8) | (uint32_t) min(left, 16));
                     nchunk += __popc(hm);
                 }
                 CTGN_TICK(1)
@@ -1075,10 +1082,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     uint2 ch = RP.chunk[c & 63];
                     if (c >= nchunk) ch = make_uint2(0u, 0u);
                     o.valid = (uint32_t) sub < (ch.y & 0xffu);
-                    const uint32_t off = ch.x + (o.valid ? (uint32_t) sub * 8u : 0u);          // legal address either way
-                    o.x = *reinterpret_cast<const double *>(pbase + off);
-                    o.y = *reinterpret_cast<const double *>(pbase_y + off);
-                    o.z = *reinterpret_cast<const double *>(pbase_z + off);
+                    const uint32_t off = ch.x + (o.valid ? (uint32_t) sub * POINT_BYTES : 0u);          // legal address either way
+                    load_point(pbase, off, o.x, o.y, o.z);                                              // x, y: one 16-byte load; z: one 8-byte load
                     o.vis = (ch.y >> 8) + (uint32_t) sub;
                 };
                 auto test = [&](const Cand &cnd) {
@@ -1165,7 +1170,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         if (e < n && row_needed) {
                             const uint32_t vis = R.vis[e];
                             const uint32_t bc = occ_tab[vis >> 6];
-                            o[n - e] = (bc >> 7) * stride3 + (vis & 63u) * 8u;      // slot 1 = farthest kept ... slot n = nearest
+                            o[n - e] = (bc >> 7) * stride3 + (vis & 63u) * POINT_BYTES;      // slot 1 = farthest kept ... slot n = nearest
                         }
                     }
                 }
@@ -1228,13 +1233,6 @@ __host__ __device__ constexpr size_t rows_kernel_smem() {
 // Splitting it off keeps the neighbour-search kernel free of the eigen-solver's registers and runs this part with
 // all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
 // ================================================================================================
-// neighbourhood sums handed over by k_search_dense (ctgn_dense.hpp), indexed by POSITION
-struct NbSums {
-    double *v;                    // [12][stride]: S.x S.y S.z | SS.xx xy xz yy yz zz | q.x q.y q.z
-    uint32_t *cnt;                // [n] neighbour count
-    size_t stride;
-};
-
 constexpr int RES_BLOCK = 256;
 constexpr int GG = 8;                // neighbours gathered per group: 3 x GG independent loads in flight per lane
 
@@ -1243,11 +1241,8 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // One wave, one keypoint per lane (position my_pos): neighbour set -> sums -> normal, gates, residual, u -> the wave's 13 x 13 product
 // U^T U added to accm (FP64 MFMA, fixed order). `rec` is this wave's 64 x 13 LDS staging area.
 __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
-                                              int ablate, const NbSums &sums, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave,
-                                              TieScratch &tie) {
+                                              int ablate, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave, TieScratch &tie) {
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
-    const uint32_t blk8 = (uint32_t) map.blk * 8u;
-    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
         // position -> keypoint: with kp.order the lanes of a wave take keypoints of neighbouring voxels, so their gathers share
         // cache lines (the sums then run in position order: still fixed, a different rounding than index order)
         const int my_kp = (kp.order && my_pos < kp.n) ? (int) kp.order[my_pos] : my_pos;
@@ -1258,18 +1253,6 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             bool fetch_rec;
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
-            if (sums.v) {
-                // k_search_dense left the neighbour count and, for a keypoint the gates can keep, the finished sums (by position)
-                res_n = min((int) sums.cnt[my_pos], KMAX);
-                fetch_rec = (res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr;
-                if (fetch_rec) {
-                    const double *sv = sums.v + my_pos;
-                    const size_t ss = sums.stride;
-                    res_S = Vec3{sv[0], sv[ss], sv[2 * ss]};
-                    res_SS = Sym3{sv[3 * ss], sv[4 * ss], sv[5 * ss], sv[6 * ss], sv[7 * ss], sv[8 * ss]};
-                    res_q = Vec3{sv[9 * ss], sv[10 * ss], sv[11 * ss]};
-                }
-            } else {
             // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
             // record in nine independent 16-byte loads
             const uint32_t cnt_raw = kp.cnt[my_kp];
@@ -1301,9 +1284,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
 #pragma unroll
                     for (int q = 0; q < GG; ++q) {
                         const uint32_t off = (GG * g + q < gat_n) ? rec32[1 + GG * g + q] : 0u;
-                        gx[q] = *reinterpret_cast<const double *>(pbase + off);
-                        gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
-                        gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
+                        load_point(pbase, off, gx[q], gy[q], gz[q]);          // one point = 24 contiguous bytes: two loads, one or two lines
                     }
                     if (g == 0) res_q = Vec3{gx[0], gy[0], gz[0]};      // points[0]: the farthest kept (ct_icp.cpp:791)
 #pragma unroll
@@ -1316,7 +1297,6 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
                         }
                     }
                 }
-            }
             }
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
@@ -1373,7 +1353,7 @@ __device__ __forceinline__ void unpack_wave_sums(int lane, const d4_t &accm, int
 // per-CU texture path — ~1 line per clock — so a 1 k-keypoint frame is spread over 16 CUs instead of 4)
 template <int BLK>
 __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                            double *partials, DebugView dbg, int ablate, NbSums sums) {
+                                                            double *partials, DebugView dbg, int ablate) {
     __shared__ double s_rec[BLK / 64][64 * 13];
     __shared__ double s_comb[BLK / 64][SYS_N];
     __shared__ TieScratch s_tie[BLK / 64];
@@ -1394,7 +1374,7 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
         tile_step = ((int) gridDim.x - x + 7) >> 3;
     }
     for (; tile < tile_end; tile += tile_step)
-        residual_tile(map, kp, st, prm, dbg, ablate, sums, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave, s_tie[wave]);
+        residual_tile(map, kp, st, prm, dbg, ablate, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave, s_tie[wave]);
     unpack_wave_sums(lane, accm, n_used_wave, s_comb[wave]);
     __syncthreads();
     for (int e = tid; e < SYS_N; e += BLK) {
@@ -1770,7 +1750,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 2) void k_gn_persistent(MapView map, KpV
                                            b * ROW_WAVES + wave, ntiles, nblk * ROW_WAVES, [&](int) {
             const int id = W.id[lane];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2
-            residual_tile(map, kv, &P.state, prm, dbg, 0, NbSums{nullptr, nullptr, 0}, id < 0 ? kv.n : id, lane, W.rec, accm, n_used_wave, P.tie[wave]);
+            residual_tile(map, kv, &P.state, prm, dbg, 0, id < 0 ? kv.n : id, lane, W.rec, accm, n_used_wave, P.tie[wave]);
         });
         unpack_wave_sums(lane, accm, n_used_wave, P.comb[wave]);
         __syncthreads();
@@ -1986,7 +1966,7 @@ __global__ void k_scatter_points(double *blocks, int blk, const PointEdit *edits
     if (i < n) {
         PointEdit e = edits[i];
         double *bx = blocks + (size_t) e.block * 3 * blk;
-        bx[e.index] = e.x; bx[blk + e.index] = e.y; bx[2 * blk + e.index] = e.z;
+        bx[3 * e.index] = e.x; bx[3 * e.index + 1] = e.y; bx[3 * e.index + 2] = e.z;
     }
 }
 

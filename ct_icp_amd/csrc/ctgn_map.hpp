@@ -9,9 +9,11 @@
 //   slots  : open-addressing table, capacity 2^p, one 16-byte slot per entry
 //              { u64 key (3 x 21-bit biased voxel coords) ; u32 block ; u32 count }
 //            key == EMPTY terminates a probe, key == TOMB (evicted voxel) does not.
-//   blocks : fixed-capacity point blocks, SoA inside the block:
-//              x[BLK] | y[BLK] | z[BLK]   (BLK = max_num_points of the level), points in insertion order
-//            so a 16-lane group reads one voxel's x (then y, z) as one contiguous 8*BLK-byte run.
+//   blocks : fixed-capacity point blocks of 3 * BLK doubles (BLK = max_num_points of the level), points in insertion order, ARRAY OF
+//            POINTS inside the block since round 3: x0 y0 z0 | x1 y1 z1 | ... A point is 24 contiguous bytes = one or two 64-byte
+//            lines, where the earlier x[BLK] | y[BLK] | z[BLK] planes spread it over three lines 8 * BLK bytes apart: the residual
+//            kernel's 20 gathers per keypoint touch a third of the lines, and a 16-lane row of the search kernel fetches 16 points
+//            with two loads (x, y as 16 bytes + z) instead of three, over the same 384 bytes.
 #pragma once
 
 #include <cmath>
@@ -170,16 +172,16 @@ struct VoxelLevel {
         {   // existing voxel: map.h:275-291
             Slot &s = slots[i];
             if ((int) s.count < blk) {
-                const double *x = bx(s.block), *y = x + blk, *z = y + blk;
+                const double *x = bx(s.block);
                 double sq_min = 1.7976931348623157e308;
                 for (uint32_t k = 0; k < s.count; ++k) {
-                    double dx = x[k] - px, dy = y[k] - py, dz = z[k] - pz;
+                    double dx = x[3 * k] - px, dy = x[3 * k + 1] - py, dz = x[3 * k + 2] - pz;
                     double sq = sq_norm3(dx, dy, dz);
                     if (sq < sq_min) sq_min = sq;
                 }
                 if (sq_min > min_distance * min_distance) {
                     double *wx = bx(s.block);
-                    wx[s.count] = px; wx[blk + s.count] = py; wx[2 * blk + s.count] = pz;
+                    wx[3 * s.count] = px; wx[3 * s.count + 1] = py; wx[3 * s.count + 2] = pz;
                     if (log_edits && !need_full_upload) point_edits.push_back(PointEdit{s.block, s.count, px, py, pz});
                     s.count++;
                     num_points++;
@@ -194,7 +196,7 @@ struct VoxelLevel {
             if (slots[i].key == KEY_TOMB) num_tombs--;
             uint32_t b = alloc_block();
             double *wx = bx(b);
-            wx[0] = px; wx[blk] = py; wx[2 * blk] = pz;
+            wx[0] = px; wx[1] = py; wx[2] = pz;
             slots[i] = Slot{key, b, 1};
             if (log_edits && !need_full_upload) point_edits.push_back(PointEdit{b, 0, px, py, pz});
             log_slot(i);
@@ -217,7 +219,7 @@ struct VoxelLevel {
             Slot &s = slots[i];
             if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
             const double *x = bx(s.block);
-            double dx = x[0] - loc[0], dy = x[blk] - loc[1], dz = x[2 * blk] - loc[2];
+            double dx = x[0] - loc[0], dy = x[1] - loc[1], dz = x[2] - loc[2];
             if (std::sqrt(sq_norm3(dx, dy, dz)) > distance) {
                 num_points -= s.count;
                 num_voxels--;
@@ -236,7 +238,7 @@ struct VoxelLevel {
             if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
             const double *x = bx(s.block);
             for (uint32_t j = 0; j < s.count; ++j, ++k)
-                if (out && k < cap) { out[3 * k] = x[j]; out[3 * k + 1] = x[blk + j]; out[3 * k + 2] = x[2 * blk + j]; }
+                if (out && k < cap) { out[3 * k] = x[3 * j]; out[3 * k + 1] = x[3 * j + 1]; out[3 * k + 2] = x[3 * j + 2]; }
         }
         return k;
     }

@@ -182,8 +182,6 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
     __shared__ TieScratch s_tie[4];
     if (st->done) return;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
-    const uint32_t blk8 = (uint32_t) map.blk * 8u;
-    const char *pbase_y = pbase + blk8, *pbase_z = pbase + 2u * blk8;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < kp.n; k += gridDim.x * blockDim.x) {
         const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) k * SEL_STRIDE);
         uint32_t rec32[SEL_STRIDE];
@@ -207,9 +205,7 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t off = (8 * g + q < n) ? rec32[1 + 8 * g + q] : 0u;
-                    gx[q] = *reinterpret_cast<const double *>(pbase + off);
-                    gy[q] = *reinterpret_cast<const double *>(pbase_y + off);
-                    gz[q] = *reinterpret_cast<const double *>(pbase_z + off);
+                    load_point(pbase, off, gx[q], gy[q], gz[q]);
                 }
                 if (g == 0) q0 = Vec3{gx[0], gy[0], gz[0]};
 #pragma unroll

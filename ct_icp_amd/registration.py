@@ -500,10 +500,6 @@ class GnSolver:
         """-1 automatic (default), 0 never, 1 always: home-voxel ordering of the GN kernels' work (include/ctgn.h)."""
         L.check(self._h, L.lib().ctgn_set_ordering(self._h, int(mode)))
 
-    def set_search_kernel(self, mode: int):
-        """ctgn_set_search_kernel: -1 automatic, 0 row kernel, 1 dense (home-voxel run) kernel for ordered uploads."""
-        L.check(self._h, L.lib().ctgn_set_search_kernel(self._h, int(mode)))
-
     def set_persistent(self, mode: int):
         """ctgn_set_persistent: -1 automatic (small frames run as one persistent launch), 0 never."""
         L.check(self._h, L.lib().ctgn_set_persistent(self._h, int(mode)))

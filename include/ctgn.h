@@ -494,14 +494,6 @@ ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
  * launch — state init, every GN iteration with an in-kernel barrier on one XCD, final re-transform), 0 = never
  * (always the three launches per iteration). Same results up to the (fixed) order of the block sums. */
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode);
-/* Neighbour-search kernel of an ORDERED upload: -1 / 0 = k_accumulate_rows (16 lanes per keypoint; the default), 1 =
- * k_search_dense (ctgn_dense.hpp: 64 keypoints of consecutive sorted positions per wave; the positions that share a home voxel
- * share one probe of the 27 / 125 sweep voxels and one scalar-fed scan of their candidates; k-selection by histogram; the
- * neighbourhood sums go to the residual kernel finished). Same neighbour counts, farthest neighbours and gate decisions either way;
- * the sums are taken in another fixed order (rounding-level). Experimental and opt-in: on the B2 sweep it is an order of magnitude
- * SLOWER than the row kernel (every home-voxel run of a tile pays a full candidate scan), so automatic mode
- * never selects it. Unordered uploads always use the row kernel. Takes effect at the next ctgn_set_keypoints. */
-ctgn_status ctgn_set_search_kernel(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel

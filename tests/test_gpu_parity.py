@@ -1047,12 +1047,12 @@ def test_config_a_reference_scene_gpu_vs_oracle(config_a_case):
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE sizes vs the oracle
-@pytest.mark.parametrize("search_kernel", ["rows", "rows_ordered", "dense"])
+@pytest.mark.parametrize("search_kernel", ["rows", "rows_ordered"])
 def test_full_size_b2_sweep_matches_oracle(config_b_full, search_kernel):
     """BASELINE.json configs[1] at its full size (the workload bench.py times): every return of the 64-beam sweep (~132 k
     keypoints) against the oracle running OpenMP over keypoints — one accumulation: neighbour counts, farthest neighbours and
     gate decisions identical, packed system <= 1e-10 relative; five iterations: pose <= 1e-7 (stated bar 1e-4). For the row
-    kernel in caller order, in home-voxel order, and for the dense (home-voxel run) kernel."""
+    kernel in caller order and in home-voxel order."""
     import os
     gm, sc = config_b_full
     om = _B2_ORACLE_MAP["om"]
@@ -1064,7 +1064,6 @@ def test_full_size_b2_sweep_matches_oracle(config_b_full, search_kernel):
     o1 = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
     s = cia.GnSolver(gm)
     s.set_ordering(0 if search_kernel == "rows" else 1)
-    s.set_search_kernel(1 if search_kernel == "dense" else 0)
     s.set_debug(True)
     s.set_keypoints(sc.raw, world0, sc.t)
     pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o1)
@@ -1096,47 +1095,14 @@ def test_full_size_b2_sweep_matches_oracle(config_b_full, search_kernel):
     assert np.abs(s.world_points() - world_o).max() < 1e-7
 
 
-def test_dense_search_kernel_small_and_sparse_inputs(box_case, nclt_case):
-    """k_search_dense forced on inputs it is not meant for (few keypoints, one or two per home voxel; the 125-voxel sweep; fewer than k
-    neighbours; min_number_neighbors < k): same neighbour counts, farthest neighbours, gate decisions and poses as the oracle."""
-    for case, frames, voxel, kw in ((box_case, 5, 0.3, {}), (nclt_case, 8, 0.8, dict(min_number_neighbors=10))):
-        om, gm = build_maps(case, frames, with_gpu=True)
-        sc, raw, t, pose0, world0 = _keypoints(case, frames, voxel)
-        o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0, **kw)
-        s = cia.GnSolver(gm)
-        s.set_ordering(1)
-        s.set_search_kernel(1)
-        s.set_debug(True)
-        s.set_keypoints(raw, world0, t)
-        pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
-        dbg = s.get_debug()
-        A, b, n_used = s.get_system()
-        Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
-        assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
-        has = info["n_neighbors"] >= max(o.min_number_neighbors, 5)
-        assert has.sum() > 300
-        assert np.array_equal(dbg["farthest"][has], info["farthest"][has]) and np.array_equal(dbg["used"], info["used"])
-        assert n_used == no
-        assert np.abs(A - Ao).max() < 1e-10 * np.abs(Ao).max()
-        o = _opts(num_iters_icp=6, threshold_orientation_norm=1e-5, **kw)
-        s.set_debug(False)
-        s.set_keypoints(raw, world0, t)
-        pose6, summ6, _ = s.solve(pose0, sc.t_begin_end, o)
-        pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
-        assert summ6.num_iters == so.num_iters and summ6.num_residuals_used == so.num_residuals_used
-        tr, rot = se3.pose_error(pose6, pose_o)
-        assert tr < 1e-7 and rot < 1e-7
-
-
-@pytest.mark.parametrize("mode", ["rows", "rows_plain_rank", "lane", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "rows_plain_rank", "lane"])
 def test_exact_distance_ties_on_a_lattice_map(mode):
     """map.h:491-500 keeps candidates in a std::priority_queue keyed by the distance only: which of two EQUAL distances survives, and in
     which order equal ones are drained, is decided by libstdc++'s heap layout. Round 3: the product reproduces that. The lane kernel and
     the batched RadiusSearch ARE the reference's queue (heap restated move for move); the row kernel detects (near-)tied candidates in its
     exact rank and replays the reference's queue for that keypoint. On a lattice — dozens of candidates at exactly equal distances around
     every query — neighbour lists, farthest neighbours, gate decisions and normals must equal the oracle's heap_mode 0 (= the reference:
-    tests/test_oracle_vs_ref.py pins that bit for bit) and, where oracle/_ref is built, the reference's own RadiusSearch. The experimental
-    dense kernel keeps the total order (d2, visit index) and is held to heap_mode 1."""
+    tests/test_oracle_vs_ref.py pins that bit for bit) and, where oracle/_ref is built, the reference's own RadiusSearch."""
     g = np.arange(-8, 9) * 0.25
     lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
     lattice = lattice[np.random.default_rng(5).permutation(len(lattice))]
@@ -1171,15 +1137,12 @@ def test_exact_distance_ties_on_a_lattice_map(mode):
     tt = np.linspace(0.0, 1.0, n)
     o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
     s = cia.GnSolver(gm)
-    s.set_ordering(1 if mode == "dense" else 0)
-    s.set_search_kernel(1 if mode == "dense" else 0)
-    s.set_variant({"rows": 0, "rows_plain_rank": 2, "lane": 1, "dense": 0}[mode])
+    s.set_variant({"rows": 0, "rows_plain_rank": 2, "lane": 1}[mode])
     s.set_debug(True)
     s.set_keypoints(qs, qs, tt)
     s.solve(pose, (0.0, 1.0), o)
     dbg = s.get_debug()
-    heap_mode = 1 if mode == "dense" else 0
-    Ao, bo, no, info = orc.gn_accumulate(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o), heap_mode=heap_mode, debug=True)
+    Ao, bo, no, info = orc.gn_accumulate(om, qs, qs, tt, pose, (0.0, 1.0), _oopts(o), heap_mode=0, debug=True)
     assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"]) and (info["n_neighbors"] == 20).all()
     assert np.array_equal(dbg["farthest"], info["farthest"])
     assert np.array_equal(dbg["used"], info["used"])
@@ -1217,7 +1180,7 @@ def test_exact_distance_ties_on_a_lattice_map(mode):
         assert summ.num_residuals_used == so.num_residuals_used and np.abs(pose_g - pose_o).max() < 1e-9
 
 
-@pytest.mark.parametrize("mode", ["rows", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "rows_ordered"])
 def test_km_scale_world_coordinates(street_case, mode):
     """SURVEY section 7 'Precision': the same scene 5 km from the origin (absolute FP64 coordinates, as the reference stores them).
     Discrete results stay identical to the oracle; the covariance C = SS / n - mu mu^T loses ~|p|^2 / sigma^2 * eps of relative
@@ -1236,8 +1199,7 @@ def test_km_scale_world_coordinates(street_case, mode):
     world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
     o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0)
     s = cia.GnSolver(gm)
-    s.set_ordering(1 if mode == "dense" else 0)
-    s.set_search_kernel(1 if mode == "dense" else 0)
+    s.set_ordering(1 if mode == "rows_ordered" else 0)
     s.set_debug(True)
     s.set_keypoints(raw, world0, t)
     s.solve(pose0, sc.t_begin_end, o)
@@ -1259,7 +1221,7 @@ def test_km_scale_world_coordinates(street_case, mode):
     assert tr < 1e-6 and rot < 1e-6, (tr, rot)
 
 
-@pytest.mark.parametrize("mode", ["rows", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "rows_ordered"])
 def test_k32_neighbours_and_64_point_voxels(box_case, mode):
     """The kernels' limits: max_number_neighbors = 32 (CTGN_MAX_NEIGHBORS) and max_num_points = 64 per voxel."""
     case = dict(box_case, resolutions=[(0.5, 0.02, 64)])
@@ -1268,8 +1230,7 @@ def test_k32_neighbours_and_64_point_voxels(box_case, mode):
     for k, min_nb in ((32, 32), (32, 12), (7, 5)):
         o = _opts(num_iters_icp=1, threshold_orientation_norm=0.0, max_number_neighbors=k, min_number_neighbors=min_nb)
         s = cia.GnSolver(gm)
-        s.set_ordering(1 if mode == "dense" else 0)
-        s.set_search_kernel(1 if mode == "dense" else 0)
+        s.set_ordering(1 if mode == "rows_ordered" else 0)
         s.set_debug(True)
         s.set_keypoints(raw, world0, t)
         pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
