@@ -86,6 +86,7 @@ struct ctgn_context {
     // undistortion staging (ctgn_transform_points): 7 x tp_cap doubles on the device, 4 x tp_cap pinned
     double *d_tp = nullptr, *h_tp = nullptr;
     size_t tp_cap = 0;
+    std::vector<hipEvent_t> tp_events;  // one per 32 k-point chunk of a host-view ctgn_transform_points (its result has arrived)
 
     // solver
     GnState *d_state = nullptr;
@@ -869,6 +870,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_kp) hipFree(h->d_kp);
         if (h->d_tp) hipFree(h->d_tp);
         if (h->h_tp) hipHostFree(h->h_tp);
+        for (auto &e : h->tp_events) hipEventDestroy(e);
         if (h->d_res) hipFree(h->d_res);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
@@ -1649,6 +1651,12 @@ ctgn_status ctgn_adaptive_sampling(ctgn_handle h, ctgn_view xyz, size_t n, const
     return CTGN_OK;
 }
 
+static void write_point(void *base, size_t stride, ctgn_dtype dt, size_t i, double x, double y, double z) {
+    char *p = static_cast<char *>(base) + i * stride;
+    if (dt == CTGN_F64) { double *q = reinterpret_cast<double *>(p); q[0] = x; q[1] = y; q[2] = z; }
+    else { float *q = reinterpret_cast<float *>(p); q[0] = (float) x; q[1] = (float) y; q[2] = (float) z; }
+}
+
 ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const double pose[14], const double tbe[2],
                                   void *out_base, size_t out_stride, ctgn_dtype out_dtype) {
     NEED_DEVICE(h);
@@ -1661,8 +1669,8 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         if (h->h_tp) HIPCHK(h, hipHostFree(h->h_tp));
         h->d_tp = nullptr; h->h_tp = nullptr; h->tp_cap = 0;
         const size_t cap = ((n + n / 4 + 1024) + 63) & ~(size_t) 63;
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_tp), (cap * 7 + 16) * sizeof(double)));      // x y z t | out x y z | pose
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_tp), (cap * 4 + 16) * sizeof(double), hipHostMallocDefault));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_tp), (cap * 7 + 32) * sizeof(double)));      // pose | x y z t records | out x y z (device views: planes)
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_tp), (cap * 7 + 32) * sizeof(double), hipHostMallocDefault));
         h->tp_cap = cap;
     }
     // array stride: n rounded up to 64, so that the four input arrays + the pose travel in ONE copy and the three output arrays
@@ -1689,30 +1697,58 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return CTGN_OK;
     }
-    bool in_range = true;
-    for (size_t i = 0; i < n; ++i) {
-        for (int a = 0; a < 3; ++a) h->h_tp[a * c + i] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
-        const double t = read_elem(ts.base, ts.stride_bytes, ts.dtype, i, 0);
-        h->h_tp[3 * c + i] = t;
-        in_range = in_range && (tbe[0] <= t && t <= tbe[1]);
+    // Host views: a pipeline over 32 k-point chunks, as in ctgn_frame_register. The caller's strided records are staged as x y z t records
+    // behind the pose in pinned memory and go up chunk by chunk while the next chunk is being staged; every chunk's kernel writes x y z
+    // records that come straight back into pinned memory; once everything is staged (and every timestamp checked: nothing reaches the
+    // caller's output before that) the chunks are handed to the caller as they arrive. The step moves 56 bytes per point across PCIe
+    // for a few flops: what is left is the two passes of the host over its own buffers.
+    constexpr size_t CHUNK = 32768;
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    while (h->tp_events.size() < nchunks) {
+        hipEvent_t e = nullptr;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->tp_events.push_back(e);
     }
-    if (!in_range) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
-    for (int i = 0; i < 14; ++i) h->h_tp[4 * c + i] = pose[i];
-    HIPCHK(h, hipMemcpyAsync(h->d_tp, h->h_tp, (4 * c + 14) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    double *d_out = h->d_tp + 4 * c + 16;           // the pose sits between the inputs and the outputs
-    const int grid = (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_transform_points, dim3(grid), dim3(256), 0, h->stream, h->d_tp, d_out, (int) n, c, h->d_tp + 4 * c, tbe[0], tbe[1]);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->h_tp, d_out, 3 * c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < n; ++i) {
-        char *p = static_cast<char *>(out_base) + i * out_stride;
-        for (int a = 0; a < 3; ++a) {
-            const double v = h->h_tp[a * c + i];
-            if (out_dtype == CTGN_F64) reinterpret_cast<double *>(p)[a] = v;
-            else reinterpret_cast<float *>(p)[a] = (float) v;
+    double *h_in = h->h_tp, *h_out = h->h_tp + 4 * h->tp_cap + 16;      // pinned: pose | records ... results
+    double *d_in = h->d_tp, *d_out = h->d_tp + 4 * h->tp_cap + 16;
+    for (int i = 0; i < 14; ++i) h_in[i] = pose[i];
+    const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
+    const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
+    bool in_range = true;
+    for (size_t k = 0; k < nchunks; ++k) {
+        const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+        for (size_t j = j0; j < j1; ++j) {
+            double *q = h_in + 16 + 4 * j;
+            if (f64) { const double *p = reinterpret_cast<const double *>(rb + j * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            else { const float *p = reinterpret_cast<const float *>(rb + j * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            const double t = tf64 ? *reinterpret_cast<const double *>(tb_ + j * ts.stride_bytes) : (double) *reinterpret_cast<const float *>(tb_ + j * ts.stride_bytes);
+            q[3] = t;
+            in_range = in_range && (tbe[0] <= t && t <= tbe[1]);
+        }
+        if (!in_range) break;
+        const size_t lo = k == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;                       // the first chunk carries the pose
+        HIPCHK(h, hipMemcpyAsync(d_in + lo, h_in + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_transform_points, dim3(grid_for(j1 - j0)), dim3(256), 0, h->stream, d_in + 16 + 4 * j0, d_out + 3 * j0, (int) (j1 - j0), (size_t) 1,
+                           d_in, tbe[0], tbe[1], (const uint32_t *) nullptr, (size_t) 0, (size_t) 4, 1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(h->tp_events[k], h->stream));
+    }
+    if (!in_range) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+    }
+    char *ob = static_cast<char *>(out_base);
+    for (size_t k = 0; k < nchunks; ++k) {
+        const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+        HIPCHK(h, hipEventSynchronize(h->tp_events[k]));
+        if (out_dtype == CTGN_F64 && out_stride == 3 * sizeof(double)) {
+            std::memcpy(ob + j0 * out_stride, h_out + 3 * j0, 3 * (j1 - j0) * sizeof(double));
+        } else {
+            for (size_t j = j0; j < j1; ++j) write_point(out_base, out_stride, out_dtype, j, h_out[3 * j], h_out[3 * j + 1], h_out[3 * j + 2]);
         }
     }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return CTGN_OK;
 }
 
@@ -1770,11 +1806,6 @@ static ctgn_status frame_reserve(ctgn_handle h, size_t n) {
     return CTGN_OK;
 }
 
-static void write_point(void *base, size_t stride, ctgn_dtype dt, size_t i, double x, double y, double z) {
-    char *p = static_cast<char *>(base) + i * stride;
-    if (dt == CTGN_F64) { double *q = reinterpret_cast<double *>(p); q[0] = x; q[1] = y; q[2] = z; }
-    else { float *q = reinterpret_cast<float *>(p); q[0] = (float) x; q[1] = (float) y; q[2] = (float) z; }
-}
 
 ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
                                 const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,

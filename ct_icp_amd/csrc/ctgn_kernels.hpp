@@ -1854,9 +1854,10 @@ __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st,
 // sel (optional): point i of the output is point sel[i] of the input (the sampled frame of the frame pipeline); out_cap = stride
 // of the output arrays.
 // in_es: coordinate a of input point j is in[j * in_es + a * cap] (x y z t records: in_es 4, cap 1; then out_cap must be given).
+// out_aos: the output is written as x y z records (out[3 i + a]) instead of three planes.
 __global__ __launch_bounds__(256) void k_transform_points(const double *in, double *out, int n, size_t cap, const double *pose,
                                                           double tb, double te, const uint32_t *sel = nullptr, size_t out_cap = 0,
-                                                          size_t in_es = 1) {
+                                                          size_t in_es = 1, int out_aos = 0) {
     if (out_cap == 0) out_cap = cap;
     __shared__ GnState s;
     if (threadIdx.x == 0) {
@@ -1874,7 +1875,8 @@ __global__ __launch_bounds__(256) void k_transform_points(const double *in, doub
         const Vec3 raw{q[0], q[cap], q[2 * cap]};
         const double alpha = alpha_timestamp(q[3 * cap], tb, te);
         const Vec3 p = ct_transform(&s, alpha, raw);
-        out[i] = p.x; out[out_cap + i] = p.y; out[2 * out_cap + i] = p.z;
+        if (out_aos) { out[3 * (size_t) i] = p.x; out[3 * (size_t) i + 1] = p.y; out[3 * (size_t) i + 2] = p.z; }
+        else { out[i] = p.x; out[out_cap + i] = p.y; out[2 * out_cap + i] = p.z; }
     }
 }
 

@@ -25,7 +25,7 @@ namespace ctgn {
 
 constexpr int SORT_SMALL_MAX = 16384;
 constexpr int SORT_SMALL_THREADS = 1024;
-constexpr int SORT_MAX_COLS = 2048;            // per-wave tiles of the large path (columns of the histogram matrix)
+constexpr int SORT_MAX_COLS = 512;             // per-wave tiles of the large path (columns of the histogram matrix): the tile grows with n
 
 inline hipError_t sort_scratch_reserve(SortScratch &S, size_t n) {
     if (S.hist) return hipSuccess;               // fixed size: the tile grows with n so that the columns stay <= SORT_MAX_COLS
@@ -181,24 +181,34 @@ __global__ __launch_bounds__(256) void k_sort_hist(const K *k0, const K *k1, siz
     }
 }
 
-// exclusive scan of hist[256 * cols] in place (digit-major: all columns of digit 0, then digit 1, ...): one block
+// exclusive scan of hist[256 * cols] in place (digit-major: all columns of digit 0, then digit 1, ...): one block, strips of 4096
+// entries — a 16-byte load per thread (coalesced), prefix of the four, wave scan by shuffles, wave totals through LDS, running carry.
+// (`total` is a multiple of 4: 256 digits x cols.)
 __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *hist, int total, int p, const unsigned long long *bits) {
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
     const unsigned long long varying = bits[0] & ~bits[1];
     if (!pass_runs(varying, p)) return;
-    const int tid = threadIdx.x, per = (total + 1023) / 1024, a = tid * per, b = min(total, a + per);
-    uint32_t sum = 0u;
-    for (int i = a; i < b; ++i) sum += hist[i];
-    s_part[tid] = sum;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0u;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele over the 1024 partial sums
-        const uint32_t o = tid >= d ? s_part[tid - d] : 0u;
+    for (int base = 0; base < total; base += 4096) {
+        const int i = base + 4 * tid;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < total) v = *reinterpret_cast<const uint4 *>(hist + i);
+        const uint32_t own = v.x + v.y + v.z + v.w;
+        uint32_t inc = own;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
-        s_part[tid] += o;
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        before += inc - own;                                    // everything in front of this thread's four entries
+        if (i < total) *reinterpret_cast<uint4 *>(hist + i) = make_uint4(before, before + v.x, before + v.x + v.y, before + v.x + v.y + v.z);
+        __syncthreads();
+        if (tid == 1023) s_carry = before + own;
         __syncthreads();
     }
-    uint32_t run = s_part[tid] - sum;
-    for (int i = a; i < b; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
 }
 
 template <typename K>
