@@ -424,6 +424,13 @@ __device__ __forceinline__ double row_sum(double v) {
     v += dpp_f64<0x140>(v);     // row_mirror
     return v;
 }
+__device__ __forceinline__ int row_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ int row_max_i32(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
@@ -621,17 +628,18 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         const uint32_t v0 = R.vis[e0], v1 = R.vis[e1];
         const float k0 = e0 < Ln ? (float) d0 : FINF, k1 = e1 < Ln ? (float) d1 : FINF;
         int lt0 = (k1 < k0) ? 1 : 0, lt1 = (k0 < k1) ? 1 : 0;       // the lane's own pair
-        int le0 = (k1 <= k0) ? 1 : 0, le1 = (k0 <= k1) ? 1 : 0;
         float r0 = k0, r1 = k1;
         for (int step = 0; step < 15; ++step) {
             r0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r0), 0x121, 0xf, 0xf, false));     // row_ror:1
             r1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r1), 0x121, 0xf, 0xf, false));
             lt0 += (r0 < k0) + (r1 < k0);
-            le0 += (r0 <= k0) + (r1 <= k0);
             lt1 += (r0 < k1) + (r1 < k1);
-            le1 += (r0 <= k1) + (r1 <= k1);
         }
-        const bool tie = (k0 < FINF && le0 != lt0) || (k1 < FINF && le1 != lt1);
+        // Ties without a second set of counters: over the Ln real keys the strict ranks add up to Ln (Ln - 1) / 2 iff no two keys are
+        // equal (every tying pair is missing from the sum). Padding keys (+inf) are never smaller than anything, so the real keys' ranks
+        // only count real keys.
+        const int rsum = row_sum_i32((e0 < Ln ? lt0 : 0) + (e1 < Ln ? lt1 : 0));
+        const bool tie = rsum != (Ln * (Ln - 1)) / 2;
         if (!__any(tie)) {
             if (e0 < Ln && lt0 < k) { R.d2[lt0] = d0; R.vis[lt0] = v0; }
             if (e1 < Ln && lt1 < k) { R.d2[lt1] = d1; R.vis[lt1] = v1; }
