@@ -628,13 +628,24 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         const uint32_t v0 = R.vis[e0], v1 = R.vis[e1];
         const float k0 = e0 < Ln ? (float) d0 : FINF, k1 = e1 < Ln ? (float) d1 : FINF;
         int lt0 = (k1 < k0) ? 1 : 0, lt1 = (k0 < k1) ? 1 : 0;       // the lane's own pair
-        float r0 = k0, r1 = k1;
-        for (int step = 0; step < 15; ++step) {
-            r0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r0), 0x121, 0xf, 0xf, false));     // row_ror:1
-            r1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r1), 0x121, 0xf, 0xf, false));
-            lt0 += (r0 < k0) + (r1 < k0);
-            lt1 += (r0 < k1) + (r1 < k1);
-        }
+        int scratch_;
+        // The other 15 lanes' keys are read straight from their registers: the DPP selector row_ror:S on the first source delivers
+        // lane (sub + S) mod 16 of the row — no rotating copies, no moves. The keys are non-negative floats (squared distances, +inf
+        // padding), which order like their bit patterns as unsigned integers, so "other < mine" is the borrow of an unsigned subtract
+        // (VOP2, which takes a DPP source; compares do not on this part) and goes into the rank with one add-with-carry. Hand-placed
+        // (the compiler materialises every rotated key with a v_mov_dpp and pairs compares through v_cndmask): 8 instructions per step
+        // instead of 12. s_nop 1: VALU write of VCC -> VALU read of VCC as carry-in.
+#define CTGN_RANK_CMP(S, OTHER, MINE, RANK)                                                                                       \
+        asm volatile("v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:" #S " row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" \
+                     : "+v"(RANK), "=&v"(scratch_) : "v"(OTHER), "v"(MINE) : "vcc");
+#define CTGN_RANK_STEP(S) CTGN_RANK_CMP(S, u0, u0, lt0) CTGN_RANK_CMP(S, u1, u0, lt0) CTGN_RANK_CMP(S, u0, u1, lt1) CTGN_RANK_CMP(S, u1, u1, lt1)
+        const int u0 = __float_as_int(k0), u1 = __float_as_int(k1);
+        asm volatile("s_nop 4" ::: "memory");       // k0 / k1 were just written by the VALU (and EXEC may have been): DPP reads need the wait states
+        CTGN_RANK_STEP(1) CTGN_RANK_STEP(2) CTGN_RANK_STEP(3) CTGN_RANK_STEP(4) CTGN_RANK_STEP(5) CTGN_RANK_STEP(6) CTGN_RANK_STEP(7)
+        CTGN_RANK_STEP(8) CTGN_RANK_STEP(9) CTGN_RANK_STEP(10) CTGN_RANK_STEP(11) CTGN_RANK_STEP(12) CTGN_RANK_STEP(13) CTGN_RANK_STEP(14)
+        CTGN_RANK_STEP(15)
+#undef CTGN_RANK_STEP
+#undef CTGN_RANK_CMP
         // Ties without a second set of counters: over the Ln real keys the strict ranks add up to Ln (Ln - 1) / 2 iff no two keys are
         // equal (every tying pair is missing from the sum). Padding keys (+inf) are never smaller than anything, so the real keys' ranks
         // only count real keys.
