@@ -104,7 +104,7 @@ struct ctgn_context {
     unsigned int *d_bar = nullptr;
     int persist_slot = 0;
     bool persist_disabled = false;
-    int persist_mode = -1;              // ctgn_set_persistent
+    int persist_mode = 0;               // ctgn_set_persistent: 0 = the three-launch loop (default), 1 = one persistent launch for small frames
     bool world_final_done = false;      // the running solve's last launch already re-transformed the keypoints and mirrored the state
     // state initialisation of a solve is deferred to its first launch (the persistent kernel does it in its prologue)
     bool init_pending = false;
@@ -647,8 +647,9 @@ ctgn_status flush_state_init(ctgn_handle h) {
 // Is this solve one for the persistent kernel? Small frames on the default row kernel, nothing that needs per-launch events, per-position
 // ordering or kernel variants; never after a barrier of it has timed out on this handle.
 bool persistent_ok(ctgn_handle h, const MapView &mv) {
-    static const int env = [] { const char *e = std::getenv("CTGN_PERSISTENT"); return e ? std::atoi(e) : 1; }();
-    if (!env || h->persist_mode == 0 || h->persist_disabled || h->n_kp < 1 || h->n_kp > 4096) return false;
+    static const int env = [] { const char *e = std::getenv("CTGN_PERSISTENT"); return e ? std::atoi(e) : -1; }();      // measurement hook: forces it on / off
+    const int mode = env >= 0 ? env : h->persist_mode;
+    if (mode != 1 || h->persist_disabled || h->n_kp < 1 || h->n_kp > 4096) return false;
     if (h->variant != 0 || h->profiling || h->ablate || h->ordering_mode == 1 || h->order_valid || h->kp_presorted) return false;
     if (!((mv.nb == 1 || mv.nb == 2) && mv.blk <= 64)) return false;
     // every keypoint must get its own row in ONE round on the one XCD (2 blocks of 4 waves per CU, 32 CUs: 1024 keypoints): with a
@@ -2442,7 +2443,7 @@ ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode) {
 }
 
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
-    if (!h || (mode != -1 && mode != 0)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h || (mode != 0 && mode != 1)) return CTGN_ERR_INVALID_ARGUMENT;
     h->persist_mode = mode;
     return CTGN_OK;
 }

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_gs_flags_count(const uint32_t *tfirst, 
         f = (!active || active[i]) && (!tfirst || tfirst[slot_of[i]] == (uint32_t) i);
         flags[i] = f ? 1 : 0;
     }
-    const uint32_t c = (uint32_t) __popcll(__ballot(f));
+    const uint32_t c = (uint32_t) __popcll(ballot64(f));
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gs_compact2(const uint8_t *flag_a, cons
     if (lane == 0) { s_red[0][wave] = pa; s_red[1][wave] = pb; }
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     const bool fa = i < n && flag_a[i], fb = i < n && flag_b[i];
-    const unsigned long long ma = __ballot(fa), mb = __ballot(fb);
+    const unsigned long long ma = ballot64(fa), mb = ballot64(fb);
     if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(ma); s_wave[1][wave] = (uint32_t) __popcll(mb); }
     __syncthreads();
     uint32_t base_a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3], base_b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
         double *my = rec + tid * 13;
         for (int c = 0; c < 12; ++c) my[c] = used ? u[c] : 0.0;
         my[12] = used ? r : 0.0;
-        const unsigned long long ub = __ballot(used);
+        const unsigned long long ub = ballot64(used);
         if ((tid & 63) == 0) wcnt[tid >> 6] = __popcll(ub);
         __syncthreads();
         if (tid < 90) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
         }
         __syncthreads();
     }
-    if (tid < SYS_N) partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = (tid < SYS_USED) ? acc : 0.0;
+    if (tid < SYS_N) partials[(size_t) blockIdx.x * SYS_N + tid] = (tid < SYS_USED) ? acc : 0.0;
 }
 
 inline size_t lane_kernel_smem() {
@@ -595,7 +595,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
             if (cut && e < Ln) atomicAdd(&R.hist[b], 1u);
         }
         const int cum = row_scan_i32((int) R.hist[sub]);
-        const uint32_t reach = row_bits(__ballot(cum >= k), row);
+        const uint32_t reach = row_bits(ballot64(cum >= k), row);
         const int bb = reach ? (__ffs(reach) - 1) : 15;
         // stable in-place compaction of the entries with bin <= bb: step m reads 16 entries, then writes at
         // positions <= the ones it read (LDS operations of a wave execute in order)
@@ -606,7 +606,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
             const uint32_t vv = R.vis[e];
             // (entries a hair above the last kept bin stay too: a near-tie of the k-th best must not be cut away unseen)
             const bool keep = (e < Ln) && (!cut || min(15, (int) (d * (1.0 - 0x1p-40) * scale)) <= bb);
-            const uint32_t km = row_bits(__ballot(keep), row);
+            const uint32_t km = row_bits(ballot64(keep), row);
             if (keep) {
                 const int pos = base + __popc(km & lt_mask);
                 R.d2[pos] = d;
@@ -651,7 +651,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         // only count real keys.
         const int rsum = row_sum_i32((e0 < Ln ? lt0 : 0) + (e1 < Ln ? lt1 : 0));
         const bool tie = rsum != (Ln * (Ln - 1)) / 2;
-        if (!__any(tie)) {
+        if (!any64(tie)) {
             if (e0 < Ln && lt0 < k) { R.d2[lt0] = d0; R.vis[lt0] = v0; }
             if (e1 < Ln && lt1 < k) { R.d2[lt1] = d1; R.vis[lt1] = v1; }
             return Ln < k ? Ln : k;
@@ -697,7 +697,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         const int lim = min(Ln, k + 1);
         const double a0 = R.d2[sub], b0 = R.d2[sub + 1], a1 = R.d2[sub + 16], b1 = R.d2[sub + 17];
         const bool mine = (sub + 1 < lim && b0 - a0 <= b0 * NEAR_TIE_REL) || (sub + 17 < lim && b1 - a1 <= b1 * NEAR_TIE_REL);
-        near_tie = near_tie || row_bits(__ballot(mine), row) != 0u;
+        near_tie = near_tie || row_bits(ballot64(mine), row) != 0u;
     }
     return Ln < k ? Ln : k;
 }
@@ -749,7 +749,7 @@ __device__ __forceinline__ int replay_reference_queue(const MapView &m, Vec3 q, 
 // offsets farthest first). Flagged lanes are replayed one after the other through the wave's TieScratch and their record replaced.
 __device__ __forceinline__ void resolve_ties(const MapView &map, const KpView &kp, int my_kp, bool wanted, uint32_t (&rec32)[SEL_STRIDE],
                                              TieScratch &T, int lane, int k) {
-    unsigned long long todo = __ballot(wanted && (rec32[0] & TIE_FLAG) != 0u);
+    unsigned long long todo = ballot64(wanted && (rec32[0] & TIE_FLAG) != 0u);
     while (todo) {
         const int L = __ffsll((long long) todo) - 1;
         todo &= todo - 1ull;
@@ -895,7 +895,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             bool any_row = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) W.mr[j * 16 + rr] & want) == want;
-            return __ballot(any_row && lane < 27);
+            return ballot64(any_row && lane < 27);
         };
         for (int r = 0; r < ((ablate & 1024) ? 0 : rounds); ++r) {
             const int src = row * 16 + r;
@@ -925,7 +925,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     if (snxt_round != r)
                         snxt = probe_issue(map, ((need >> lane) & 1ull) && !(ablate & 16), kx + sv / 9 - 1, ky + (sv / 3) % 3 - 1, kz + sv % 3 - 1);
                     st_need = need;
-                    if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(snxt.active));
+                    if (PROF) pc[10] += (unsigned long long) __popcll(ballot64(snxt.active));
                     const uint32_t bc = probe_resolve(map, snxt);
                     const int cnt = (int) (bc & 127u);
                     const int inc = row_scan_i32(cnt);                       // inclusive prefix within each DPP row
@@ -936,7 +936,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     for (int hh = 0; hh < 2; ++hh) {
                         const int left = cnt - 16 * hh;
                         const bool has = left > 0;
-                        const unsigned long long hb = __ballot(has);
+                        const unsigned long long hb = ballot64(has);
                         if (!hb) break;
                         if (has) SH.chunk[nchunk + __popcll(hb & ((1ull << lane) - 1ull))] =
                                 make_uint2((bc >> 7) * stride3 + 16u * POINT_BYTES * hh,
@@ -987,7 +987,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     load_point(pbase, off, o.x, o.y, o.z);
                 };
                 auto test = [&](const Cand &cnd) {
-                    if (PROF) pc[11] += 4ull * (unsigned long long) __popcll(__ballot(cnd.valid));   // per keypoint, as the row path counts
+                    if (PROF) pc[11] += 4ull * (unsigned long long) __popcll(ballot64(cnd.valid));   // per keypoint, as the row path counts
                     double d2[4];
                     unsigned long long pm[4];
 #pragma unroll
@@ -996,7 +996,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         d2[j] = sq_norm3(dx, dy, dz);
                         // the stream filter is only an optimisation: a candidate that ties the current k-th best in d2 is
                         // admitted whatever its visit index, and the exact total order (d2, vis) decides in row_select
-                        pm[j] = __ballot(cnd.valid && d2[j] <= Kth[j] && !(ablate & 128));
+                        pm[j] = ballot64(cnd.valid && d2[j] <= Kth[j] && !(ablate & 128));
                     }
                     // a list that cannot take this step's admissions: cut every row back to its k best first, then admit against the
                     // tighter bounds (after the cut a list holds <= k <= 32 entries and a step adds <= 64)
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         for (int j = 0; j < 4; ++j) {
                             L[j] = __builtin_amdgcn_readlane(Ln, 16 * j);
                             Kth[j] = bcast(kth_d2, 16 * j);
-                            pm[j] = __ballot(cnd.valid && d2[j] <= Kth[j]);
+                            pm[j] = ballot64(cnd.valid && d2[j] <= Kth[j]);
                         }
                         CTGN_TICK(3)
                     }
@@ -1063,9 +1063,9 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                                           fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
-                if (PROF) pc[10] += (unsigned long long) __popcll(__ballot(cur.active));
+                if (PROF) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
                 // a batch none of whose voxels any row can reach (most batches of a bounded 125-voxel sweep): nothing to resolve or stream
-                if (__any(cur.active)) {
+                if (any64(cur.active)) {
                 const uint32_t bc = probe_resolve(map, cur);
                 if (bc) RP.occ[cur_v] = bc;
                 // Once the row holds k candidates and knows its k-th best distance, a voxel that lies entirely farther away cannot
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 for (int hh = 0; hh < 4; ++hh) {
                     const int left = cnt_mine - 16 * hh;
                     const bool has = left > 0;
-                    const unsigned long long hb = __ballot(has);
+                    const unsigned long long hb = ballot64(has);
                     if (!hb) break;
                     const uint32_t hm = row_bits(hb, row);
                     if (has) RP.chunk[nchunk + __popc(hm & lt_mask)] =
@@ -1106,11 +1106,11 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     o.vis = (ch.y >> 8) + (uint32_t) sub;
                 };
                 auto test = [&](const Cand &cnd) {
-                    if (PROF) pc[11] += (unsigned long long) __popcll(__ballot(cnd.valid));
+                    if (PROF) pc[11] += (unsigned long long) __popcll(ballot64(cnd.valid));
                     const double dx = cnd.x - qx, dy = cnd.y - qy, dz = cnd.z - qz;
                     const double d2 = sq_norm3(dx, dy, dz);
                     const bool pass = cnd.valid && d2 <= kth_d2 && !(ablate & 128);
-                    const uint32_t pm = row_bits(__ballot(pass), row);
+                    const uint32_t pm = row_bits(ballot64(pass), row);
                     if (pass) {
                         const int pos = Ln + __popc(pm & lt_mask);
                         R.d2[pos] = d2;
@@ -1120,12 +1120,12 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 };
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
                 fetch(0, ca);
-                for (int c = 0; !(ablate & 1) && __any(c < nchunk); c += 2) {
+                for (int c = 0; !(ablate & 1) && any64(c < nchunk); c += 2) {
                     fetch(c + 1, cb);
                     test(ca);
                     fetch(c + 2, ca);
                     test(cb);
-                    if (__any(Ln > LCAP - 32)) {
+                    if (any64(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
                         Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
-                if (NB == 2 && it + 1 < VIT && __any(Ln >= k && !(kth_d2 < map.r2thr))) {
+                if (NB == 2 && it + 1 < VIT && any64(Ln >= k && !(kth_d2 < map.r2thr))) {
                     Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
                     if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
                     CTGN_TICK(3)
@@ -1165,7 +1165,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             // candidates was never pruned (Ln < k throughout), so Ln already is its exact neighbour count, and the residual kernel
             // drops it on that count alone: when no row of the wave can be used, skip the selection and hand over counts only.
             const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr;
-            if (!(ablate & 2) && __any(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
+            if (!(ablate & 2) && any64(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
             const int n = (ablate & 2) ? min(Ln, k) : Ln;
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST
@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
         // A[i = l & 15][k] and B[k][j = l & 15] (one LDS read per lane and step — the lane-per-entry loop this replaces read
         // four doubles per lane and keypoint and was bound by LDS bandwidth). Accumulation order is fixed: deterministic.
         double *my = rec + lane * 13;
-        const unsigned long long used_lanes = __ballot(used);
+        const unsigned long long used_lanes = ballot64(used);
         n_used_wave += __popcll(used_lanes);
         if (used_lanes == 0ull) return;              // a wave of dropped keypoints adds exact zeros: nothing to stage, nothing to multiply
 #pragma unroll
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
     for (int e = tid; e < SYS_N; e += BLK) {
         double s = 0.0;
         for (int w = 0; w < BLK / 64; ++w) s += s_comb[w][e];
-        partials[(size_t) e * MAX_PARTIAL_BLOCKS + blockIdx.x] = s;
+        partials[(size_t) blockIdx.x * SYS_N + e] = s;          // block-major: one contiguous 768-byte record per block (see reduce_partials)
     }
 }
 
@@ -1426,41 +1426,38 @@ struct SolveScratch {                 // LDS of the 12 x 12 solve (wave 0)
     int perm[12];
 };
 
-// Sum of the per-block partials of the packed system, 16 waves: wave w owns entries w, w+16, ..., w+80 — six independent
-// lane-strided sums (a lane takes blocks 2 lane and 2 lane + 1 of each 128-block span; 16-byte loads, all in flight together), then
-// six fixed shuffle trees. `load2(entry, b)` returns the partials of blocks b and b + 1 (b even). Deterministic.
-// NW waves share the 96 entries (wave w owns w, w + NW, ...); the lane -> block assignment and the shuffle tree of an entry do not
-// depend on NW, so every NW gives the same sums bit for bit.
-template <int NW, int RU, typename Load2>
-__device__ __forceinline__ void reduce_partials(Load2 load2, int nblocks, int wave, int lane, double *sys_global, double *s_sys) {
-    constexpr int EPW = SYS_N / NW;
-    static_assert(SYS_N % NW == 0, "entries split evenly over the waves");
-    double acc[EPW];
+// Sum of the per-block partials of the packed system. Layout since round 3: BLOCK-major, partials[block][96] — a block's record is 768
+// contiguous bytes, written with two coalesced wave stores and spread over the L2 channels. (Rounds 1-2 stored entry-major,
+// [96][2048]: the 96 columns lie 16 KB apart, which is one and the same L2 channel set for every one of them — each block's 96
+// eight-byte writes and every reader's loads queued there; found while timing the persistent kernel's exchange)
+// THREADS / 96 groups of 96 threads: thread (g, e) adds entry e of blocks g, g + G, g + 2G, ... in that order (coalesced across e,
+// eight loads in flight), the groups' sums are added in group order. Fixed order: deterministic. s_tmp: G x 96 doubles of LDS.
+template <int THREADS>
+__device__ __forceinline__ void reduce_partials(const double *partials, int nblocks, int tid, double *sys_global, double *s_sys, double *s_tmp) {
+    constexpr int G = THREADS / SYS_N;
+    static_assert(G >= 1, "at least one group of 96 threads");
+    if (tid < G * SYS_N) {
+        const int g = tid / SYS_N, e = tid - g * SYS_N;
+        const double *col = partials + e;
+        double sum = 0.0;
+        int b = g;
+        for (; b + 7 * G < nblocks; b += 8 * G) {
+            double v[8];
 #pragma unroll
-    for (int q = 0; q < EPW; ++q) acc[q] = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += 128 * RU) {
-        double2 v[RU][EPW];
+            for (int q = 0; q < 8; ++q) v[q] = col[(size_t) (b + q * G) * SYS_N];
 #pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int b = b0 + 128 * u + 2 * lane;
-            const int bb = b < nblocks ? b : 0;
-#pragma unroll
-            for (int q = 0; q < EPW; ++q) v[u][q] = load2(wave + NW * q, bb);
+            for (int q = 0; q < 8; ++q) sum += v[q];
         }
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int b = b0 + 128 * u + 2 * lane;
-#pragma unroll
-            for (int q = 0; q < EPW; ++q) {
-                acc[q] += (b < nblocks) ? v[u][q].x : 0.0;
-                acc[q] += (b + 1 < nblocks) ? v[u][q].y : 0.0;
-            }
-        }
+        for (; b < nblocks; b += G) sum += col[(size_t) b * SYS_N];
+        s_tmp[g * SYS_N + e] = sum;
     }
+    __syncthreads();
+    if (tid < SYS_N) {
+        double sum = 0.0;
 #pragma unroll
-    for (int q = 0; q < EPW; ++q) {
-        const double s = wave_sum_fixed(acc[q]);
-        if (lane == 0) { sys_global[wave + NW * q] = s; s_sys[wave + NW * q] = s; }
+        for (int g = 0; g < G; ++g) sum += s_tmp[g * SYS_N + tid];
+        sys_global[tid] = sum;
+        s_sys[tid] = sum;
     }
 }
 
@@ -1655,14 +1652,13 @@ template <int BLKS>
 __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
                                                        GnParams prm, int mode, int min_used) {
     __shared__ SolveScratch S;
+    __shared__ double s_tmp[(BLKS / SYS_N) * SYS_N];
     if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tc0 = __builtin_readcyclecounter();
     const unsigned long long wall0 = wall_clock64();
     if (mode != 2) {
-        reduce_partials<BLKS / 64, (BLKS == SOLVE_BLOCK ? 3 : 1)>(
-                        [&](int e, int b) { return *reinterpret_cast<const double2 *>(partials + (size_t) e * MAX_PARTIAL_BLOCKS + b); },
-                        nblocks, wave, lane, sys, S.sys);
+        reduce_partials<BLKS>(partials, nblocks, tid, sys, S.sys, s_tmp);
     } else {
         if (tid < SYS_N) S.sys[tid] = sys[tid];
     }

@@ -13,6 +13,12 @@
 
 #define CTGN_HD __host__ __device__ __forceinline__
 
+// Wave votes on a bool. HIP's __ballot / __any take an int: the predicate — already a lane mask in a scalar register pair — is first
+// turned into 0 / 1 per lane (v_cndmask) and compared against zero again (v_cmp_ne); two vector instructions per vote that the builtin
+// on a bool does not need. The search kernel votes several times per 16-candidate step.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 namespace ctgn {
 
 struct Vec3 {

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
     if (tid < SYS_N) {
         double t = 0.0;
         for (int w = 0; w < EVAL_BLOCK / 64; ++w) t += s_comb[w][tid];
-        partials[(size_t) tid * MAX_PARTIAL_BLOCKS + blockIdx.x] = t;
+        partials[(size_t) blockIdx.x * SYS_N + tid] = t;            // block-major (reduce_partials, ctgn_kernels.hpp)
     }
 }
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
     if (have_eval) {
         for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
             double acc = 0.0;
-            for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) e * MAX_PARTIAL_BLOCKS + b];
+            for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) b * SYS_N + e];
             acc = wave_sum_fixed(acc);
             if (lane == 0) s_sys[e] = acc;
         }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
 #pragma unroll
         for (int j = 0; j < 12; ++j) row += hs[j] * CTGN_BCAST(y, j);
         const double model_cost_change = -wave_sum_fixed(lane < 12 ? y * (gs_i + 0.5 * row) : 0.0);   // -(J y).(r + J y / 2)
-        const bool finite_all = __ballot(lane < 12 && !isfinite(y)) == 0ull;
+        const bool finite_all = ballot64(lane < 12 && !isfinite(y)) == 0ull;
         ok = ok && finite_all && model_cost_change > 0.0;
         if (lane < 12) s_delta[lane] = y * sc_i;
         RWSYNC();

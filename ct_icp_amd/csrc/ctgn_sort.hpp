@@ -45,11 +45,11 @@ inline void sort_scratch_free(SortScratch &S) {
 
 // lanes of the wave whose (valid) element has the same 8-bit digit as this lane's
 __device__ __forceinline__ unsigned long long digit_peers(uint32_t d, bool valid) {
-    unsigned long long peers = __ballot(valid);
+    unsigned long long peers = ballot64(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
+        const unsigned long long m = ballot64(bit);
         peers &= bit ? m : ~m;
     }
     return valid ? peers : 0ull;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_flag_counts(const uint8_t *flags, size_
     __shared__ uint32_t s_cnt[4];
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     const bool f = i < n && flags[i];
-    const uint32_t c = (uint32_t) __popcll(__ballot(f));
+    const uint32_t c = (uint32_t) __popcll(ballot64(f));
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_compact1(const uint8_t *flags, const ui
     if (lane == 0) s_red[wave] = pa;
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     const bool f = i < n && flags[i];
-    const unsigned long long m = __ballot(f);
+    const unsigned long long m = ballot64(f);
     if (lane == 0) s_wave[wave] = (uint32_t) __popcll(m);
     __syncthreads();
     uint32_t base = s_red[0] + s_red[1] + s_red[2] + s_red[3];

@@ -501,7 +501,7 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_set_ordering(self._h, int(mode)))
 
     def set_persistent(self, mode: int):
-        """ctgn_set_persistent: -1 automatic (small frames run as one persistent launch), 0 never."""
+        """ctgn_set_persistent: 1 = small frames (<= 1 024 keypoints) run as one persistent launch, 0 (default) = the three-launch loop."""
         L.check(self._h, L.lib().ctgn_set_persistent(self._h, int(mode)))
 
     def set_variant(self, v: int):

@@ -490,9 +490,11 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * costs at 132 k keypoints (num_iters_icp >= 13 there); never below 32 k keypoints. Takes effect at the
  * next ctgn_set_keypoints. Debug capture and the robust route keep caller-order records and read through the order instead. */
 ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
-/* The persistent small-frame kernel: -1 = automatic (default: solves of at most 4096 keypoints on the default row kernel run as ONE
- * launch — state init, every GN iteration with an in-kernel barrier on one XCD, final re-transform), 0 = never
- * (always the three launches per iteration). Same results up to the (fixed) order of the block sums. */
+/* The persistent small-frame kernel: 1 = solves of at most 1 024 keypoints on the default row kernel run as ONE launch — state init,
+ * every GN iteration with an in-kernel barrier on one XCD, final re-transform; 0 (default) = always the three
+ * launches per iteration. Off by default: once the partial sums were laid out block-major (the persistent kernel's exchange is where
+ * the L2-channel conflict of the old layout was found) the three-launch loop runs a small frame's iteration in the same 28-29 us.
+ * Same results up to the (fixed) order of the block sums. */
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
