@@ -387,6 +387,16 @@ ctgn_status sync_level(ctgn_handle h, int li) {
     return CTGN_OK;
 }
 
+// MapView::r2adm: how far beyond the radius the row kernels collect candidates. The sweep of (2 nb + 1)^3 voxels round the query's own is
+// certain to hold every point within nb * resolution of it (Voxel::Coordinates truncates, src/SlamCore/types.cxx:13-20: the voxels of
+// index 0 are the wide ones), which is >= the radius by the choice of nb (map.h:416-432); 7 % of the radius is plenty for the few
+// centimetres a keypoint moves between the searches of a solve.
+static double collect_sq_threshold(double r2thr, double radius, int nb, double res) {
+    static const double factor = std::getenv("CTGN_COLLECT") ? std::atof(std::getenv("CTGN_COLLECT")) : 1.0;     // measurement hook
+    const double reach = std::min((double) nb * res * (1.0 - 1e-9), radius * factor);
+    return (std::isfinite(reach) && reach * reach > r2thr) ? reach * reach : r2thr;
+}
+
 ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     if (radius <= 0) radius = h->opts.default_radius;
     int map_id, nb;
@@ -403,6 +413,7 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
         mv->nb = nb;
         mv->resolution = res;
         mv->r2thr = radius_sq_threshold(radius);
+        mv->r2adm = collect_sq_threshold(mv->r2thr, radius, nb, res);
         return CTGN_OK;
     }
     ctgn_status st = sync_level(h, map_id);
@@ -416,6 +427,7 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     mv->nb = nb;
     mv->resolution = res;
     mv->r2thr = radius_sq_threshold(radius);
+    mv->r2adm = collect_sq_threshold(mv->r2thr, radius, nb, res);
     return CTGN_OK;
 }
 
@@ -487,6 +499,10 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.cnt = h->d_res + (size_t) h->cap_kp * SEL_STRIDE;
     v.kth = reinterpret_cast<float *>(h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 1));
     v.kth_valid = 0;
+    // Pools pay where the search is throughput-bound: a pool check is an extra dependent phase in front of the searches that remain, and a
+    // frame of a few thousand keypoints (a handful of waves per CU) is bound by exactly that chain (B1 / C: +3 % with pools, B2 -7 %, D -29 %).
+    static const int env_pool_min = [] { const char *e = std::getenv("CTGN_POOL_MIN"); return e ? std::atoi(e) : 8192; }();      // measurement hook
+    v.pools = h->n_kp >= env_pool_min ? 1 : 0;
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
@@ -597,7 +613,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         // one instantiation per (sweep half-width, selection flavour, instrumentation, waves per SIMD)
         auto launch = [&](auto kernel, size_t smem, unsigned long long *prof) {
             const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
-            const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
+            static const int env_rounds_later = [] { const char *e = std::getenv("CTGN_ROUNDS_LATER"); return e ? std::atoi(e) : 0; }();   // measurement hook
+            const int rounds = (kv.kth_valid && env_rounds_later > 0) ? std::min(16, env_rounds_later) : pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
             static const int env_xcd = [] { const char *e = std::getenv("CTGN_XCD_SPLIT"); return e ? std::atoi(e) : -1; }();     // measurement hook
@@ -1099,7 +1116,7 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), (cap * 7 + KP_TAIL) * sizeof(double)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 2 * cap) * sizeof(uint32_t)));   // records | counts | k-th distances
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 3 * cap) * sizeof(uint32_t)));   // records | counts | pool radius, k-th distance
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
@@ -1418,6 +1435,10 @@ static ctgn_status gn_collect(ctgn_handle h, double pose_out[14], ctgn_summary *
         if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "[HIP] in-kernel barrier timed out; retry"); }
         return fail(h, CTGN_ERR_HIP, "[HIP] the persistent small-frame kernel's barrier timed out (device shared?); the handle now uses the three-launch loop — retry the call");
     }
+    if (s.failed == GN_FAILED_PEER) {
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "[RCCL] a peer rank failed before the exchange"); }
+        return fail(h, CTGN_ERR_INVALID_ARGUMENT, "keypoint-sharded solve: another rank could not start its solve (see that rank's error); the pose is unchanged");
+    }
     if (pose_out) for (int i = 0; i < 14; ++i) pose_out[i] = s.pose[i];
     if (summary) {
         std::memset(summary, 0, sizeof(*summary));
@@ -1573,6 +1594,22 @@ ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double t
     NEED_DEVICE(h);
     if (!h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
     ctgn_status st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
+    if (st != CTGN_OK && opts && opts->num_iters_icp > 0 && opts->num_iters_icp <= 1000 && h->d_sys) {
+        // This rank cannot start (a timestamp of ITS shard outside the frame, a failed launch ...) while its peers, whose shards were
+        // fine, are about to wait in the all-reduce. Fail together: take part in every exchange with a poisoned count; every rank's
+        // solve kernel sees the negative sum, stops before the pose changes and reports GN_FAILED_PEER.
+        const std::string own_error = ctgn_last_error(h);
+        double poison[CTGN_SYSTEM_DOUBLES] = {0.0};
+        poison[90] = GN_PEER_POISON;
+        bool ok = hipMemcpyAsync(h->d_sys, poison, sizeof(poison), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        for (int it = 0; ok && it < opts->num_iters_icp; ++it)
+            ok = rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess;
+        hipStreamSynchronize(h->stream);
+        h->gn_active = false;
+        fail(h, st, own_error);
+        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", own_error.c_str()); }
+        return st;
+    }
     MapView mv;
     if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
     for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {

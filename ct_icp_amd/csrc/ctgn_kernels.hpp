@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ctgn_map.hpp"
 #include "ctgn_math.hpp"
@@ -44,16 +45,23 @@ struct MapView {
     int nb;                  // sweep half-width (voxel_neighborhood)
     double resolution;
     double r2thr;            // radius_sq_threshold(radius)
+    double r2adm;            // row kernels: candidates are COLLECTED up to this squared distance (>= r2thr, inside the sweep's guaranteed
+                             // reach nb * resolution); neighbours are those within r2thr. The margin is what lets a keypoint with fewer
+                             // than k neighbours keep a pool that is known to be complete beyond the radius (rows_tiles, phase V)
 };
 
 struct KpView {
     const double *rx, *ry, *rz, *t;
     double *wx, *wy, *wz;
-    uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: count, then the byte offsets of the kept points
+    uint32_t *sel;           // [n][SEL_STRIDE] per-keypoint hand-over of k_accumulate_rows: word 0 = n | pool size << 8 | TIE_FLAG, then the byte
+                             // offsets of the pool's points nearest first — the first n are the neighbours
     uint32_t *cnt;           // [n] the record's count again, dense: the residual kernel looks here first and only fetches the records it will use
-    float *kth;              // [n] squared distance of the k-th neighbour the last search found (rounded up; +inf: fewer than k): with the
-                             // keypoint's displacement since then it bounds the next search (k_accumulate_rows); nullptr = not kept
+    float *kth;              // [n][2] left by the last search / pool check of the keypoint (k_accumulate_rows, phase V):
+                             //   [0] radius round its position then inside which its pool is complete (rounded down; 0: no pool) — without
+                             //       pools (k at the record's capacity): the k-th neighbour's distance (rounded up; 0: fewer than k)
+                             //   [1] distance of its k-th neighbour then, or the search radius if it had fewer than k (rounded up)
     int kth_valid;           // 1: kth[] and the world points come from the previous search of THIS solve on the same map (set per launch)
+    int pools;               // 1: bounded searches keep pools and later iterations check them first (rows_tiles, phase V); 0: every iteration searches
     int n;
     const uint32_t *order;   // k_accumulate_rows works on keypoint order[s] at position s (positions sorted by home voxel); nullptr = identity
     int chunk;               // rounds of a tile that take consecutive positions (>= 1)
@@ -549,7 +557,10 @@ struct WaveScratch {
     int kx[64], ky[64], kz[64];        // its voxel; kx == INT_MIN -> no search
     int id[64];                        // its index in the caller's arrays; -1 = none
     float kb[64];                      // admission bound of its search (squared distance, rounded up); +inf = the radius only
+    float rr2[64];                     // pool certificate: every map point NOT in its pool is at least sqrt(rr2) away from the new position (0: no pool)
     uint16_t mr[64];                   // per axis, which voxel offsets -2 .. +2 of its home voxel reach inside that bound (bit 5 a + o + 2)
+    uint8_t todo[64];                  // 1: the keypoint needs a search this iteration (no pool, or its pool could not be certified)
+    uint8_t slot[64];                  // round r, row j of the search phase works on the keypoint of lane slot[4 r + j] (255: nothing)
     union {
         struct {
             RowList list[4];
@@ -584,17 +595,24 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
     const uint32_t lt_mask = (1u << sub) - 1u;
     // lists of at most 32 entries go straight to the register rank below (with a carried-over bound that is nearly every list);
     // longer ones are first cut with the histogram
-    if (HIST && maxLn > 32) {
+    // Up to three passes: the first bins [0, hi]; a pass that still leaves a row more than 32 entries (many candidates in the bin
+    // the k-th one falls into) bins that one bin again, entries below it kept as they are.
+    double lo = 0.0, width = hi;
+    auto hist_pass = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;      // lo == 0: no entries below the binned range
         R.hist[sub] = 0;
-        const double scale = hi > 0.0 ? 16.0 / hi : 0.0;
+        const double scale = width > 0.0 ? 16.0 / width : 0.0;
         const int nown = (maxLn + 15) >> 4;
         const bool cut = Ln > k;
+        auto bin_of = [&](double d) { return FIRST ? min(15, (int) (d * scale)) : (d < lo ? -1 : min(15, (int) ((d - lo) * scale))); };
+        int below = 0;                          // entries under the binned range: kept, and counted towards k
         for (int m = 0; m < nown; ++m) {
             const int e = sub + 16 * m;
-            const int b = min(15, (int) (R.d2[e] * scale));
-            if (cut && e < Ln) atomicAdd(&R.hist[b], 1u);
+            const int b = bin_of(R.d2[e]);
+            if (cut && e < Ln && b >= 0) atomicAdd(&R.hist[b], 1u);
+            if (!FIRST) below += __popc(row_bits(ballot64(cut && e < Ln && b < 0), row));
         }
-        const int cum = row_scan_i32((int) R.hist[sub]);
+        const int cum = below + row_scan_i32((int) R.hist[sub]);
         const uint32_t reach = row_bits(ballot64(cum >= k), row);
         const int bb = reach ? (__ffs(reach) - 1) : 15;
         // stable in-place compaction of the entries with bin <= bb: step m reads 16 entries, then writes at
@@ -605,7 +623,7 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
             const double d = R.d2[e];
             const uint32_t vv = R.vis[e];
             // (entries a hair above the last kept bin stay too: a near-tie of the k-th best must not be cut away unseen)
-            const bool keep = (e < Ln) && (!cut || min(15, (int) (d * (1.0 - 0x1p-40) * scale)) <= bb);
+            const bool keep = (e < Ln) && (!cut || bin_of(d * (1.0 - 0x1p-40)) <= bb);
             const uint32_t km = row_bits(ballot64(keep), row);
             if (keep) {
                 const int pos = base + __popc(km & lt_mask);
@@ -614,8 +632,14 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
             }
             base += __popc(km);
         }
+        // a further pass bins the last kept bin again (each row its own)
+        if (cut) { lo = lo + bb * (width / 16.0); width = width / 16.0; }
         Ln = base;
         maxLn = max_over_rows(Ln);
+    };
+    if (HIST && maxLn > 32) {
+        hist_pass(std::true_type{});
+        for (int pass = 1; pass < 3 && maxLn > 32; ++pass) hist_pass(std::false_type{});
     }
     if (HIST && maxLn <= 32) {
         // Fast rank for <= 32 surviving entries per row: every lane owns entries `sub` and `sub + 16` and keeps their
@@ -706,6 +730,9 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
 // neighbour records (k_residual_reduce, k_robust_prepare), not by the search kernel, whose registers and instruction stream stay as
 // they are (an inlined replay cost the search kernel 4 % on the B2 sweep). The search kernel only sets TIE_FLAG in the record's count.
 constexpr uint32_t TIE_FLAG = 0x80000000u;
+constexpr uint32_t REC_N_MASK = 63u;           // record word 0: bits 0-5 neighbours kept (n), bits 8-13 pool size (m >= n), bit 31 TIE_FLAG
+constexpr int POOL_REFILL = 4;                 // a keypoint whose pool check fails is searched up to its (k + POOL_REFILL)-th pool member
+constexpr int POOL_EXTRA = 8;                  // spare pool members behind the k neighbours (k + POOL_EXTRA <= KMAX or as many as fit)
 struct TieScratch {            // one per wave: the queue of the lane being replayed (keys, their squares, payload = point byte offset)
     double d[KMAX], s[KMAX];
     uint32_t v[KMAX];
@@ -746,7 +773,7 @@ __device__ __forceinline__ int replay_reference_queue(const MapView &m, Vec3 q, 
     return kept;
 }
 // All (active) lanes of a wave call this right after loading their keypoint's record into rec32 (count | TIE_FLAG, then the byte
-// offsets farthest first). Flagged lanes are replayed one after the other through the wave's TieScratch and their record replaced.
+// offsets nearest first). Flagged lanes are replayed one after the other through the wave's TieScratch and their record replaced.
 __device__ __forceinline__ void resolve_ties(const MapView &map, const KpView &kp, int my_kp, bool wanted, uint32_t (&rec32)[SEL_STRIDE],
                                              TieScratch &T, int lane, int k) {
     unsigned long long todo = ballot64(wanted && (rec32[0] & TIE_FLAG) != 0u);
@@ -757,10 +784,10 @@ __device__ __forceinline__ void resolve_ties(const MapView &map, const KpView &k
             const int n = replay_reference_queue(map, Vec3{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]}, k, T);
             rec32[0] = (uint32_t) n;
 #pragma unroll
-            for (int q = 0; q < KMAX; ++q) rec32[1 + q] = q < n ? T.v[n - 1 - q] : 0u;
+            for (int q = 0; q < KMAX; ++q) rec32[1 + q] = q < n ? T.v[q] : 0u;
         }
     }
-    rec32[0] &= ~TIE_FLAG;
+    rec32[0] &= REC_N_MASK;
 }
 
 // true iff the four rows of the wave hold the same, valid voxel (kx, ky, kz are row-uniform values)
@@ -794,11 +821,14 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     RowProbe<OCC> &RP = W.probe[row];
     SharedStage &SH = W.stage;
     const int k = prm.max_nb;
+    // pool: how many of a search's nearest candidates the keypoint's record keeps (the k neighbours + spare ones), see phase V
+    const int pool_cap = ((ablate & 2048) || !kp.pools) ? k : min(KMAX, k + (((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : POOL_EXTRA));
+    const bool pool_on = pool_cap > k;
     const int blk = map.blk;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
     const uint32_t stride3 = 3u * (uint32_t) blk * 8u;                     // bytes per block; uniform base + 32-bit lane offset loads
 
-    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 8: rounds on the fast path, 9: rounds, 10: hash probes issued, 11: map points streamed
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 6: pool checks; 8: keypoints certified by them, 9: search rounds, 10: hash probes issued, 11: map points fetched
     unsigned long long tprev = 0;
     if (PROF) tprev = __builtin_readcyclecounter();
     const unsigned long long t_wave_start = tprev;
@@ -821,7 +851,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // reuse). kp.chunk consecutive rounds take consecutive positions (the staged neighbourhood of one round then often
         // serves the next) and groups of kp.chunk rounds are strided over the whole order; the library passes 1 — longer
         // chunks unbalance the tiles by more than the reuse saves.
-        int my_kp = -1;
+        int my_kp = -1, n_search = 0;
         if (sub < rounds) {
             const int c = kp.chunk, g = sub / c, j = sub - g * c, cg = min(c, rounds - g * c);
             const int pos = g * ntiles * 4 * c + tile * 4 * cg + j * 4 + row;
@@ -831,52 +861,160 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         {
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
-        float kbv = __int_as_float(0x7f800000);
+        float kbv = __int_as_float(0x7f800000), rr2v = 0.f;
         if (own) {
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
             const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
-            const Vec3 before{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};          // where the last search (or the upload) saw it
+            const Vec3 before{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};          // where the last iteration (or the upload) saw it
             if (first_iter) {
                 p = before;
             } else {
                 p = ct_transform(st, alpha, raw);
                 kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
                 if (kp.kth_valid && !(ablate & 256)) {
-                    // The k neighbours of the previous search lie within sqrt(kth) + |p - before| of the new position (the map does not
-                    // change inside a solve): an upper bound on the new k-th distance, usually a few millimetres above it. Admitting
-                    // only candidates inside it leaves ~k of the ~260 streamed points in the list; the result is the same set.
                     const double dx = p.x - before.x, dy = p.y - before.y, dz = p.z - before.z;
-                    const double reach = sqrt((double) kp.kth[my_kp]) + sqrt(sq_norm3(dx, dy, dz));
-                    kbv = __double2float_ru(reach * reach * (1.0 + 1e-9));
+                    const double moved = sqrt(sq_norm3(dx, dy, dz));
+                    const double rprev = (double) kp.kth[2 * my_kp], kprev = (double) kp.kth[2 * my_kp + 1];
+                    // kth[1] = distance of the previous k-th neighbour (rounded up). The k neighbours found then lie within that + the distance
+                    // moved of the new position: an upper bound on the new k-th distance, and a search that admits only candidates inside
+                    // it keeps ~k of the streamed points in its list (with fewer than k neighbours then: the radius, i.e. no bound).
+                    if (kprev > 0.0) {
+                        const double reach = kprev + moved;
+                        kbv = __double2float_ru(reach * reach * (1.0 + 1e-9));
+                    }
+                    if (pool_on) {
+                        // kth[0] = radius around the PREVIOUS position inside which every map point is in the keypoint's pool (rounded
+                        // down; 0: no pool): around the new position that radius is smaller by the distance moved (the map does not
+                        // change inside a solve)
+                        const double rnow = rprev - moved * (1.0 + 1e-9) - 1e-12;
+                        if (rnow > 0.0) rr2v = __double2float_rd(rnow * rnow * (1.0 - 1e-9));
+                    }
                 }
             }
             int a = voxel_coord(p.x, map.resolution), b = voxel_coord(p.y, map.resolution), c = voxel_coord(p.z, map.resolution);
             if (sweep_in_short_range(a, NB) && sweep_in_short_range(b, NB) && sweep_in_short_range(c, NB)) {
                 kxv = a; kyv = b; kzv = c;
+            } else {
+                rr2v = 0.f;
             }
         }
         W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
         W.kx[lane] = kxv; W.ky[lane] = kyv; W.kz[lane] = kzv;
         W.id[lane] = my_kp;
         W.kb[lane] = kbv;
+        W.rr2[lane] = rr2v;
+        W.todo[lane] = own ? 1 : 0;
+        }
+        CTGN_TICK(0)
+        // ---------------- phase V: pools. The previous bounded search (or pool check) of this solve left the keypoint a POOL — its nearest
+        // candidates, the k neighbours among them, nearest first — and the radius inside which the pool is complete. If the new k-th
+        // nearest pool member is still inside that radius (shrunk by the distance the keypoint has moved since), no map point outside the
+        // pool can be among the k nearest, nor tie with one of them: the neighbour set is the k nearest pool members — up to KMAX
+        // gathered points and one selection instead of the hash probes and the ~120 streamed candidates of a search. Exactly the same
+        // set in the same order: the certificate is conservative (directed roundings), and a keypoint it does not cover takes the
+        // search below, bounded by its pool.
+        if (pool_on && kp.kth_valid && !first_iter && !(ablate & 256) && any64(W.rr2[lane] > 0.f)) {
+            uint32_t *T = reinterpret_cast<uint32_t *>(RP.chunk);            // the row's pool: point byte offsets by pool index
+            struct PoolRec { uint32_t hdr, o0, o1; };
+            struct PoolPts { double x0, y0, z0, x1, y1, z1; };
+            auto request = [&](int r, PoolRec &q) {                          // round r's record words
+                const int id = W.id[row * 16 + min(r, rounds - 1)];
+                const uint32_t *o = kp.sel + (size_t) max(id, 0) * SEL_STRIDE;
+                q.hdr = o[0]; q.o0 = o[1 + sub]; q.o1 = o[17 + sub];
+            };
+            auto pool_size = [&](int r, const PoolRec &q) {                  // 0: the round's keypoint has no pool to check
+                return (r < rounds && W.rr2[row * 16 + min(r, rounds - 1)] > 0.f) ? (int) ((q.hdr >> 8) & REC_N_MASK) : 0;
+            };
+            auto gather = [&](int m, const PoolRec &q, PoolPts &t) {         // its pool members, two per lane (masked lanes read offset 0)
+                load_point(pbase, sub < m ? q.o0 : 0u, t.x0, t.y0, t.z0);
+                load_point(pbase, sub + 16 < m ? q.o1 : 0u, t.x1, t.y1, t.z1);
+            };
+            // Three rounds in flight: while round r is selected, the points of round r + 1 and the record of round r + 2 are on their way
+            PoolRec rec_cur{0u, 0u, 0u}, rec_nxt{0u, 0u, 0u}, rec_far{0u, 0u, 0u};
+            PoolPts pts_cur{0, 0, 0, 0, 0, 0}, pts_nxt{0, 0, 0, 0, 0, 0};
+            request(0, rec_cur);
+            request(1, rec_nxt);
+            gather(pool_size(0, rec_cur), rec_cur, pts_cur);
+            for (int r = 0; r < rounds; ++r) {
+                const int src = row * 16 + r;
+                request(r + 2, rec_far);
+                gather(pool_size(r + 1, rec_nxt), rec_nxt, pts_nxt);
+                const float rr2 = W.rr2[src];
+                const bool vrow = rr2 > 0.f;                                  // row-uniform
+                if (any64(vrow)) {
+                const int m = pool_size(r, rec_cur);
+                const bool v0 = sub < m, v1 = sub + 16 < m;
+                if (PROF) pc[11] += (unsigned long long) (__popcll(ballot64(v0)) + __popcll(ballot64(v1)));
+                const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
+                R.d2[sub] = sq_norm3(pts_cur.x0 - qx, pts_cur.y0 - qy, pts_cur.z0 - qz); R.vis[sub] = (uint32_t) sub;
+                R.d2[sub + 16] = sq_norm3(pts_cur.x1 - qx, pts_cur.y1 - qy, pts_cur.z1 - qz); R.vis[sub + 16] = (uint32_t) (sub + 16);
+                T[sub] = rec_cur.o0; T[sub + 16] = rec_cur.o1;
+                bool tie = false;
+                row_select<HIST>(R, m, KMAX, sub, row, map.r2adm, tie);     // the whole pool, sorted by its distances to the new position
+                const double s0 = R.d2[sub], s1 = R.d2[sub + 16];
+                const int n_in = row_sum_i32(((v0 && s0 <= map.r2thr) ? 1 : 0) + ((v1 && s1 <= map.r2thr) ? 1 : 0));   // map.h:491-493
+                const int n = min(n_in, k);
+                // needed: the k-th neighbour's distance — or, with fewer than k pool members inside the radius, the radius itself —
+                // lies strictly inside the region the pool is known to be complete in
+                const double need2 = n_in >= k ? R.d2[k - 1] : map.r2thr;
+                const bool pass = vrow && need2 * (1.0 + 1e-8) < (double) rr2;
+                const int kp_r = W.id[src];
+                if (PROF) pc[8] += (unsigned long long) __popcll(ballot64(pass && sub == 0));
+                if (pass) {
+                    uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
+                    if (sub == 0) {
+                        const uint32_t flagged = (uint32_t) n | ((uint32_t) m << 8) | (tie ? TIE_FLAG : 0u);
+                        o[0] = flagged; kp.cnt[kp_r] = flagged;
+                        kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
+                        kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
+                        W.todo[src] = 0;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = sub + 16 * h;
+                        if (e < m) o[1 + e] = T[R.vis[e]];                        // nearest first: the n neighbours, then the rest of the pool
+                    }
+                } else if (vrow && sub == 0 && n_in >= k + POOL_REFILL) {
+                    // searched below, admitting what lies within the (k + 4)-th pool member (a pool again, at the price of four candidates)
+                    W.kb[src] = __double2float_ru(R.d2[k + POOL_REFILL - 1] * (1.0 + 0x1p-40));
+                }
+                }
+                rec_cur = rec_nxt; rec_nxt = rec_far; pts_cur = pts_nxt;
+            }
+            CTGN_TICK(6)
+        }
+
+        // ---------------- phase A2: the keypoints that are searched
+        {
+        const bool searched = W.todo[lane] != 0;
         // Per axis a voxel offset -1 / 0 / +1 is needed iff the slab of that offset lies within the keypoint's bound (offset 0 always):
         // the product of the three per-axis sets is a superset of the sweep voxels whose box reaches inside the bound — a superfluous
         // voxel only streams candidates that the bound then rejects. Once per keypoint, here, where every lane has its own.
         uint32_t mr = 0x1084u;                     // offset 0 of every axis
-        if (kxv != INT_MIN) {
-            const double bnd = fmin(map.r2thr, (double) kbv) * (1.0 + 1e-8) + 1e-12;
+        const int kxv = W.kx[lane], kyv = W.ky[lane], kzv = W.kz[lane];
+        if (searched && kxv != INT_MIN) {
+            const double px = W.px[lane], py = W.py[lane], pz = W.pz[lane];
+            const double bnd = fmin(map.r2adm, (double) W.kb[lane]) * (1.0 + 1e-8) + 1e-12;
 #pragma unroll
             for (int o = -NB; o <= NB; ++o) {
                 if (o == 0) continue;
                 double g;
-                g = axis_gap(p.x, kxv + o, map.resolution); mr |= g * g <= bnd ? 1u << (o + 2) : 0u;
-                g = axis_gap(p.y, kyv + o, map.resolution); mr |= g * g <= bnd ? 1u << (5 + o + 2) : 0u;
-                g = axis_gap(p.z, kzv + o, map.resolution); mr |= g * g <= bnd ? 1u << (10 + o + 2) : 0u;
+                g = axis_gap(px, kxv + o, map.resolution); mr |= g * g <= bnd ? 1u << (o + 2) : 0u;
+                g = axis_gap(py, kyv + o, map.resolution); mr |= g * g <= bnd ? 1u << (5 + o + 2) : 0u;
+                g = axis_gap(pz, kzv + o, map.resolution); mr |= g * g <= bnd ? 1u << (10 + o + 2) : 0u;
             }
         }
         W.mr[lane] = (uint16_t) ((ablate & 512) ? 0x7fffu : mr);
+        // the searched keypoints, compacted into rounds of four: position in the order (sub, row), so that with nothing certified
+        // (first search) round r holds the keypoints of lanes (0..3, r) as before — four consecutive ones
+        const unsigned long long sm = ballot64(searched);
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q += __popc(row_bits(sm, j) & ((1u << (sub + (j < row ? 1 : 0))) - 1u));
+        n_search = (int) __popcll(sm);
+        if (lane >= n_search) W.slot[lane] = 255;
+        if (searched) W.slot[q] = (uint8_t) lane;
         }
-        CTGN_TICK(0)
 
         // ---------------- phase B: the row works on the keypoint owned by its lane `r`
         Probe nxt;
@@ -894,24 +1032,34 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             const uint32_t want = (1u << (svl / 9 + 1)) | (1u << (5 + (svl / 3) % 3 + 1)) | (1u << (10 + svl % 3 + 1));    // offsets -1 .. +1 = bits 1 .. 3
             bool any_row = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) any_row = any_row || ((uint32_t) W.mr[j * 16 + rr] & want) == want;
+            for (int j = 0; j < 4; ++j) {
+                const int sj = W.slot[4 * rr + j];
+                any_row = any_row || (sj != 255 && ((uint32_t) W.mr[sj & 63] & want) == want);
+            }
             return ballot64(any_row && lane < 27);
         };
-        for (int r = 0; r < ((ablate & 1024) ? 0 : rounds); ++r) {
-            const int src = row * 16 + r;
+        const int search_rounds = (n_search + 3) >> 2;
+        for (int r = 0; r < ((ablate & 1024) ? 0 : search_rounds); ++r) {
+            const int slot_r = W.slot[4 * r + row];
+            const bool idle = slot_r == 255;                       // this row has no keypoint in the last round
+            const int src = idle ? row * 16 : slot_r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
-            const int kx = W.kx[src], ky = W.ky[src], kz = W.kz[src];
+            const int kx = idle ? INT_MIN : W.kx[src], ky = W.ky[src], kz = W.kz[src];
             const bool searching = kx != INT_MIN;
             const uint32_t lt_mask = (1u << sub) - 1u;
             int Ln = 0;
             // admission bound of the stream: the radius or the bound carried over from the previous search, then the k-th best so far
-            double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
+            double kth_d2 = fmin(map.r2adm, (double) W.kb[src]);
+            // A search that starts with a bound (carried over from the previous one) keeps a pool: its bound exceeds the new k-th distance by
+            // about the distance the keypoint has moved, so nearly everything it admits comes for free. A search bounded by the radius only
+            // would have to carry the spare members through every cut of its long stream: it keeps the k neighbours and leaves no pool.
+            const int kpool = (double) W.kb[src] < map.r2adm ? pool_cap : k;
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             bool tie_seen = false;                // some selection of this round met candidates whose distances (nearly) tie
-            if (PROF) { pc[9] += 1; pc[8] += uniform_home ? 1 : 0; }
+            if (PROF) pc[9] += 1;
 
             if (uniform_home) {
                 // ===== fast path: shared, flattened neighbourhood =====
@@ -1004,8 +1152,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                             max(L[2] + (int) __popcll(pm[2]), L[3] + (int) __popcll(pm[3]))) > LCAP) {
                         CTGN_TICK(2)
                         Ln = row == 0 ? L[0] : row == 1 ? L[1] : row == 2 ? L[2] : L[3];
-                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
-                        if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
+                        Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             L[j] = __builtin_amdgcn_readlane(Ln, 16 * j);
@@ -1056,11 +1204,12 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
                     nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
-                } else if (r + 1 < rounds) {
-                    const int src2 = row * 16 + r + 1;
-                    const int kx2 = W.kx[src2];
+                } else if (r + 1 < search_rounds) {
+                    const int slot2 = W.slot[4 * (r + 1) + row];
+                    const int src2 = slot2 == 255 ? row * 16 : slot2;
+                    const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2];
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
-                                          fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
+                                          fmin(map.r2adm, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
                 if (PROF) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
@@ -1074,7 +1223,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // 125-voxel sweep (8 probe batches): on the 27-voxel sweep (2 batches) the extra selection costs more than the
                 // culled chunks save (B2: 0.094 -> 0.105 ms per launch), on the 125-voxel one it wins (D: 3.11 -> 2.31 ms).
                 bool within_kth = true;
-                if (NB == 2 && it > 0 && kth_d2 < map.r2thr) {
+                if (NB == 2 && it > 0 && kth_d2 < map.r2adm) {
                     const int vv = (cur_v == 255) ? 0 : cur_v;
                     const double gx = axis_gap(qx, kx + vv / (S * S) - NB, map.resolution), gy = axis_gap(qy, ky + (vv / S) % S - NB, map.resolution),
                                  gz = axis_gap(qz, kz + vv % S - NB, map.resolution);
@@ -1128,8 +1277,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     if (any64(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
-                        Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
-                        if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
+                        Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
                         CTGN_TICK(3)
                     }
                 }
@@ -1138,17 +1287,18 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
-                if (NB == 2 && it + 1 < VIT && any64(Ln >= k && !(kth_d2 < map.r2thr))) {
-                    Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
-                    if (Ln >= k) kth_d2 = kth_bound(R.d2[k - 1], map.r2thr);
+                if (NB == 2 && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2adm))) {
+                    Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+                    if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
                     CTGN_TICK(3)
                 }
             }
             }
             // the next round's shared probes go out now, so their latency hides behind this round's selection and sums
-            if (SHARED && NB == 1 && blk <= 32 && r + 1 < rounds) {
-                const int src2 = row * 16 + r + 1;
-                const int kx2 = W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
+            if (SHARED && NB == 1 && blk <= 32 && r + 1 < search_rounds) {
+                const int slot2 = W.slot[4 * (r + 1) + row];
+                const int src2 = slot2 == 255 ? row * 16 : slot2;
+                const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
                 if (!(ablate & 32) && rows_share_home(kx2, ky2, kz2)) {
                     const unsigned long long need2 = shared_need(r + 1);
                     need_next = need2;
@@ -1164,32 +1314,54 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             // B3: final selection -> list sorted ascending, [0..n). A row that ends with fewer than min_number_neighbors (or 5)
             // candidates was never pruned (Ln < k throughout), so Ln already is its exact neighbour count, and the residual kernel
             // drops it on that count alone: when no row of the wave can be used, skip the selection and hand over counts only.
-            const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr;
-            if (!(ablate & 2) && any64(row_needed)) Ln = row_select<HIST>(R, Ln, k, sub, row, kth_d2, tie_seen);
-            const int n = (ablate & 2) ? min(Ln, k) : Ln;
+            // With pools every row is sorted and kept, the empty ones too: a keypoint with too few neighbours to be used (or none within
+            // reach) is then certified as such by phase V instead of being searched again in every iteration.
+            const bool row_needed = (Ln >= prm.min_nb && Ln >= 5) || dbg.n_nb != nullptr || (pool_on && searching);
+            const int admitted = Ln;
+            if (!(ablate & 2) && any64(row_needed)) Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+            const int m = min(Ln, kpool);          // pool: what the record keeps, sorted nearest first
+            // the neighbours: the k nearest of those within the radius (the list was collected up to r2adm >= r2thr; map.h:491-493)
+            int n = min(Ln, k);
+            if (map.r2adm > map.r2thr && !(ablate & 2) && any64(row_needed)) {
+                const double s0 = R.d2[sub], s1 = R.d2[sub + 16];
+                n = min(k, row_sum_i32(((sub < m && s0 <= map.r2thr) ? 1 : 0) + ((sub + 16 < m && s1 <= map.r2thr) ? 1 : 0)));
+            }
             CTGN_TICK(4)
-            // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, FARTHEST
-            // first (the reference's neighbour order; the list is sorted nearest first), in a per-keypoint record. The covariance sums
-            // are then taken by the owner lane in phase C — no cross-lane reductions and no point loads here.
+            // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, nearest first
+            // (the reference's neighbour vector is the same set farthest first: its readers walk the record backwards), in a
+            // per-keypoint record; behind them the rest of the pool (phase V of the next iteration). The covariance sums are then
+            // taken by the residual kernel — no cross-lane reductions and no point loads here.
             {
-                const int kp_r = W.id[src];
+                const int kp_r = idle ? -1 : W.id[src];
                 if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
+                    const bool sorted = row_needed && !(ablate & 2);
                     if (sub == 0) {
                         // (nearly) tied candidates: which of them the reference keeps, and in which order, only its own queue says
                         // (map.h:491-513) — the kernels that read this record replay it for this keypoint (resolve_ties)
-                        const uint32_t flagged = (uint32_t) n | ((tie_seen && row_needed) ? TIE_FLAG : 0u);
+                        const uint32_t flagged = (uint32_t) n | ((uint32_t) (sorted ? m : 0) << 8) | ((tie_seen && row_needed) ? TIE_FLAG : 0u);
                         o[0] = flagged; kp.cnt[kp_r] = flagged;
-                        // a full, sorted list (Ln >= k implies the selection ran): its last entry is the k-th neighbour
-                        if (kp.kth) kp.kth[kp_r] = (n >= k && !(ablate & 2)) ? __double2float_ru(R.d2[k - 1]) : __int_as_float(0x7f800000);
+                        if (kp.kth) {
+                            float kthv = 0.f;
+                            if (sorted && kpool > k) {
+                                // Everything this search did not put into the list lies farther than the admission bound it ended with
+                                // (culled voxels and rejected candidates were beyond the bound of their moment, and bounds only shrink);
+                                // everything the selections dropped lies at or beyond the last pool member. Inside the smaller of the two
+                                // the pool is complete.
+                                const double r2 = admitted > kpool ? fmin(kth_d2, R.d2[kpool - 1]) : kth_d2;
+                                kthv = __double2float_rd(sqrt(r2) * (1.0 - 1e-12));
+                            }
+                            kp.kth[2 * kp_r] = kthv;
+                            kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(sorted && n >= k ? R.d2[k - 1] : map.r2thr) * (1.0 + 1e-12));
+                        }
                     }
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int e = sub + 16 * m;
-                        if (e < n && row_needed) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = sub + 16 * h;
+                        if (e < m && row_needed) {
                             const uint32_t vis = R.vis[e];
                             const uint32_t bc = occ_tab[vis >> 6];
-                            o[n - e] = (bc >> 7) * stride3 + (vis & 63u) * POINT_BYTES;      // slot 1 = farthest kept ... slot n = nearest
+                            o[1 + e] = (bc >> 7) * stride3 + (vis & 63u) * POINT_BYTES;      // nearest first: the n neighbours, then the pool's spare members
                         }
                     }
                 }
@@ -1200,7 +1372,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     }
     if (PROF && lane == 0) {
         unsigned long long tot_ = 0;
-        for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 8) tot_ += pc[q]; }
+        for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 7) tot_ += pc[q]; }
         atomicMax(&prof[10], tot_);            // slowest wave
         atomicAdd(&prof[11], 1ull);            // waves
         atomicAdd(&prof[12], pc[10]);          // hash probes issued (voxels not culled; the shared-home path probes once per wave)
@@ -1275,7 +1447,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
             // record in nine independent 16-byte loads
             const uint32_t cnt_raw = kp.cnt[my_kp];
-            const int cnt_n = min((int) (cnt_raw & ~TIE_FLAG), KMAX);
+            const int cnt_n = min((int) (cnt_raw & REC_N_MASK), KMAX);
             fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
             uint32_t rec32[SEL_STRIDE];
             rec32[0] = (uint32_t) cnt_n | (cnt_raw & TIE_FLAG);
@@ -1294,10 +1466,11 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             // neighbour. On a street scan that is every second keypoint that has neighbours at all.
             const int gat_n = ((res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr) ? res_n : 0;
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
-            // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240).
+            // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240) — the
+            // record is nearest-first, so it is walked from entry n - 1 down to entry 0.
             // Gathers in groups of eight (24 independent loads in flight), sums strictly in order.
 #pragma unroll
-            for (int g = 0; g < KMAX / GG; ++g) {
+            for (int g = KMAX / GG - 1; g >= 0; --g) {
                 if (GG * g < gat_n) {
                     double gx[GG], gy[GG], gz[GG];
 #pragma unroll
@@ -1305,11 +1478,11 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
                         const uint32_t off = (GG * g + q < gat_n) ? rec32[1 + GG * g + q] : 0u;
                         load_point(pbase, off, gx[q], gy[q], gz[q]);          // one point = 24 contiguous bytes: two loads, one or two lines
                     }
-                    if (g == 0) res_q = Vec3{gx[0], gy[0], gz[0]};      // points[0]: the farthest kept (ct_icp.cpp:791)
 #pragma unroll
-                    for (int q = 0; q < GG; ++q) {
+                    for (int q = GG - 1; q >= 0; --q) {
                         if (GG * g + q < gat_n) {
                             const double x = gx[q], y = gy[q], z = gz[q];
+                            if (GG * g + q == gat_n - 1) res_q = Vec3{x, y, z};      // points[0]: the farthest kept (ct_icp.cpp:791)
                             res_S.x += x; res_S.y += y; res_S.z += z;
                             res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
                             res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
@@ -1461,12 +1634,22 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
     }
 }
 
+// GnState::failed: 1 = fewer than min_used keypoints (the reference's soft failure), 3 = GN_FAILED_BARRIER (persistent kernel),
+// 4 = a peer rank of the keypoint-sharded mode failed before the exchange (it takes part in every all-reduce with a count of
+// -1e300, so that every rank stops with the same error instead of waiting for it for ever)
+constexpr int GN_FAILED_PEER = 4;
+constexpr double GN_PEER_POISON = -1e300;
+
 // normalise, motion prior, LDL^T, pose update, stop test (ct_icp.cpp:860-962, :978-980) by ONE wave on the packed system in S.sys
 __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const GnParams &prm, int min_used, int lane,
                                             unsigned long long tc0, unsigned long long wall0) {
     double *s_sys = S.sys, *s_m = S.m, *s_temp = S.temp, *s_x = S.x, *s_b = S.b, *s_sc = S.sc, *s_q = S.q;
     int *s_perm = S.perm;
     const unsigned long long tc1 = __builtin_readcyclecounter();
+    if (s_sys[90] < -0.5) {               // keypoint-sharded mode: a peer could not start its solve and poisoned the summed count
+        if (lane == 0) { st->n_used = 0; st->failed = GN_FAILED_PEER; st->done = 1; }
+        return;
+    }
     const int n_used = (int) (s_sys[90] + 0.5);
     if (n_used < min_used) {              // ct_icp.cpp:860-871 — soft failure, pose untouched
         if (lane == 0) { st->n_used = n_used; st->failed = 1; st->done = 1; }

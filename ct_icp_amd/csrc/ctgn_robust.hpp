@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
         const int n = (n_all >= prm.min_nb && n_all >= 5) ? n_all : 0;          // invalid below (:566-567): nothing to gather, and the search kernel hands over no offsets
         Vec3 S{0, 0, 0}, q0{0, 0, 0};
         double SS9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // farthest-first, summed front to back (neighborhood.h:236-240), WITHOUT fused multiply-adds: this route weighs
-        // rank-deficient neighbourhoods too (:574-579), whose "normal" is decided by the roundings (jacobi_svd3_exact)
+        // the reference's neighbour vector is farthest-first and summed front to back (neighborhood.h:236-240): the record is nearest-first,
+        // walked from entry n - 1 down to entry 0. WITHOUT fused multiply-adds: this route weighs rank-deficient neighbourhoods
+        // too (:574-579), whose "normal" is decided by the roundings (jacobi_svd3_exact)
 #pragma unroll
-        for (int g = 0; g < KMAX / 8; ++g) {
+        for (int g = KMAX / 8 - 1; g >= 0; --g) {
             if (8 * g < n) {
                 double gx[8], gy[8], gz[8];
 #pragma unroll
@@ -207,17 +208,18 @@ __global__ __launch_bounds__(256) void k_robust_prepare(MapView map, KpView kp, 
                     const uint32_t off = (8 * g + q < n) ? rec32[1 + 8 * g + q] : 0u;
                     load_point(pbase, off, gx[q], gy[q], gz[q]);
                 }
-                if (g == 0) q0 = Vec3{gx[0], gy[0], gz[0]};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 7; q >= 0; --q) {
                     if (8 * g + q < n) {
 #pragma clang fp contract(off)
                         const double x = gx[q], y = gy[q], z = gz[q];
+                        const int i_ref = n - 1 - (8 * g + q);                    // its index in the reference's vector
+                        if (i_ref == 0) q0 = Vec3{x, y, z};
                         S.x += x; S.y += y; S.z += z;
                         const double xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
                         SS9[0] += xx; SS9[1] += xy; SS9[2] += xz; SS9[3] += xy; SS9[4] += yy; SS9[5] += yz; SS9[6] += xz; SS9[7] += yz; SS9[8] += zz;
-                        if (8 * g + q < prm.num_closest) {                    // neighborhood.points[i], :585-595
-                            const size_t at = (size_t) (8 * g + q) * rb.cap + k;
+                        if (i_ref < prm.num_closest) {                            // neighborhood.points[i], :585-595
+                            const size_t at = (size_t) i_ref * rb.cap + k;
                             rb.ref[at] = x;
                             rb.ref[(size_t) prm.num_closest * rb.cap + at] = y;
                             rb.ref[(size_t) 2 * prm.num_closest * rb.cap + at] = z;

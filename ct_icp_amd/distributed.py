@@ -109,7 +109,16 @@ class ShardedGnSolver:
         s = self.solver
         if self.library_collective:
             return s.solve_sharded(pose14, t_begin_end, options, motion_model)
-        s.gn_begin(pose14, t_begin_end, options, motion_model)
+        try:
+            s.gn_begin(pose14, t_begin_end, options, motion_model)
+        except Exception:
+            # fail TOGETHER (as ctgn_solve_sharded does): the peers are about to wait in the all-reduce, so take part in every
+            # exchange with a poisoned count (-1e300): their solve step sees the negative sum and stops with an error too
+            self.system.zero_()
+            self.system[90] = -1e300
+            for _ in range(options.num_iters_icp):
+                allreduce_system(self.system, self.group)
+            raise
         for _ in range(options.num_iters_icp):
             s.gn_accumulate()                      # local shard -> packed system in self.system
             allreduce_system(self.system, self.group)

@@ -408,6 +408,16 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
             assert np.array_equal(w_f, sh.solver.world_points())
             A, b, n = sh.solver.get_system()
             assert n == summ_s.num_residuals_used
+            # a rank whose shard cannot start (timestamp outside the frame) still takes part in every exchange with a poisoned count,
+            # so the job fails instead of hanging its peers in the all-reduce; the handle stays usable
+            t_bad = t.copy()
+            t_bad[3] = sc.t_begin_end[1] + 1.0
+            sh.set_keypoints(raw, world0, t_bad)
+            with pytest.raises(Exception, match="timestamp|TIMESTAMP"):
+                sh.solve(pose0, sc.t_begin_end, o)
+            sh.set_keypoints(raw, world0, t)
+            pose_s2, _, _ = sh.solve(pose0, sc.t_begin_end, o)
+            assert np.array_equal(pose_f, pose_s2)
             sh.close()
     finally:
         if created:
