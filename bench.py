@@ -348,8 +348,10 @@ class Runner:
         s.traffic_counters(reset=True)
         self.iterate(1)
         p0, q0 = s.traffic_counters(reset=True)
+        s.phase_cycles(reset=True)
         self.iterate(W["ipf"] - 1)
         p1, q1 = s.traffic_counters(reset=True)
+        certified = int(s.phase_cycles(reset=True)[8])      # keypoints whose neighbours came from their pool (no search), summed over these launches
         s.gn_end()
         s.rewind()
         s.gn_begin(W["pose0"], W["inp"]["tbe"], self.options(steady_after + 1), W["mm"])
@@ -363,6 +365,7 @@ class Runner:
         for key, (p_, q_, launches) in {"first": (p0, q0, 1), "later": (p1, q1, later_n), "steady": (ps, qs, 1)}.items():
             out[key] = {"bytes_per_launch": (n * B_KP * launches + p_ * B_SLOT + q_ * B_PT) / launches, "probes_per_keypoint": p_ / launches / n,
                         "points_per_keypoint": q_ / launches / n}
+        out["later"]["pool_certified_frac"] = certified / later_n / n
         return out
 
     def close(self):
@@ -384,7 +387,13 @@ def roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep,
             "traffic": traffic, "traffic_source": pmc_src,
             "achieved_definition": f"mean over the {ipf} searches of a fresh solve of: algorithmic bytes the kernel requests per launch (32 B/keypoint + 16 B per "
                                    "hash probe it issues + 24 B per map point it streams, counted by the instrumented instantiation) / HIP-event launch "
-                                   "time; the first search of a solve is bounded by the radius only, the others by the carried-over k-th distance",
+                                   "time; the first search of a solve is bounded by the radius only, the second by the carried-over k-th distance; from the "
+                                   "third on (frames of >= 8192 keypoints) a keypoint whose pool certifies its neighbours fetches the pool's points "
+                                   "(24 B each, counted) and is not searched: the requested bytes fall faster than the time, so this fraction FALLS "
+                                   "when pools make the step faster (DESIGN.md section 17)",
+            "frac_survey_8d_all_sweep_voxels": (alg_all / t_k / 1e9 / HBM_PEAK_GBS) if t_k > 0 else None,
+            "frac_survey_8d_note": "SURVEY.md 8(d)'s literal per-keypoint figure (every voxel of the sweep, every point in them) over the same time: "
+                                   "above 1 because the kernel culls what that formula charges - context, not evidence",
             "hbm_counter_gbs": (traffic / t_k / 1e9) if traffic and t_k > 0 else None,
             "hbm_counter_frac": (traffic / t_k / 1e9 / HBM_PEAK_GBS) if traffic and t_k > 0 else None,
             "kernel": "k_accumulate_rows (voxel-hash neighbour search + k-nearest selection)" if variant != 1 else "k_accumulate_lane",
@@ -400,6 +409,8 @@ def roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep,
             roof[key].update({"requested_bytes_per_launch": r["bytes_per_launch"], "requested_bytes_per_keypoint": r["bytes_per_launch"] / n_kp,
                               "probes_issued_per_keypoint": r["probes_per_keypoint"], "points_streamed_per_keypoint": r["points_per_keypoint"],
                               "achieved": g, "frac": g / HBM_PEAK_GBS})
+            if "pool_certified_frac" in r:
+                roof[key]["pool_certified_frac"] = r["pool_certified_frac"]
     if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
         wc = pmc["SQ_WAVE_CYCLES"]
         roof.update({"wait_frac": pmc["SQ_WAIT_ANY"] / wc, "issue_stall_frac": pmc["SQ_WAIT_INST_ANY"] / wc,

@@ -172,6 +172,7 @@ SYMBOLS = {
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_persistent": (C.c_int, [_H, C.c_int32]),
+    "ctgn_set_pools": (C.c_int, [_H, C.c_int32]),
     "ctgn_traffic_counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_phase_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_test_sort_pairs": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),

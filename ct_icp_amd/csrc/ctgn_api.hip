@@ -171,6 +171,7 @@ struct ctgn_context {
     } fr;
 
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
+    int pool_mode = -1;                 // ctgn_set_pools: -1 automatic, 0 never, 1 always
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
@@ -502,7 +503,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     // Pools pay where the search is throughput-bound: a pool check is an extra dependent phase in front of the searches that remain, and a
     // frame of a few thousand keypoints (a handful of waves per CU) is bound by exactly that chain (B1 / C: +3 % with pools, B2 -7 %, D -29 %).
     static const int env_pool_min = [] { const char *e = std::getenv("CTGN_POOL_MIN"); return e ? std::atoi(e) : 8192; }();      // measurement hook
-    v.pools = h->n_kp >= env_pool_min ? 1 : 0;
+    v.pools = h->pool_mode >= 0 ? h->pool_mode : (h->n_kp >= env_pool_min ? 1 : 0);
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
@@ -2482,6 +2483,12 @@ ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode) {
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
     if (!h || (mode != 0 && mode != 1)) return CTGN_ERR_INVALID_ARGUMENT;
     h->persist_mode = mode;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_pools(ctgn_handle h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return CTGN_ERR_INVALID_ARGUMENT;
+    h->pool_mode = mode;
     return CTGN_OK;
 }
 

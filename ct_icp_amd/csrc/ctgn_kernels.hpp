@@ -852,6 +852,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // serves the next) and groups of kp.chunk rounds are strided over the whole order; the library passes 1 — longer
         // chunks unbalance the tiles by more than the reuse saves.
         int my_kp = -1, n_search = 0;
+        bool compact = false;              // pools were checked: the keypoints still to be searched are compacted into rounds (W.slot)
         if (sub < rounds) {
             const int c = kp.chunk, g = sub / c, j = sub - g * c, cg = min(c, rounds - g * c);
             const int pos = g * ntiles * 4 * c + tile * 4 * cg + j * 4 + row;
@@ -914,6 +915,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // set in the same order: the certificate is conservative (directed roundings), and a keypoint it does not cover takes the
         // search below, bounded by its pool.
         if (pool_on && kp.kth_valid && !first_iter && !(ablate & 256) && any64(W.rr2[lane] > 0.f)) {
+            compact = true;
             uint32_t *T = reinterpret_cast<uint32_t *>(RP.chunk);            // the row's pool: point byte offsets by pool index
             struct PoolRec { uint32_t hdr, o0, o1; };
             struct PoolPts { double x0, y0, z0, x1, y1, z1; };
@@ -1012,8 +1014,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
 #pragma unroll
         for (int j = 0; j < 4; ++j) q += __popc(row_bits(sm, j) & ((1u << (sub + (j < row ? 1 : 0))) - 1u));
         n_search = (int) __popcll(sm);
-        if (lane >= n_search) W.slot[lane] = 255;
-        if (searched) W.slot[q] = (uint8_t) lane;
+        if (compact) {
+            if (lane >= n_search) W.slot[lane] = 255;
+            if (searched) W.slot[q] = (uint8_t) lane;
+        }
         }
 
         // ---------------- phase B: the row works on the keypoint owned by its lane `r`
@@ -1027,20 +1031,23 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // Which of the 27 sweep voxels of the shared home voxel can hold one of the k nearest of some row's keypoint of round rr: those in
         // the product of that keypoint's per-axis offset sets (W.mr, phase A; with a carried-over bound typically 1-4 voxels instead of 27).
         // Bit i = the i-th nearest sweep voxel, lane i's.
+        // the lane whose keypoint row j works on in search round r (255: none). Without a pool check every keypoint of the tile is searched
+        // and round r simply takes the lanes (0..3, r) — no table, no LDS round trip in front of the round's first loads.
+        auto slot_of = [&](int r, int j) -> int { return compact ? (int) W.slot[4 * r + j] : j * 16 + r; };
         auto shared_need = [&](int rr) -> unsigned long long {
             const int svl = lane < 27 ? (int) c_sweep1.v[lane] : 13;
             const uint32_t want = (1u << (svl / 9 + 1)) | (1u << (5 + (svl / 3) % 3 + 1)) | (1u << (10 + svl % 3 + 1));    // offsets -1 .. +1 = bits 1 .. 3
             bool any_row = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int sj = W.slot[4 * rr + j];
+                const int sj = slot_of(rr, j);
                 any_row = any_row || (sj != 255 && ((uint32_t) W.mr[sj & 63] & want) == want);
             }
             return ballot64(any_row && lane < 27);
         };
-        const int search_rounds = (n_search + 3) >> 2;
+        const int search_rounds = compact ? (n_search + 3) >> 2 : rounds;
         for (int r = 0; r < ((ablate & 1024) ? 0 : search_rounds); ++r) {
-            const int slot_r = W.slot[4 * r + row];
+            const int slot_r = slot_of(r, row);
             const bool idle = slot_r == 255;                       // this row has no keypoint in the last round
             const int src = idle ? row * 16 : slot_r;
             const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
@@ -1205,7 +1212,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 if (it + 1 < VIT) {
                     nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
                 } else if (r + 1 < search_rounds) {
-                    const int slot2 = W.slot[4 * (r + 1) + row];
+                    const int slot2 = slot_of(r + 1, row);
                     const int src2 = slot2 == 255 ? row * 16 : slot2;
                     const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2];
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
@@ -1296,7 +1303,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             }
             // the next round's shared probes go out now, so their latency hides behind this round's selection and sums
             if (SHARED && NB == 1 && blk <= 32 && r + 1 < search_rounds) {
-                const int slot2 = W.slot[4 * (r + 1) + row];
+                const int slot2 = slot_of(r + 1, row);
                 const int src2 = slot2 == 255 ? row * 16 : slot2;
                 const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2], ky2 = W.ky[src2], kz2 = W.kz[src2];
                 if (!(ablate & 32) && rows_share_home(kx2, ky2, kz2)) {

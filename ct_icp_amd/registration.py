@@ -504,6 +504,10 @@ class GnSolver:
         """ctgn_set_persistent: 1 = small frames (<= 1 024 keypoints) run as one persistent launch, 0 (default) = the three-launch loop."""
         L.check(self._h, L.lib().ctgn_set_persistent(self._h, int(mode)))
 
+    def set_pools(self, mode: int):
+        """ctgn_set_pools: -1 = automatic (frames of >= 8 192 keypoints), 0 = every iteration searches, 1 = pools for every frame."""
+        L.check(self._h, L.lib().ctgn_set_pools(self._h, int(mode)))
+
     def set_variant(self, v: int):
         L.check(self._h, L.lib().ctgn_set_variant(self._h, v))
 

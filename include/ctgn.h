@@ -496,6 +496,12 @@ ctgn_status ctgn_set_ordering(ctgn_handle h, int32_t mode);
  * the L2-channel conflict of the old layout was found) the three-launch loop runs a small frame's iteration in the same 28-29 us.
  * Same results up to the (fixed) order of the block sums. */
 ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode);
+/* Neighbour pools: -1 = automatic (default: frames of at least 8 192 keypoints), 0 = never, 1 = always. With
+ * pools a bounded search of a solve also keeps up to eight spare candidates behind the k neighbours and the radius inside which that
+ * pool is complete; the next iterations first check the pool — if its k-th nearest member still lies inside that radius, shrunk by the
+ * distance the keypoint has moved, the k nearest pool members ARE the neighbours — and search only the keypoints this does not cover.
+ * Identical neighbour sets in identical order (bit-identical poses): only the time changes. */
+ctgn_status ctgn_set_pools(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel

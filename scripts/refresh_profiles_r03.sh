@@ -27,6 +27,8 @@ scripts/gpu_pmc.sh > gpurun_out/pmc_all.log 2>&1
 for i in 1 2 3 4 5; do cp gpurun_out/pmc_$i.txt $P/r03_pmc_pass$i.txt; done
 # phase clocks of the search kernel on fresh solves: first search of a solve vs the bounded ones
 timeout 300 python scripts/rows_prof3.py B2 6 2>&1 | grep '^{' > $P/r03_search_kernel_phases.txt
+# neighbour pools: search-kernel time of each iteration of fresh solves, pools on (mask 0) and off (mask 2048)
+( for w in B2 D C; do timeout 300 python scripts/iter_times.py $w 0 2048 2>&1 | grep '^{'; done ) > $P/r03_pools_iter_times.txt
 # small frames: where a fresh solve spends its time, persistent kernel on and off
 ( for p in 1 0; do echo "CTGN_PERSISTENT=$p"; CTGN_PERSISTENT=$p timeout 300 python scripts/fresh_probe.py B1 2>&1 | grep -E "back-to-back|device stamps|us host" | tail -3; done ) > $P/r03_small_frame_probe.txt 2>&1
 # frame pipeline: host-clock marks

@@ -297,6 +297,76 @@ def test_stepwise_api_equals_fused_loop(box_case):
             assert np.array_equal(pose_p, pose_q) and np.array_equal(w_p, w_q) and np.array_equal(sys_p[0], sys_q[0])
 
 
+def test_pools_give_the_same_neighbours_as_searching_every_iteration(box_case, nclt_case):
+    """Round 3: neighbour pools (ctgn_set_pools). With pools a later iteration first checks the pool its previous
+    bounded search left (gathered pool members + one selection, conservative certificate) and searches only what that does not cover.
+    The neighbour sets and their order must be the ones a search finds: pose, world points, packed system and the captured per-keypoint
+    neighbourhoods (count, normal, a2D, farthest neighbour) are bit-identical with pools on and off, after every iteration — on the
+    27-voxel sweep (box), the 125-voxel sweep with sparse neighbourhoods in use (NCLT profile: min 10 < max 20), with the whole pose
+    error moving the keypoints (large perturbation: few pools certify) and with a converged pose (all of them do), and through the
+    robust route. The instrumented instantiation counts what the pools certified: nothing in iterations 0 / 1, most keypoints later."""
+    cases = []
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    for perturb in ((0.005, 0.03), (0.0, 0.0), (0.02, 0.2)):
+        sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.3, perturb=perturb)
+        cases.append((gm, sc, raw, t, pose0, world0, _opts(num_iters_icp=6, threshold_orientation_norm=0.0), _prior(box_case, 5)[0]))
+    omn, gmn = build_maps(nclt_case, 8, with_gpu=True)
+    scn = nclt_case["scans"][8]
+    sel = syn.grid_sample_indices(scn.raw, 0.8)[:1500]
+    pose_n = syn.perturb_pose(scn.pose_gt, 0.01, 0.05, seed=7)
+    cases.append((gmn, scn, scn.raw[sel], scn.t[sel], pose_n, se3.ct_transform(pose_n, scn.t_begin_end, scn.t[sel], scn.raw[sel]),
+                  _opts(num_iters_icp=8, min_number_neighbors=10, threshold_orientation_norm=0.0), _prior(nclt_case, 8)[0]))
+    for gmap, sc, raw, t, pose0, world0, o, prior in cases:
+        runs = []
+        for pools in (0, 1):
+            s = cia.GnSolver(gmap)
+            s.set_pools(pools)
+            s.set_debug(True)
+            s.set_keypoints(raw, world0, t)
+            s.gn_begin(pose0, sc.t_begin_end, o, prior)
+            per_iter = []
+            for _ in range(o.num_iters_icp):
+                s.gn_iterate(1)
+                d = s.get_debug()
+                per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["normal"].copy(), d["a2d"].copy(), d["farthest"].copy(), d["used"].copy()))
+            pose, summ, _ = s.gn_end()
+            runs.append((pose, summ, s.world_points(), per_iter))
+        (pose_a, summ_a, w_a, it_a), (pose_b, summ_b, w_b, it_b) = runs
+        assert summ_a.success and summ_a.num_iters == summ_b.num_iters == o.num_iters_icp and summ_a.num_residuals_used == summ_b.num_residuals_used
+        assert np.array_equal(pose_a, pose_b) and np.array_equal(w_a, w_b)
+        for k_it, (a, b) in enumerate(zip(it_a, it_b)):
+            assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and a[0][2] == b[0][2], k_it
+            for x, y in zip(a[1:], b[1:]):
+                assert np.array_equal(x, y), k_it
+        # the instrumented instantiation says how many keypoints the pools certified per iteration
+        s = cia.GnSolver(gmap)
+        s.set_pools(1); s.set_variant(3)
+        s.set_keypoints(raw, world0, t)
+        s.gn_begin(pose0, sc.t_begin_end, o, prior)
+        s.phase_cycles(reset=True)
+        certified = []
+        for _ in range(o.num_iters_icp):
+            s.gn_iterate(1)
+            certified.append(int(s.phase_cycles(reset=True)[8]))
+        pose_v, _, _ = s.gn_end()
+        assert np.array_equal(pose_v, pose_a)
+        assert certified[0] == 0 and certified[1] == 0 and certified[-1] > 0.5 * len(t), certified
+    # the robust route searches once per outer iteration through the same kernel
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.3)
+    o = cia.CTICPOptions(solver=cia.CERES, debug_print=False, num_iters_icp=5, ls_max_num_iters=3)
+    if o is not None:
+        outs = []
+        for pools in (0, 1):
+            s = cia.GnSolver(gm)
+            s.set_pools(pools)
+            s.set_keypoints(raw, world0, t)
+            pose_r, summ_r, _ = s.solve_robust(pose0, sc.t_begin_end, o)
+            outs.append((pose_r, s.world_points(), s.robust_blocks()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        for key in outs[0][2]:
+            assert np.array_equal(np.asarray(outs[0][2][key]), np.asarray(outs[1][2][key])), key
+
+
 # ------------------------------------------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def config_b_full():
