@@ -895,15 +895,17 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
                             "the sampled frame and of every scan point -> pose, summary, indices, N x 3 f64 world points D2H; then "
                             "far-voxel eviction + insertion of the device-resident sampled frame"}
     pipeline.update(pcounts)
+    world_buf = np.zeros_like(raw)
     for rep, m in enumerate(maps[:4]):
         cia.grid_sampling(m, raw, 0.5)                   # a fresh handle sizes its scratch on the first scan-sized call: not a per-frame cost
+        cia.transform_points(m, raw, t, inp["pose_gt"], inp["tbe"], out=world_buf)     # likewise its pinned staging buffers and helper threads
         m.RemoveElementsFarFromLocation(inp["pose_gt"][11:14], 100.0)     # every frame evicts: the timed update is not the table's first scan
         t0 = time.perf_counter()
         keep = np.sort(cia.grid_sampling(m, raw, 0.5))
         t1 = time.perf_counter()
         kp = cia.grid_sampling(m, raw[keep], 1.5)                    # keypoint selection (odometry.cpp:538)
         t1b = time.perf_counter()
-        world = cia.transform_points(m, raw, t, inp["pose_gt"], inp["tbe"])
+        world = cia.transform_points(m, raw, t, inp["pose_gt"], inp["tbe"], out=world_buf)     # in place, like the reference's loop (odometry.cpp:461-486)
         t2 = time.perf_counter()
         m.RemoveElementsFarFromLocation(inp["pose_gt"][11:14], 100.0)
         kept = m.InsertPointCloud(world[keep])
@@ -1052,10 +1054,12 @@ def cpu_baseline(inp, pose0, world0, args, om=None):
     # the steps either side of the path on one core, as the reference runs them (only its undistortion loop is OpenMP)
     om2 = orc.Map(resolutions=[(0.8, 0.1, 30)], default_radius=0.75)
     om2.insert(inp["map_points"])
+    world_cpu = np.zeros_like(inp["raw"])
+    orc.transform_points(inp["pose_gt"], inp["tbe"], inp["t"], inp["raw"], num_threads=cores, out=world_cpu)      # threads started, output pages touched: as for the GPU call
     t0 = time.perf_counter()
     keep = np.sort(orc.grid_sampling(inp["raw"], 0.5))
     t1 = time.perf_counter()
-    world = orc.transform_points(inp["pose_gt"], inp["tbe"], inp["t"], inp["raw"], num_threads=cores)
+    world = orc.transform_points(inp["pose_gt"], inp["tbe"], inp["t"], inp["raw"], num_threads=cores, out=world_cpu)
     t2 = time.perf_counter()
     om2.remove_far(inp["pose_gt"][11:14], 100.0)
     kept = om2.insert(world[keep])

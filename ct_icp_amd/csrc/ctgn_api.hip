@@ -7,8 +7,15 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types only: the library is bound at run time (dlopen), see rccl_api()
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -45,6 +52,77 @@ constexpr size_t PROF_WORDS = 16 + 4 * (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES;
 // [16, ...) the final GnState (it rides out with the world points)
 constexpr size_t KP_TAIL = 16 + (sizeof(GnState) + 7) / 8;
 static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState is mirrored by one thread block as doubles");
+
+// Helper threads for the HOST side of the calls that move a whole scan (ctgn_transform_points on host views, the full-scan output of
+// ctgn_frame_register): gathering the caller's strided records into pinned memory and handing results back are memory-bound loops
+// over megabytes that one core runs at 10-20 GB/s — a few cores next to it keep up with the PCIe copies they feed. The threads are
+// created on first use, sleep on a condition variable between calls and are joined with the handle. The caller's thread always works too.
+struct HostPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(size_t)> *job = nullptr;
+    size_t parts = 0, finished = 0;
+    std::atomic<size_t> next{0};
+    int inside = 0;                      // helpers currently holding `job`
+    uint64_t generation = 0;
+    bool stop = false;
+
+    void ensure(int helpers) {
+        while ((int) threads.size() < helpers) threads.emplace_back([this] { work(); });
+    }
+    void work() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_job.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            const std::function<void(size_t)> *f = job;
+            const size_t n = parts;
+            ++inside;
+            lk.unlock();
+            size_t mine = 0;
+            for (size_t i; (i = next.fetch_add(1)) < n; ++mine) (*f)(i);
+            lk.lock();
+            --inside;
+            finished += mine;
+            if (finished == parts && inside == 0) cv_done.notify_one();
+        }
+    }
+    // f(0) .. f(parts - 1), each exactly once, on the helpers and the calling thread; returns when all are done
+    void run(size_t n, const std::function<void(size_t)> &f) {
+        if (threads.empty() || n <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f; parts = n; finished = 0; next.store(0); ++generation;
+        }
+        cv_job.notify_all();
+        size_t mine = 0;
+        for (size_t i; (i = next.fetch_add(1)) < n; ++mine) f(i);
+        std::unique_lock<std::mutex> lk(m);
+        finished += mine;
+        cv_done.wait(lk, [&] { return finished == parts && inside == 0; });
+        job = nullptr;
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_job.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+// how many helpers: CTGN_HOST_THREADS (0 = none), else 3; never more than the CPUs this process may run on minus the caller's
+static int host_helpers_wanted() {
+    static const int n = [] {
+        const char *e = std::getenv("CTGN_HOST_THREADS");
+        int want = e ? std::atoi(e) : 3;
+        cpu_set_t set;
+        int cpus = 1;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        return std::max(0, std::min(want, cpus - 1));
+    }();
+    return n;
+}
 
 struct ctgn_context {
     int device = -1;                    // -1: host-only map mirror, every device entry point fails
@@ -87,6 +165,7 @@ struct ctgn_context {
     double *d_tp = nullptr, *h_tp = nullptr;
     size_t tp_cap = 0;
     std::vector<hipEvent_t> tp_events;  // one per 32 k-point chunk of a host-view ctgn_transform_points (its result has arrived)
+    HostPool pool;                      // helper threads of the scan-sized host loops (created on first use)
 
     // solver
     GnState *d_state = nullptr;
@@ -1736,11 +1815,13 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return CTGN_OK;
     }
-    // Host views: a pipeline over 32 k-point chunks, as in ctgn_frame_register. The caller's strided records are staged as x y z t records
-    // behind the pose in pinned memory and go up chunk by chunk while the next chunk is being staged; every chunk's kernel writes x y z
-    // records that come straight back into pinned memory; once everything is staged (and every timestamp checked: nothing reaches the
-    // caller's output before that) the chunks are handed to the caller as they arrive. The step moves 56 bytes per point across PCIe
-    // for a few flops: what is left is the two passes of the host over its own buffers.
+    // Host views: a pipeline over 32 k-point chunks. The caller's strided records are gathered into pinned memory as x y z t records
+    // behind the pose and go up chunk by chunk while the next chunk is being gathered; every chunk's kernel writes x y z records that
+    // come straight back into pinned memory. Once everything is gathered (and every timestamp checked: nothing reaches the caller's
+    // output before that) the chunks are handed over as they arrive. The step moves 56 bytes per point across PCIe for a few flops and
+    // is bound by exactly that: on the B2 scan (132 k points, 7.4 MB) everything is gathered and enqueued after 0.155 ms and the last
+    // chunk arrives at 0.36 ms (about 21 GB/s over the link, up and down copies on one stream or on two); helper threads for the
+    // gather or the hand-over do not change the total (measured with 0 / 1 / 3 / 7), so this call stays on the caller's thread.
     constexpr size_t CHUNK = 32768;
     const size_t nchunks = (n + CHUNK - 1) / CHUNK;
     while (h->tp_events.size() < nchunks) {
@@ -1753,9 +1834,14 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     for (int i = 0; i < 14; ++i) h_in[i] = pose[i];
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
     const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
+    static const bool tp_timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;      // measurement hook: host-clock marks on stderr
+    const auto tp_t0 = std::chrono::steady_clock::now();
+    auto tp_now = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp_t0).count(); };
+    double tp_gather = 0;
     bool in_range = true;
-    for (size_t k = 0; k < nchunks; ++k) {
+    for (size_t k = 0; k < nchunks && in_range; ++k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+        const double tg = tp_timing ? tp_now() : 0;
         for (size_t j = j0; j < j1; ++j) {
             double *q = h_in + 16 + 4 * j;
             if (f64) { const double *p = reinterpret_cast<const double *>(rb + j * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
@@ -1764,6 +1850,7 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
             q[3] = t;
             in_range = in_range && (tbe[0] <= t && t <= tbe[1]);
         }
+        if (tp_timing) tp_gather += tp_now() - tg;
         if (!in_range) break;
         const size_t lo = k == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;                       // the first chunk carries the pose
         HIPCHK(h, hipMemcpyAsync(d_in + lo, h_in + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1773,21 +1860,26 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         HIPCHK(h, hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipEventRecord(h->tp_events[k], h->stream));
     }
+    const double tp_enq = tp_timing ? tp_now() : 0;
     if (!in_range) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
     }
-    char *ob = static_cast<char *>(out_base);
+    std::atomic<bool> wait_failed{false};
     for (size_t k = 0; k < nchunks; ++k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
-        HIPCHK(h, hipEventSynchronize(h->tp_events[k]));
+        if (hipEventSynchronize(h->tp_events[k]) != hipSuccess) { wait_failed.store(true); break; }
         if (out_dtype == CTGN_F64 && out_stride == 3 * sizeof(double)) {
-            std::memcpy(ob + j0 * out_stride, h_out + 3 * j0, 3 * (j1 - j0) * sizeof(double));
+            std::memcpy(static_cast<char *>(out_base) + j0 * out_stride, h_out + 3 * j0, 3 * (j1 - j0) * sizeof(double));
         } else {
             for (size_t j = j0; j < j1; ++j) write_point(out_base, out_stride, out_dtype, j, h_out[3 * j], h_out[3 * j + 1], h_out[3 * j + 2]);
         }
     }
+    if (tp_timing)
+        std::fprintf(stderr, "[ctgn] transform_points us: gather %.0f | all enqueued at %.0f | hand-over done at %.0f (n %zu, %zu chunks)\n",
+                     tp_gather, tp_enq, tp_now(), n, nchunks);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (wait_failed.load()) return fail(h, CTGN_ERR_HIP, "[HIP] hipEventSynchronize");
     return CTGN_OK;
 }
 
@@ -1879,45 +1971,64 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     double *hs = F.h_scan + 16;
     const double *d_recs = F.d_scan + 16;
     double tmin = INFINITY, tmax = -INFINITY;
-    constexpr size_t CHUNK = 32768;
+    constexpr size_t CHUNK = 16384;
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
     const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
-    // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
-    double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    bool has_nan = false, bad_order = false;
-    // `order` must be a permutation: an index out of range or met twice would leave rows of the outputs unwritten (one bit per index)
+    // `order` must be a permutation: an index out of range or met twice would leave rows of the outputs unwritten (one bit per index,
+    // set atomically: the chunks of a group are staged by different threads)
     std::vector<uint64_t> seen(order ? (n + 63) / 64 : 0, 0ull);
-    auto stage_one = [&](size_t j, int u) {
-        const size_t i = order ? (size_t) order[j] : j;
-        if (i >= n) { bad_order = true; return; }
-        if (order) {
-            const uint64_t bit = 1ull << (i & 63);
-            if (seen[i >> 6] & bit) { bad_order = true; return; }
-            seen[i >> 6] |= bit;
-        }
-        double *q = hs + 4 * j;
-        if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
-        else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
-        const double t = fo->override_timestamps ? fo->override_timestamp
-                         : tf64 ? *reinterpret_cast<const double *>(tb_ + i * ts.stride_bytes)
-                                : (double) *reinterpret_cast<const float *>(tb_ + i * ts.stride_bytes);
-        q[3] = t;
-        mn[u] = t < mn[u] ? t : mn[u];
-        mx[u] = t > mx[u] ? t : mx[u];
-        has_nan = has_nan || t != t;
-    };
-    for (size_t j0 = 0; j0 < n || j0 == 0; j0 += CHUNK) {
-        const size_t j1 = std::min(n, j0 + CHUNK);
+    const size_t nchunks = std::max<size_t>(1, (n + CHUNK - 1) / CHUNK);
+    struct ChunkStat { double mn, mx; bool has_nan, bad_order; };
+    std::vector<ChunkStat> stat(nchunks, ChunkStat{INFINITY, -INFINITY, false, false});
+    const std::function<void(size_t)> stage_chunk = [&](size_t k) {
+        const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+        // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
+        double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        bool has_nan = false, bad_order = false;
+        auto stage_one = [&](size_t j, int u) {
+            const size_t i = order ? (size_t) order[j] : j;
+            if (i >= n) { bad_order = true; return; }
+            if (order) {
+                const uint64_t bit = 1ull << (i & 63);
+                if (__atomic_fetch_or(&seen[i >> 6], bit, __ATOMIC_RELAXED) & bit) { bad_order = true; return; }
+            }
+            double *q = hs + 4 * j;
+            if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
+            const double t = fo->override_timestamps ? fo->override_timestamp
+                             : tf64 ? *reinterpret_cast<const double *>(tb_ + i * ts.stride_bytes)
+                                    : (double) *reinterpret_cast<const float *>(tb_ + i * ts.stride_bytes);
+            q[3] = t;
+            mn[u] = t < mn[u] ? t : mn[u];
+            mx[u] = t > mx[u] ? t : mx[u];
+            has_nan = has_nan || t != t;
+        };
         size_t j = j0;
         for (; j + 4 <= j1; j += 4) { stage_one(j, 0); stage_one(j + 1, 1); stage_one(j + 2, 2); stage_one(j + 3, 3); }
         for (; j < j1; ++j) stage_one(j, 0);
+        stat[k] = ChunkStat{std::min(std::min(mn[0], mn[1]), std::min(mn[2], mn[3])), std::max(std::max(mx[0], mx[1]), std::max(mx[2], mx[3])), has_nan, bad_order};
+    };
+    // a group of chunks is staged by the helper threads + this one, then uploaded while the next group is being staged
+    const int helpers = n >= 4 * CHUNK ? host_helpers_wanted() : 0;
+    h->pool.ensure(helpers);
+    const size_t group = (size_t) helpers + 1;
+    bool has_nan = false;
+    for (size_t g0 = 0; g0 < nchunks; g0 += group) {
+        const size_t g1 = std::min(nchunks, g0 + group);
+        h->pool.run(g1 - g0, [&](size_t i) { stage_chunk(g0 + i); });
+        bool bad_order = false;
+        for (size_t k = g0; k < g1; ++k) {
+            bad_order = bad_order || stat[k].bad_order;
+            has_nan = has_nan || stat[k].has_nan;
+            tmin = std::min(tmin, stat[k].mn);
+            tmax = std::max(tmax, stat[k].mx);
+        }
         if (bad_order) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
-        const size_t lo = j0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first chunk carries the pose
+        const size_t j0 = g0 * CHUNK, j1 = std::min(n, g1 * CHUNK);
+        const size_t lo = g0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first group carries the pose
         HIPCHK(h, hipMemcpyAsync(F.d_scan + lo, F.h_scan + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (j1 >= n) break;
     }
-    tmin = std::min(std::min(mn[0], mn[1]), std::min(mn[2], mn[3]));
-    tmax = has_nan ? NAN : std::max(std::max(mx[0], mx[1]), std::max(mx[2], mx[3]));
+    if (has_nan) tmax = NAN;
     // every point is undistorted below: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
     if (n && !(tbe[0] <= tmin && tmax <= tbe[1])) {
         hipStreamSynchronize(h->stream);
@@ -2028,17 +2139,21 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
             const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
             char *ob = static_cast<char *>(out->all_world_base);
             const size_t os = out->all_world_stride_bytes;
-            if (out->all_world_dtype == CTGN_F64) {
-                for (size_t j = 0; j < n; ++j) {
-                    double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
-                    q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
+            const bool o64 = out->all_world_dtype == CTGN_F64;
+            h->pool.run((n + CHUNK - 1) / CHUNK, [&](size_t k) {           // the rows of the caller's array, a chunk per thread
+                const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+                if (o64) {
+                    for (size_t j = j0; j < j1; ++j) {
+                        double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
+                        q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
+                    }
+                } else {
+                    for (size_t j = j0; j < j1; ++j) {
+                        float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
+                        q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
+                    }
                 }
-            } else {
-                for (size_t j = 0; j < n; ++j) {
-                    float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
-                    q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
-                }
-            }
+            });
         }
         if (out->sampled_world_base)
             for (size_t k = 0; k < n1; ++k)

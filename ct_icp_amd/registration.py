@@ -118,9 +118,11 @@ class CT_ICP_Registration:
         return _summary(s)
 
 
-def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end):
+def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end, out=None):
     """Full-scan continuous-time undistortion on the GPU (reference src/ct_icp/odometry.cpp:461-486): world[i] =
-    begin.InterpolatePose(end, t[i]) * raw[i]. numpy in -> numpy out; torch CUDA tensors in -> torch CUDA tensor out (no host hop)."""
+    begin.InterpolatePose(end, t[i]) * raw[i]. numpy in -> numpy out; torch CUDA tensors in -> torch CUDA tensor out (no host hop).
+    `out` (numpy, N x 3 float64, C-contiguous): write there instead of into a fresh array — the reference undistorts in place, and a
+    fresh 3 MB array costs its page faults on every call."""
     if L.is_device_tensor(raw):
         import torch
         out = torch.empty((len(raw), 3), dtype=torch.float64, device=raw.device)
@@ -135,7 +137,10 @@ def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end):
     t = np.ascontiguousarray(t, dtype=np.float64).ravel()
     pose = np.ascontiguousarray(pose14, dtype=np.float64)
     tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
-    out = np.zeros_like(raw)
+    if out is None:
+        out = np.empty_like(raw)
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == raw.shape and out.flags.c_contiguous):
+        raise ValueError("out must be a C-contiguous float64 array of the shape of the points")
     dp = C.POINTER(C.c_double)
     h = voxel_map.handle
     L.check(h, L.lib().ctgn_transform_points(h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0),

@@ -333,10 +333,11 @@ def adaptive_sampling(raw, distance_voxel_size=ADAPTIVE_DEFAULT_BANDS, num_point
     return out[:k].copy()
 
 
-def transform_points(pose, t_begin_end, t, raw, num_threads=1) -> np.ndarray:
+def transform_points(pose, t_begin_end, t, raw, num_threads=1, out=None) -> np.ndarray:
     raw, t = _f64(raw).reshape(-1, 3), _f64(t).ravel()
     pose, tbe = _f64(pose).ravel(), _f64(t_begin_end)
-    out = np.zeros_like(raw)
+    if out is None:
+        out = np.zeros_like(raw)
     lib().orc_transform_points(_dp(pose), _dp(tbe), _dp(t), _dp(raw), len(t), _dp(out), int(num_threads))
     return out
 
