@@ -1,6 +1,8 @@
 """SURVEY.md section 5's sanitizer row: the CPU oracle (the checker) and the product's host-side map mirror under
 -fsanitize=address,undefined with every report fatal (`make -C oracle asan`: oracle/asan_oracle.c drives the oracle through its whole
-surface, oracle/asan_host_mirror.cpp fuzzes ct_icp_amd/csrc/ctgn_map.hpp against a std::map model). CPU only."""
+surface, oracle/asan_host_mirror.cpp fuzzes ct_icp_amd/csrc/ctgn_map.hpp against a std::map model), and the product's helper-thread
+pool of the host-side staging loops (ct_icp_amd/csrc/ctgn_hostpool.hpp) under the thread sanitizer and under address + undefined
+(oracle/tsan_hostpool.cpp: every part exactly once, nothing touched after run() returns). CPU only."""
 import os
 import subprocess
 
@@ -22,3 +24,11 @@ def test_sanitized_program_runs_clean(asan_build, program):
     r = subprocess.run([os.path.join(asan_build, program)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert f"{program} ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+@pytest.mark.parametrize("program", ["tsan_hostpool", "asan_hostpool"])
+def test_host_pool_runs_clean_under_sanitizers(asan_build, program):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([os.path.join(asan_build, program)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "hostpool ok" in r.stdout and "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
