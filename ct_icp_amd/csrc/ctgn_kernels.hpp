@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             } else {
             // ===== generic path: every row probes and streams its own keypoint's neighbourhood =====
             st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
-            const double r2bound = kth_d2;        // the probes are culled against the bound the round starts with
+            const double r2bound = kth_d2;        // the probes are culled against the bound the round starts with (27-voxel sweep: both batches)
             const uint32_t mreach = W.mr[src];
             if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
@@ -1210,7 +1210,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 Probe cur = nxt;
                 const int cur_v = nxt_v;
                 if (it + 1 < VIT) {
-                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
+                    // (against the row's CURRENT bound: on the 125-voxel sweep a first search knows its k-th best after the first batch or
+                    // two, and the remaining batches then probe only the voxels that bound can still reach instead of every voxel
+                    // within the radius — hash probes into a map larger than the caches are what that sweep waits for)
+                    nxt = issue_batch<NB>(map, it + 1, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, NB == 2 ? fmin(r2bound, kth_d2) : r2bound, mreach);
                 } else if (r + 1 < search_rounds) {
                     const int slot2 = slot_of(r + 1, row);
                     const int src2 = slot2 == 255 ? row * 16 : slot2;

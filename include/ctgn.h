@@ -479,9 +479,10 @@ ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t la
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 /* Measurement hook: skip phases of the row kernel (bit 0 candidate streaming, 1 final selection, 2 hand-over records,
  * 3 normal/residual/Jacobian, 4 hash probes, 5 shared-home-voxel path (variant 5), 6 radius cull of the probes off, 7 no list
- * appends, 8 no carried-over bound, 9 no slab masks, 10 no rounds at all = phase A only). Results are INVALID while a mask is set —
- * except bits 5, 6, 8 and 9, which only switch exact optimisations off — and a starved solve keeps launching the search so that
- * it can be timed (ablation profiling, DESIGN.md section 13, scripts/ablate2.sh). */
+ * appends, 8 no carried-over bound and no pools, 9 no slab masks, 10 no rounds at all = phase A only, 11 no neighbour pools,
+ * 12-15 spare pool members instead of 8 (1..12)). Results are INVALID while a mask is set — except bits 5, 6, 8, 9 and 11-15, which only
+ * switch exact optimisations off or tune them — and a starved solve keeps launching the search so that it can be timed (ablation
+ * profiling, DESIGN.md sections 13 and 17, scripts/ablate2.sh, scripts/iter_times.py). */
 ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
 /* Keypoint ordering of the GN kernels: -1 = automatic (default), 0 = never, 1 = always. When ordered, the kernels work through
  * the upload in home-voxel order (positions sorted once per upload on the device, the kernels iterate on a position-ordered
