@@ -410,16 +410,6 @@ ctgn_status sync_level(ctgn_handle h, int li) {
     return CTGN_OK;
 }
 
-// MapView::r2adm: how far beyond the radius the row kernels collect candidates. The sweep of (2 nb + 1)^3 voxels round the query's own is
-// certain to hold every point within nb * resolution of it (Voxel::Coordinates truncates, src/SlamCore/types.cxx:13-20: the voxels of
-// index 0 are the wide ones), which is >= the radius by the choice of nb (map.h:416-432); 7 % of the radius is plenty for the few
-// centimetres a keypoint moves between the searches of a solve.
-static double collect_sq_threshold(double r2thr, double radius, int nb, double res) {
-    static const double factor = std::getenv("CTGN_COLLECT") ? std::atof(std::getenv("CTGN_COLLECT")) : 1.0;     // measurement hook
-    const double reach = std::min((double) nb * res * (1.0 - 1e-9), radius * factor);
-    return (std::isfinite(reach) && reach * reach > r2thr) ? reach * reach : r2thr;
-}
-
 ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     if (radius <= 0) radius = h->opts.default_radius;
     int map_id, nb;
@@ -436,7 +426,6 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
         mv->nb = nb;
         mv->resolution = res;
         mv->r2thr = radius_sq_threshold(radius);
-        mv->r2adm = collect_sq_threshold(mv->r2thr, radius, nb, res);
         return CTGN_OK;
     }
     ctgn_status st = sync_level(h, map_id);
@@ -450,7 +439,6 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
     mv->nb = nb;
     mv->resolution = res;
     mv->r2thr = radius_sq_threshold(radius);
-    mv->r2adm = collect_sq_threshold(mv->r2thr, radius, nb, res);
     return CTGN_OK;
 }
 
@@ -636,8 +624,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         // one instantiation per (sweep half-width, selection flavour, instrumentation, waves per SIMD)
         auto launch = [&](auto kernel, size_t smem, unsigned long long *prof) {
             const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
-            static const int env_rounds_later = [] { const char *e = std::getenv("CTGN_ROUNDS_LATER"); return e ? std::atoi(e) : 0; }();   // measurement hook
-            const int rounds = (kv.kth_valid && env_rounds_later > 0) ? std::min(16, env_rounds_later) : pick_rounds(h->n_kp, rb * ROW_WAVES);
+            const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
             static const int env_xcd = [] { const char *e = std::getenv("CTGN_XCD_SPLIT"); return e ? std::atoi(e) : -1; }();     // measurement hook

@@ -45,9 +45,6 @@ struct MapView {
     int nb;                  // sweep half-width (voxel_neighborhood)
     double resolution;
     double r2thr;            // radius_sq_threshold(radius)
-    double r2adm;            // row kernels: candidates are COLLECTED up to this squared distance (>= r2thr, inside the sweep's guaranteed
-                             // reach nb * resolution); neighbours are those within r2thr. The margin is what lets a keypoint with fewer
-                             // than k neighbours keep a pool that is known to be complete beyond the radius (rows_tiles, phase V)
 };
 
 struct KpView {
@@ -952,7 +949,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 R.d2[sub + 16] = sq_norm3(pts_cur.x1 - qx, pts_cur.y1 - qy, pts_cur.z1 - qz); R.vis[sub + 16] = (uint32_t) (sub + 16);
                 T[sub] = rec_cur.o0; T[sub + 16] = rec_cur.o1;
                 bool tie = false;
-                row_select<HIST>(R, m, KMAX, sub, row, map.r2adm, tie);     // the whole pool, sorted by its distances to the new position
+                row_select<HIST>(R, m, KMAX, sub, row, map.r2thr, tie);     // the whole pool, sorted by its distances to the new position
                 const double s0 = R.d2[sub], s1 = R.d2[sub + 16];
                 const int n_in = row_sum_i32(((v0 && s0 <= map.r2thr) ? 1 : 0) + ((v1 && s1 <= map.r2thr) ? 1 : 0));   // map.h:491-493
                 const int n = min(n_in, k);
@@ -996,7 +993,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         const int kxv = W.kx[lane], kyv = W.ky[lane], kzv = W.kz[lane];
         if (searched && kxv != INT_MIN) {
             const double px = W.px[lane], py = W.py[lane], pz = W.pz[lane];
-            const double bnd = fmin(map.r2adm, (double) W.kb[lane]) * (1.0 + 1e-8) + 1e-12;
+            const double bnd = fmin(map.r2thr, (double) W.kb[lane]) * (1.0 + 1e-8) + 1e-12;
 #pragma unroll
             for (int o = -NB; o <= NB; ++o) {
                 if (o == 0) continue;
@@ -1056,11 +1053,11 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             const uint32_t lt_mask = (1u << sub) - 1u;
             int Ln = 0;
             // admission bound of the stream: the radius or the bound carried over from the previous search, then the k-th best so far
-            double kth_d2 = fmin(map.r2adm, (double) W.kb[src]);
+            double kth_d2 = fmin(map.r2thr, (double) W.kb[src]);
             // A search that starts with a bound (carried over from the previous one) keeps a pool: its bound exceeds the new k-th distance by
             // about the distance the keypoint has moved, so nearly everything it admits comes for free. A search bounded by the radius only
             // would have to carry the spare members through every cut of its long stream: it keeps the k neighbours and leaves no pool.
-            const int kpool = (double) W.kb[src] < map.r2adm ? pool_cap : k;
+            const int kpool = (double) W.kb[src] < map.r2thr ? pool_cap : k;
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
@@ -1160,7 +1157,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         CTGN_TICK(2)
                         Ln = row == 0 ? L[0] : row == 1 ? L[1] : row == 2 ? L[2] : L[3];
                         Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
-                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             L[j] = __builtin_amdgcn_readlane(Ln, 16 * j);
@@ -1219,7 +1216,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     const int src2 = slot2 == 255 ? row * 16 : slot2;
                     const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2];
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
-                                          fmin(map.r2adm, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
+                                          fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
                 if (PROF) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
@@ -1233,7 +1230,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // 125-voxel sweep (8 probe batches): on the 27-voxel sweep (2 batches) the extra selection costs more than the
                 // culled chunks save (B2: 0.094 -> 0.105 ms per launch), on the 125-voxel one it wins (D: 3.11 -> 2.31 ms).
                 bool within_kth = true;
-                if (NB == 2 && it > 0 && kth_d2 < map.r2adm) {
+                if (NB == 2 && it > 0 && kth_d2 < map.r2thr) {
                     const int vv = (cur_v == 255) ? 0 : cur_v;
                     const double gx = axis_gap(qx, kx + vv / (S * S) - NB, map.resolution), gy = axis_gap(qy, ky + (vv / S) % S - NB, map.resolution),
                                  gz = axis_gap(qz, kz + vv % S - NB, map.resolution);
@@ -1288,7 +1285,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         // list nearly full somewhere in the wave: cut every row back to its k best
                         CTGN_TICK(2)
                         Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
-                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
                         CTGN_TICK(3)
                     }
                 }
@@ -1297,9 +1294,9 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
-                if (NB == 2 && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2adm))) {
+                if (NB == 2 && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2thr))) {
                     Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
-                    if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2adm);
+                    if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
                     CTGN_TICK(3)
                 }
             }
@@ -1330,12 +1327,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             const int admitted = Ln;
             if (!(ablate & 2) && any64(row_needed)) Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
             const int m = min(Ln, kpool);          // pool: what the record keeps, sorted nearest first
-            // the neighbours: the k nearest of those within the radius (the list was collected up to r2adm >= r2thr; map.h:491-493)
-            int n = min(Ln, k);
-            if (map.r2adm > map.r2thr && !(ablate & 2) && any64(row_needed)) {
-                const double s0 = R.d2[sub], s1 = R.d2[sub + 16];
-                n = min(k, row_sum_i32(((sub < m && s0 <= map.r2thr) ? 1 : 0) + ((sub + 16 < m && s1 <= map.r2thr) ? 1 : 0)));
-            }
+            const int n = min(Ln, k);              // the neighbours (every list entry lies within the radius, map.h:491-493)
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, nearest first
             // (the reference's neighbour vector is the same set farthest first: its readers walk the record backwards), in a
