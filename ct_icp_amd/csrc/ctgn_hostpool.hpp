@@ -38,6 +38,7 @@ struct HostPool {
             seen = generation;
             const std::function<void(size_t)> *f = job;
             const size_t n = parts;
+            if (!f) continue;                // woke up after that run had already finished (its caller did the work): nothing to join
             ++inside;
             lk.unlock();
             size_t mine = 0;
@@ -52,7 +53,10 @@ struct HostPool {
     void run(size_t n, const std::function<void(size_t)> &f) {
         if (threads.empty() || n <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
         {
-            std::lock_guard<std::mutex> lk(m);
+            // a helper holds (job, parts) from the moment it has read them under the lock until it leaves (`inside`): run() does not return
+            // before that, so nothing is published while a helper of an earlier run could still claim an index
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return inside == 0; });
             job = &f; parts = n; finished = 0; next.store(0); ++generation;
         }
         cv_job.notify_all();
