@@ -1173,6 +1173,12 @@ def test_full_size_b2_sweep_matches_oracle(config_b_full, search_kernel):
     tr, rot = se3.pose_error(pose5, pose_o)
     assert tr < 1e-7 and rot < 1e-7, (tr, rot)
     assert np.abs(s.world_points() - world_o).max() < 1e-7
+    # at this size the later iterations run on neighbour pools: searching every iteration instead gives the same bits
+    w5 = s.world_points()
+    s.set_pools(0)
+    s.set_keypoints(sc.raw, world0, sc.t)
+    pose5_np, summ5_np, _ = s.solve(pose0, sc.t_begin_end, o5, mm)
+    assert np.array_equal(pose5, pose5_np) and np.array_equal(w5, s.world_points()) and summ5.num_residuals_used == summ5_np.num_residuals_used
 
 
 @pytest.mark.parametrize("mode", ["rows", "rows_plain_rank", "lane"])
@@ -1379,6 +1385,12 @@ def test_config_d_ouster_scan_matches_oracle():
         assert summ5.num_iters == so5.num_iters == 5 and summ5.num_residuals_used == so5.num_residuals_used
         tr, rot = se3.pose_error(pose5, pose_o5)
         assert tr < TIGHT and rot < TIGHT, (tr, rot)
+        # iterations 3-5 ran on neighbour pools (99.9 % of the keypoints certified on this scan): searching every iteration gives the same bits
+        w5 = s.world_points()
+        s.set_pools(0)
+        s.set_keypoints(raw, world0, t)
+        pose5_np, summ5_np, _ = s.solve(pose0, inp["tbe"], o5)
+        assert np.array_equal(pose5, pose5_np) and np.array_equal(w5, s.world_points()) and summ5_np.num_residuals_used == summ5.num_residuals_used
 
 
 # ------------------------------------------------------------------------------------------------- two GPUs (skipped on a 1-GPU box)
