@@ -643,15 +643,15 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();
             switch (h->variant) {
-                case 2: launch(k_accumulate_rows<1, false, false, 3>, sm, nullptr); break;
+                case 2: launch(k_accumulate_rows<1, false, false, 3, false, false>, sm, nullptr); break;
                 case 3: launch(k_accumulate_rows<1, true, true, 3>, sm, h->d_prof); break;
-                case 4: launch(k_accumulate_rows<1, true, false, 4>, sm, nullptr); break;
-                case 5: launch(k_accumulate_rows<1, true, false, 3, true>, sm, nullptr); break;      // with the shared-home-voxel path (A/B hook)
+                case 4: launch(k_accumulate_rows<1, true, false, 4, false, false>, sm, nullptr); break;
+                case 5: launch(k_accumulate_rows<1, true, false, 3, true, false>, sm, nullptr); break;      // with the shared-home-voxel path (A/B hook)
                 default: launch(k_accumulate_rows<1, true, false, 3>, sm, nullptr); break;
             }
         } else {
             const size_t sm = rows_kernel_smem<2>();
-            if (h->variant == 2) launch(k_accumulate_rows<2, false, false, 3>, sm, nullptr);
+            if (h->variant == 2) launch(k_accumulate_rows<2, false, false, 3, false, false>, sm, nullptr);
             else if (h->variant == 3) launch(k_accumulate_rows<2, true, true, 3>, sm, h->d_prof);
             else launch(k_accumulate_rows<2, true, false, 3>, sm, nullptr);
         }

@@ -807,7 +807,7 @@ __device__ __forceinline__ bool rows_share_home(int kx, int ky, int kz) {
 // The tile loop of the row search: the body of k_accumulate_rows, and — with `after_tile`, called by the whole wave when a tile's
 // rounds are done, while W.id[] still names the tile's keypoints — of the persistent small-frame kernel (k_gn_persistent), which runs
 // the residual part for the same keypoints right there.
-template <int NB, bool HIST, bool PROF, bool SHARED, typename AfterTile>
+template <int NB, bool HIST, bool PROF, bool SHARED, bool POOLS, typename AfterTile>
 __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
                                            int first_iter, int rounds, unsigned long long *prof, int ablate, char *smem, int tile_first, int tile_end,
                                            int tile_step, AfterTile after_tile) {
@@ -819,7 +819,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     SharedStage &SH = W.stage;
     const int k = prm.max_nb;
     // pool: how many of a search's nearest candidates the keypoint's record keeps (the k neighbours + spare ones), see phase V
-    const int pool_cap = ((ablate & 2048) || !kp.pools) ? k : min(KMAX, k + (((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : POOL_EXTRA));
+    const int pool_cap = (!POOLS || (ablate & 2048) || !kp.pools) ? k : min(KMAX, k + (((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : POOL_EXTRA));
     const bool pool_on = pool_cap > k;
     const int blk = map.blk;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
@@ -911,7 +911,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // gathered points and one selection instead of the hash probes and the ~120 streamed candidates of a search. Exactly the same
         // set in the same order: the certificate is conservative (directed roundings), and a keypoint it does not cover takes the
         // search below, bounded by its pool.
-        if (pool_on && kp.kth_valid && !first_iter && !(ablate & 256) && any64(W.rr2[lane] > 0.f)) {
+        if (POOLS && pool_on && kp.kth_valid && !first_iter && !(ablate & 256) && any64(W.rr2[lane] > 0.f)) {
             compact = true;
             uint32_t *T = reinterpret_cast<uint32_t *>(RP.chunk);            // the row's pool: point byte offsets by pool index
             struct PoolRec { uint32_t hdr, o0, o1; };
@@ -1386,8 +1386,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
 #undef CTGN_TICK
 }
 
-// NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles.
-template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false>
+// NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles; POOLS = compile the
+// pool check (phase V) in: off for the A/B instantiations and the small-frame persistent kernel, which never see a frame large enough
+// to use it and would only carry its registers.
+template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
                                                                unsigned long long *prof = nullptr, int ablate = 0) {
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         tile_end = min(ntiles, (x + 1) * per);
         tile_step = blocks_on_x * ROW_WAVES;
     }
-    rows_tiles<NB, HIST, PROF, SHARED>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
+    rows_tiles<NB, HIST, PROF, SHARED, POOLS>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
 }
 
 template <int NB>
@@ -1946,7 +1948,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 2) void k_gn_persistent(MapView map, KpV
         WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> &W =
             reinterpret_cast<WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> *>(smem)[wave];
         // search of a tile, then — same wave, keypoints still named by W.id — its residual part: lane l takes keypoint W.id[l]
-        rows_tiles<NB, true, false, false>(map, kv, &P.state, prm, dbg, (iters_before + it) == 0 ? 1 : 0, rounds, nullptr, 0, smem,
+        rows_tiles<NB, true, false, false, false>(map, kv, &P.state, prm, dbg, (iters_before + it) == 0 ? 1 : 0, rounds, nullptr, 0, smem,
                                            b * ROW_WAVES + wave, ntiles, nblk * ROW_WAVES, [&](int) {
             const int id = W.id[lane];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2
