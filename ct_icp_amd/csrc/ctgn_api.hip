@@ -107,7 +107,8 @@ struct ctgn_context {
     // undistortion staging (ctgn_transform_points): 7 x tp_cap doubles on the device, 4 x tp_cap pinned
     double *d_tp = nullptr, *h_tp = nullptr;
     size_t tp_cap = 0;
-    std::vector<hipEvent_t> tp_events;  // one per 32 k-point chunk of a host-view ctgn_transform_points (its result has arrived)
+    std::vector<hipEvent_t> tp_events;  // per 32 k-point chunk of a host-view ctgn_transform_points: its result has arrived | its kernel is done
+    hipStream_t stream_down = nullptr;  // results travel back on their own stream, beside the uploads of the chunks behind them
     HostPool pool;                      // helper threads of the scan-sized host loops (created on first use)
 
     // solver
@@ -899,6 +900,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_tp) hipFree(h->d_tp);
         if (h->h_tp) hipHostFree(h->h_tp);
         for (auto &e : h->tp_events) hipEventDestroy(e);
+        if (h->stream_down) hipStreamDestroy(h->stream_down);
         if (h->d_res) hipFree(h->d_res);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
@@ -1747,14 +1749,15 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     }
     // Host views: a pipeline over 32 k-point chunks. The caller's strided records are gathered into pinned memory as x y z t records
     // behind the pose and go up chunk by chunk while the next chunk is being gathered; every chunk's kernel writes x y z records that
-    // come straight back into pinned memory. Once everything is gathered (and every timestamp checked: nothing reaches the caller's
-    // output before that) the chunks are handed over as they arrive. The step moves 56 bytes per point across PCIe for a few flops and
-    // is bound by exactly that: on the B2 scan (132 k points, 7.4 MB) everything is gathered and enqueued after 0.155 ms and the last
-    // chunk arrives at 0.36 ms (about 21 GB/s over the link, up and down copies on one stream or on two); helper threads for the
-    // gather or the hand-over do not change the total (measured with 0 / 1 / 3 / 7), so this call stays on the caller's thread.
+    // come back into pinned memory on a second stream, beside the uploads of the chunks behind them. Once everything is gathered (and
+    // every timestamp checked: nothing reaches the caller's output before that) the chunks are handed over as they arrive. The step
+    // moves 56 bytes per point across PCIe for a few flops. Measured on the B2 scan (132 k points, 7.4 MB; CTGN_FRAME_TIMING marks):
+    // gathered and enqueued after 0.17 ms, handed over at 0.28 ms; on one stream 0.35 ms (the copies then queue behind one another);
+    // 16 k chunks cost more in runtime calls than they gain in overlap (0.39 ms); helper threads for the hand-over do not pay (0.30 ms).
     constexpr size_t CHUNK = 32768;
     const size_t nchunks = (n + CHUNK - 1) / CHUNK;
-    while (h->tp_events.size() < nchunks) {
+    if (!h->stream_down) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+    while (h->tp_events.size() < 2 * nchunks) {
         hipEvent_t e = nullptr;
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->tp_events.push_back(e);
@@ -1787,12 +1790,16 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         hipLaunchKernelGGL(k_transform_points, dim3(grid_for(j1 - j0)), dim3(256), 0, h->stream, d_in + 16 + 4 * j0, d_out + 3 * j0, (int) (j1 - j0), (size_t) 1,
                            d_in, tbe[0], tbe[1], (const uint32_t *) nullptr, (size_t) 0, (size_t) 4, 1);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipEventRecord(h->tp_events[k], h->stream));
+        // the result travels back on a second stream, beside the uploads of the chunks behind it
+        HIPCHK(h, hipEventRecord(h->tp_events[nchunks + k], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_down, h->tp_events[nchunks + k], 0));
+        HIPCHK(h, hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream_down));
+        HIPCHK(h, hipEventRecord(h->tp_events[k], h->stream_down));
     }
     const double tp_enq = tp_timing ? tp_now() : 0;
     if (!in_range) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream_down));
         return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
     }
     std::atomic<bool> wait_failed{false};
@@ -1808,6 +1815,7 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     if (tp_timing)
         std::fprintf(stderr, "[ctgn] transform_points us: gather %.0f | all enqueued at %.0f | hand-over done at %.0f (n %zu, %zu chunks)\n",
                      tp_gather, tp_enq, tp_now(), n, nchunks);
+    HIPCHK(h, hipStreamSynchronize(h->stream_down));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (wait_failed.load()) return fail(h, CTGN_ERR_HIP, "[HIP] hipEventSynchronize");
     return CTGN_OK;
