@@ -655,7 +655,8 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         // padding), which order like their bit patterns as unsigned integers, so "other < mine" is the borrow of an unsigned subtract
         // (VOP2, which takes a DPP source; compares do not on this part) and goes into the rank with one add-with-carry. Hand-placed
         // (the compiler materialises every rotated key with a v_mov_dpp and pairs compares through v_cndmask): 8 instructions per step
-        // instead of 12. s_nop 1: VALU write of VCC -> VALU read of VCC as carry-in.
+        // instead of 12. s_nop 1: VALU write of VCC -> VALU read of VCC as carry-in needs two wait states on this part (the compiler
+        // puts the same s_nop 1 between its own v_sub_co / v_subb pairs; inline assembly is not seen by its hazard recogniser).
 #define CTGN_RANK_CMP(S, OTHER, MINE, RANK)                                                                                       \
         asm volatile("v_sub_co_u32_dpp %1, vcc, %2, %3 row_ror:" #S " row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" \
                      : "+v"(RANK), "=&v"(scratch_) : "v"(OTHER), "v"(MINE) : "vcc");
