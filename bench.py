@@ -629,6 +629,7 @@ def main():
                     help="home-voxel ordering of the GN kernels' work (ctgn_set_ordering); auto = the library's cost model")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic, wait fractions)")
     ap.add_argument("--no-extras", action="store_true", help="skip frames/s, robust route, frame stages")
+    ap.add_argument("--detail-stdout", action="store_true", help="also print the full detail object as an EARLIER stdout line (default: files only)")
     ap.add_argument("--clock-warm", type=int, default=CLOCK_WARM)
     ap.add_argument("--inner", action="store_true", help="the run the PMC passes profile: timed loop only, no extras")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -794,10 +795,127 @@ def main():
             result["weak_scaling_line"] = {"value": float(nw.item()) * args.steps / float(tw.item()), "ms_per_step": float(tw.item()) / args.steps * 1e3,
                                            "keypoints_per_gpu": int(len(Ww["t"])), "workload": "B2-small sweep per rank, sharded loop", "scaling": "weak"}
     if rank == 0:
-        print(json.dumps(result, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)), flush=True)
+        emit(result, args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+DETAIL_NAME = "bench_detail.json"
+LINE_LIMIT = 4096              # the driver keeps a tail of its child's output: the line it parses must fit well inside it
+
+
+def _round(o, sig=5):
+    """Numbers to `sig` significant digits (the line is a record, not an archive); NaN / inf -> None: strict JSON only."""
+    if isinstance(o, bool) or o is None or isinstance(o, str):
+        return o
+    if isinstance(o, (int, np.integer)):
+        return int(o)
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        if f != f or f in (float("inf"), float("-inf")):
+            return None
+        return float(f"{f:.{sig}g}")
+    if isinstance(o, dict):
+        return {k: _round(v, sig) for k, v in o.items() if v is not None or k in ("vs_baseline", "traffic")}
+    if isinstance(o, (list, tuple, np.ndarray)):
+        return [_round(v, sig) for v in o]
+    return str(o)
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_counter_frac", "kernel_ms_avg", "alg_bytes_per_launch", "wait_frac",
+                "tcc_hit_rate", "valu_instructions_per_keypoint")
+    out.setdefault("traffic", None)
+    out["kernel"] = str(r.get("kernel", "")).split(" ")[0]
+    if isinstance(r.get("first_iteration"), dict):
+        out["first_iteration"] = _pick(r["first_iteration"], "kernel_ms", "frac")
+    if isinstance(r.get("later_iterations"), dict):
+        out["later_iterations"] = _pick(r["later_iterations"], "kernel_ms", "frac", "pool_certified_frac")
+    return out
+
+
+def _compact_cpu(c):
+    return _pick(c, "value", "unit", "cores", "kind", "single_thread_value") if isinstance(c, dict) else None
+
+
+def compact_line(result) -> str:
+    """The ONE stdout line of the contract: strict JSON, < LINE_LIMIT bytes. Headline keys, a compact `roofline` and `cpu_baseline`,
+    parity, frames/s, and per sub-workload {value, ms_per_step, frac, parity, cpu}. Everything else (definitions, notes, per-stage tables)
+    is in the detail file (`bench_detail.json`, next to this script and under gpurun_out/ when that directory exists)."""
+    line = _pick(result, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    cfg = result.get("config", {})
+    line["config"] = _pick(cfg, "workload_id", "keypoints_per_gpu", "keypoints_total", "map_points", "searched_level_mb", "iterations_per_solve")
+    line["config"]["workload"] = {"B2": "config B2 = BASELINE.json configs[1]: synthetic HDL-64E sweep, every return a keypoint, driving-profile map 0.8 m x 30 pts, "
+                                        "radius 0.75 (27 voxels), k=20, 5-iteration fresh solves",
+                                  "D": "config D = BASELINE.json configs[3]: Ouster-128-style 2.1 M-ray scan, 0.05 m grid keypoints, map 0.5 m x 40 pts within "
+                                       "100 m, radius 0.8 (125 voxels), k=20"}.get(cfg.get("workload_id"), str(cfg.get("workload", ""))[:160])
+    if "parallelism" in cfg:
+        line["config"]["parallelism"] = str(cfg["parallelism"])[:120]
+    line["roofline"] = _compact_roofline(result.get("roofline"))
+    line["cpu_baseline"] = _compact_cpu(result.get("cpu_baseline"))
+    if isinstance(result.get("cpu_baseline"), dict) and "sample" in result["cpu_baseline"]:
+        line["cpu_baseline"]["sample"] = str(result["cpu_baseline"]["sample"])[:150]
+    for k in ("parity_m_rad", "gpu_over_cpu", "first_iteration_ms", "later_iteration_ms", "strong_scaling_efficiency"):
+        if k in result:
+            line[k] = result[k]
+    if isinstance(result.get("frames_per_sec"), dict):
+        line["frames_per_sec"] = _pick(result["frames_per_sec"], "value", "ms_per_frame", "keypoints")
+    if isinstance(result.get("robust_route"), dict):
+        line["robust_route"] = _pick(result["robust_route"], "value", "ms_per_frame")
+    if isinstance(result.get("frame_pipeline"), dict):
+        line["frame_pipeline"] = _pick(result["frame_pipeline"], "frame_ms", "register_ms", "update_map_ms", "frames_per_sec")
+    if isinstance(result.get("config_e"), dict):
+        line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures")
+    for k in ("strong_scaling_single_gpu_reference", "weak_scaling_line"):
+        if isinstance(result.get(k), dict):
+            line[k] = _pick(result[k], "value", "ms_per_step", "keypoints", "keypoints_per_gpu", "scaling")
+    subs = {}
+    for name, w in (result.get("workloads") or {}).items():
+        s = _pick(w, "value", "ms_per_step", "keypoints", "parity_m_rad", "gpu_over_cpu")
+        r = w.get("roofline") or {}
+        s.update(_pick(r, "frac", "kernel_ms_avg", "traffic", "hbm_counter_frac", "wait_frac", "tcc_hit_rate"))
+        if isinstance(w.get("cpu_baseline"), dict):
+            s["cpu"] = _pick(w["cpu_baseline"], "value", "cores", "kind")
+        if isinstance(w.get("frames_per_sec"), dict):
+            s["frame_ms"] = w["frames_per_sec"].get("ms_per_frame")
+        if isinstance(w.get("robust_route"), dict):
+            s["robust_frame_ms"] = w["robust_route"].get("ms_per_frame")
+        subs[name] = s
+    if subs:
+        line["workloads"] = subs
+    line["detail"] = DETAIL_NAME
+    line = _round(line)
+    for k in ("value",):                                 # the headline keeps its digits
+        if isinstance(result.get(k), (int, float)):
+            line[k] = float(result[k])
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    while len(text) >= LINE_LIMIT and line.get("workloads"):      # never over the limit: shed sub-workloads last in, first out
+        line["workloads"].popitem()
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(result, args):
+    """Detail to files, the compact line — and nothing else — to stdout."""
+    detail = json.dumps(result, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_NAME if not args.inner else "bench_detail_inner.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+    if args.detail_stdout:
+        print(detail, flush=True)
+    print(compact_line(result), flush=True)
 
 
 def usable_cores() -> int:

@@ -1,0 +1,63 @@
+"""The driver parses the LAST stdout line of bench.py and keeps only a tail of the output (round 3's 24 KB line arrived cut and did not
+parse). The line bench.py prints is built by bench.compact_line(): strict JSON, < 4096 bytes, carrying the contract's keys plus a compact
+`roofline` and `cpu_baseline`; everything else goes to bench_detail.json. CPU tier: built from recorded results, no GPU."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _reject(name):
+    raise ValueError(f"non-strict JSON constant {name}")
+
+
+RECORDED = [os.path.join(ROOT, "profiles", f) for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if f.endswith(".json") and "bench" in f]
+
+
+def _load(path):
+    txt = open(path).read().strip().splitlines()[-1]
+    return json.loads(txt)
+
+
+@pytest.mark.parametrize("path", RECORDED, ids=[os.path.basename(p) for p in RECORDED])
+def test_compact_line_of_recorded_results(path):
+    import bench
+    d = _load(path)
+    if "metric" not in d or "roofline" not in d:
+        pytest.skip("not a bench line")
+    line = bench.compact_line(d)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT <= 4096, len(line)
+    c = json.loads(line, parse_constant=_reject)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in c, k
+    assert c["value"] == d["value"] and c["config"]["workload_id"] == d["config"]["workload_id"] and isinstance(c["config"]["workload"], str)
+    r = c["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - d["roofline"]["frac"]) <= 1e-4 * abs(d["roofline"]["frac"]) + 1e-12
+    if "cpu_baseline" in d:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c["cpu_baseline"], k
+    for name, w in (d.get("workloads") or {}).items():
+        assert abs(c["workloads"][name]["value"] - w["value"]) <= 1e-4 * w["value"]
+
+
+def test_compact_line_survives_a_hostile_result():
+    """NaN / inf never reach the line, arbitrarily long strings and many sub-workloads cannot push it over the limit."""
+    import bench
+    d = _load(os.path.join(ROOT, "profiles", "r03_bench_n1.json"))
+    d["roofline"]["frac"] = float("nan")
+    d["roofline"]["traffic"] = float("inf")
+    d["config"]["workload"] = "x" * 50_000
+    d["config"]["parallelism"] = "y" * 50_000
+    d["cpu_baseline"]["sample"] = "z" * 50_000
+    for i in range(200):
+        d["workloads"][f"W{i}"] = dict(d["workloads"]["D"])
+    line = bench.compact_line(d)
+    assert len(line) < 4096
+    c = json.loads(line, parse_constant=_reject)
+    assert c["value"] == d["value"] and c["roofline"].get("frac") is None and c["roofline"]["traffic"] is None

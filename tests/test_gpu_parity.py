@@ -1598,8 +1598,12 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
            "--d-sweeps", "1", "--d-radius", "45", "--no-pmc"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096, [len(ln) for ln in lines]      # stdout is the one compact line and nothing else
+    d = json.loads(lines[0])
+    full = json.load(open(os.path.join(root, "bench_detail.json")))                 # everything else: the detail file
+    assert full["value"] == d["value"]
+    d["parity"] = full["parity"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["workload_id"] == "D"
     assert d["config"]["keypoints_total"] > 100_000 and abs(d["config"]["keypoints_per_gpu"] * 2 - d["config"]["keypoints_total"]) <= 1
     assert d["parity_m_rad"][0] < 1e-4 and d["parity_m_rad"][1] < 1e-4 and d["parity"]["n_used_gpu"] == d["parity"]["n_used_oracle"]
