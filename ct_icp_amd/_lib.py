@@ -99,7 +99,7 @@ class View(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_bytes", C.c_size_t), ("dtype", C.c_int32), ("_pad", C.c_int32)]
 
 
-# every symbol include/ctgn.h declares: name -> (restype, argtypes)
+# every symbol include/ctgn.h declares (+ the measurement / test hooks of ct_icp_amd/csrc/ctgn_internal.h): name -> (restype, argtypes)
 _dp = C.POINTER(C.c_double)
 _H = C.c_void_p
 SYMBOLS = {

@@ -2,6 +2,7 @@
 // Host side only: context, device residency of the voxel map (full / delta upload), keypoint staging, launch
 // sequencing of the GN loop on one HIP stream. No CPU fallback exists for any query or solve entry point.
 #include "../../include/ctgn.h"
+#include "ctgn_internal.h"      // measurement / test hooks: exported, but not part of the contract
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>

@@ -1,0 +1,47 @@
+/* ctgn_internal.h — measurement and test hooks of libctgn.so that are NOT part of the drop-in contract (include/ctgn.h).
+ *
+ * The reference-side binding (integration/) sees include/ctgn.h only. What is declared here is exported by the same
+ * shared library for this repository's own tests, profiling scripts and bench.py: ablation masks of the row kernel, the instrumented
+ * instantiation's phase clocks and traffic counters, the per-wave timeline, and direct entry points to the library's sort / compaction
+ * kernels. Nothing here is stable ABI. */
+#ifndef CTGN_INTERNAL_H
+#define CTGN_INTERNAL_H
+
+#include "../../include/ctgn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Measurement hook: skip phases of the row kernel (bit 0 candidate streaming, 1 final selection, 2 hand-over records,
+ * 3 normal/residual/Jacobian, 4 hash probes, 5 shared-home-voxel path (variant 5), 6 radius cull of the probes off, 7 no list
+ * appends, 8 no carried-over bound and no pools, 9 no slab masks, 10 no rounds at all = phase A only, 11 no neighbour pools,
+ * 12-15 spare pool members instead of 8 (1..12)). Results are INVALID while a mask is set — except bits 5, 6, 8, 9 and 11-15, which only
+ * switch exact optimisations off or tune them — and a starved solve keeps launching the search so that it can be timed (ablation
+ * profiling, DESIGN.md sections 13 and 17, scripts/ablate2.sh, scripts/iter_times.py). */
+ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
+/* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
+ * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
+ * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel
+ * fast path, 9 = rounds (counts, per wave), 10 = clocks of the slowest wave (max), 11 = waves. */
+ctgn_status ctgn_phase_cycles(ctgn_handle h, uint64_t out[12], int32_t reset);
+/* What the instrumented row kernel (variant 3) actually requested from the memory system since the last reset: out[0] = hash probes
+ * issued (sweep voxels NOT culled against the radius / the k-th best distance; the shared-home-voxel path probes its 27 voxels once
+ * per wave), out[1] = map points streamed. bench.py prices the kernel's algorithmic bytes with these instead of
+ * charging every point of all 27 / 125 sweep voxels. Measurement hook. */
+ctgn_status ctgn_traffic_counters(ctgn_handle h, uint64_t out[2], int32_t reset);
+/* Per-wave timeline of the last variant-3 launch: 4 words per wave slot (start clock, end clock, fast-path rounds,
+ * rounds); slots of waves that did not run keep their previous content (zero initially). */
+ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves);
+
+/* Test hooks for the library's own sort / compaction kernels (ctgn_sort.hpp; they replace a vendor sort library on the frame path: the
+ * map-update batch, the adaptive sampler, the home-voxel ordering): order_out[j] = index of the j-th smallest key under a STABLE sort on
+ * the low key_bits bits (key_bytes 4: the keys are narrowed to 32 bits first); out_indices = ascending indices whose flag is non-zero.
+ * Host arrays in and out. */
+ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, int32_t key_bits, int32_t key_bytes, uint32_t *order_out);
+ctgn_status ctgn_test_compact(ctgn_handle h, const uint8_t *flags, size_t n, uint32_t *out_indices, size_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTGN_INTERNAL_H */

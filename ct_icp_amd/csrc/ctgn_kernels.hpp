@@ -1,25 +1,26 @@
 // ctgn_kernels.hpp — gfx950 (CDNA4, wave64) kernels of the Gauss–Newton CT-ICP path.
 //
 // One GN iteration of ct_icp::CT_ICP_Registration::DoRegisterGaussNewton (reference
-// src/ct_icp/ct_icp.cpp:745-981) is two launches on one stream, with no host synchronisation:
+// src/ct_icp/ct_icp.cpp:745-981) is three launches on one stream, with no host synchronisation:
 //
-//   k_accumulate_*   per keypoint: [re-transform with the current pose, :964-966] -> voxel-hash neighbour
-//                    search (include/ct_icp/map.h:449-514) -> mean/covariance -> normal + a2D
-//                    (include/SlamCore/experimental/neighborhood.h:225-257,285-316) -> gates, residual,
-//                    12-vector u (:782-841) -> per-block packed sum of u u^T | -u r | count (:843-850)
+//   k_accumulate_rows  per keypoint: [re-transform with the current pose, :964-966] -> voxel-hash neighbour
+//                      search (include/ct_icp/map.h:449-514) -> neighbour record (k_accumulate_lane: search + the next step fused)
+//   k_residual_reduce  mean/covariance -> normal + a2D (include/SlamCore/experimental/neighborhood.h:225-257,285-316) -> gates,
+//                      residual, 12-vector u (:782-841) -> per-block packed sum of u u^T | -u r | count (:843-850)
 //   k_reduce_solve   fixed-order sum of the per-block partials -> normalise, motion prior, LDL^T, pose
 //                    update, stop test (:860-962, :978-980); writes the stop flag the next launches read.
 //
 // Two accumulate kernels share everything except the search:
 //   k_accumulate_rows  (default) 16 lanes cooperate on one keypoint, 4 keypoints per wave in flight:
 //                      the 27/125 hash probes of a keypoint are issued by the 16 lanes in parallel, a voxel's
-//                      SoA point block is read as contiguous 8*BLK-byte runs, candidates are compacted into a
-//                      per-row LDS list with ballot/popcount, the k nearest are selected in LDS, and the
-//                      covariance sums are reduced with DPP row butterflies (no LDS, no bpermute).
+//                      point block (an array of 24-byte points) is read in chunks of 16 points, candidates are compacted
+//                      into a per-row LDS list with ballot/popcount, the k nearest are selected with DPP row operations;
+//                      the kept points' byte offsets go to a per-keypoint record that k_residual_reduce consumes.
 //   k_accumulate_lane  one lane per keypoint, sequential insertion list in LDS — the simple restatement used
 //                      to cross-check the row kernel on the GPU (ctgn_set_variant(h, 1)).
 //
-// No MFMA anywhere: the path is gather + tiny fixed-size outer products (BASELINE.json north_star).
+// The search is gather + selection (no matrix pipe, as BASELINE.json's north_star says); the one dense contraction of the path — the
+// 13 x 13 product U^T U of a wave's 64 residual records in k_residual_reduce — runs on v_mfma_f64_16x16x4_f64.
 #pragma once
 
 #include <hip/hip_runtime.h>

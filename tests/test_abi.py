@@ -13,10 +13,11 @@ from ct_icp_amd import _lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ctgn.h")
+INTERNAL = os.path.join(ROOT, "ct_icp_amd", "csrc", "ctgn_internal.h")      # measurement / test hooks: exported, not part of the contract
 
 
-def _declared_symbols():
-    src = open(HEADER).read()
+def _declared_symbols(path=HEADER):
+    src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ctgn_[a-z0-9_]+)\s*\(", src)))
 
@@ -27,7 +28,13 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ctgn.h but not exported by libctgn.so"
-    assert set(declared) == set(L.SYMBOLS), set(declared) ^ set(L.SYMBOLS)
+    internal = _declared_symbols(INTERNAL)
+    for name in internal:
+        assert hasattr(lib, name), f"{name} declared in ctgn_internal.h but not exported by libctgn.so"
+    assert not set(internal) & set(declared)
+    # the contract header carries no ablation / instrumentation / test entry points
+    assert not [n for n in declared if re.search(r"ablation|phase_cycles|wave_timeline|traffic_counters|ctgn_test_", n)]
+    assert set(declared) | set(internal) == set(L.SYMBOLS), (set(declared) | set(internal)) ^ set(L.SYMBOLS)
     assert lib.ctgn_abi_version() == 5
 
 
