@@ -595,7 +595,7 @@ def register_calls(W, cia, om):
     res["frames_per_sec"]["gpu_vs_oracle_m_rad"] = [tr, rot]
     rp = orc.RobustPrior(previous_begin_tr=tuple(inp["prev_b"]), previous_end_tr=tuple(inp["prev_e"]))
     t0 = time.perf_counter()
-    pose_r, _, s_r = orc.register_robust(om, W["raw"], W["t"], W["pose0"], inp["tbe"], orc.RobustOptions(**rb_kw), rp, heap_mode=1)
+    pose_r, _, s_r = orc.register_robust(om, W["raw"], W["t"], W["pose0"], inp["tbe"], orc.RobustOptions(**rb_kw), rp, heap_mode=0)
     res["robust_route"]["cpu_port_ms_per_frame_1_thread"] = (time.perf_counter() - t0) * 1e3
     tr, rot = se3.pose_error(res["robust_route"].pop("pose"), pose_r)
     res["robust_route"]["gpu_vs_oracle_m_rad"] = [tr, rot]
@@ -1123,7 +1123,7 @@ def cpu_baseline(inp, pose0, world0, args, om=None):
     ro = orc.RobustOptions(**ROBUST_PROFILE)
     rp = orc.RobustPrior(previous_begin_tr=tuple(inp["prev_b"]), previous_end_tr=tuple(inp["prev_e"]))
     t0 = time.perf_counter()
-    pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=1)
+    pose_r, _, s_r = orc.register_robust(om, inp["raw"][sel], inp["t"][sel], pose0, inp["tbe"], ro, rp, heap_mode=0)
     robust_ms = (time.perf_counter() - t0) * 1e3
     # M2 (frames/s): one whole Register(solver GN) on the reference's keypoint count (1.5 m grid of the 0.5 m-subsampled sweep), driving
     # profile (5 iterations, stop at ||x|| < 0.1) — the same call measure_frames_per_sec times through the C ABI. Port: the oracle on 1

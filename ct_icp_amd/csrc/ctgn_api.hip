@@ -577,7 +577,16 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
         hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
     }
-    const int grid = std::max(1, std::min((h->n_kp + RES_BLOCK - 1) / RES_BLOCK, h->res_grid_cap));
+    // A scan whose 256-thread tiles are all resident at once anyway (<= 3 blocks per CU) runs 512-thread blocks: the same waves on the same
+    // CUs, half as many per-block records for the solve kernel to sum (a 132 k-keypoint sweep: 259 instead of 518).
+    static const int env_blk = [] { const char *e = std::getenv("CTGN_RES_BLOCK"); return e ? std::atoi(e) : 0; }();              // measurement hook
+    const int tiles256 = (h->n_kp + RES_BLOCK - 1) / RES_BLOCK;
+    if (env_blk ? env_blk == 512 : tiles256 <= 3 * h->num_cus) {
+        const int grid = std::max(1, std::min((h->n_kp + 511) / 512, h->res_grid_cap));
+        hipLaunchKernelGGL(k_residual_reduce<512>, dim3(grid), dim3(512), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
+        return grid;
+    }
+    const int grid = std::max(1, std::min(tiles256, h->res_grid_cap));
     hipLaunchKernelGGL(k_residual_reduce<RES_BLOCK>, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
                        h->ablate);
     return grid;

@@ -192,32 +192,64 @@ __device__ __forceinline__ bool sweep_in_short_range(int k, int nb) {
     return (k - nb >= -32768) && (k + nb + 1 <= 32767);
 }
 
+// How k_residual_reduce gets a neighbourhood's normal and a2D (neighborhood.h:285-316):
+//   NORMALS_EXACT   Eigen's JacobiSVD restated operation for operation, correctly rounded division / square root, no fused multiply-add
+//                   (normal_a2d_exact, ctgn_math.hpp): normals and a2D bit-identical to the reference build's, at ~4x the instructions;
+//   NORMALS_HYBRID  the fast cyclic Jacobi (sym3_normal_a2d: hardware reciprocal seeds + Newton steps; agrees with the above to ~1e-16 /
+//                   a2D^2 on the normal), and the exact one only for a keypoint whose gate `|dist| < max_dist` (ct_icp.cpp:803) lies within
+//                   1e-7 of its threshold under the fast normal, or whose neighbourhood is close to rank-deficient (a2D < 1e-2: the normal
+//                   is then decided by roundings): the discrete outputs (gate decisions, n_used) are the exact route's;
+//   NORMALS_FAST    the fast solver only (rounds 1-3).
+// The default is a compile-time constant; bits 16-17 of the ablation mask select another one at run time (A/B, tests).
+constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
+#ifndef CTGN_CULL1_DEFAULT
+#define CTGN_CULL1_DEFAULT 0         // 1: the first search of a 27-voxel sweep culls its second probe batch's voxels (rows_tiles, cull1); bit 18 of the ablation mask flips it
+#endif
+#ifndef CTGN_NORMALS_DEFAULT
+#define CTGN_NORMALS_DEFAULT 1
+#endif
+__device__ __forceinline__ int normals_mode(int ablate) { const int m = (ablate >> 16) & 3; return m ? m : CTGN_NORMALS_DEFAULT; }
+
 // Gates + residual + 12-vector u for one keypoint (ct_icp.cpp:769-841). n = neighbours kept,
 // S = sum p, SS = sum p p^T (6 unique), q = farthest kept neighbour (the reference's `closest_point`).
+// The arithmetic between the sums and the gate is the reference build's: no fused multiply-add (a stock x86-64 build cannot fuse; the
+// oracle is compiled -ffp-contract=off for the same reason), Eigen's association of the dot product at :782.
 __device__ __forceinline__ bool residual_jacobian(int n, Vec3 S, Sym3 SS, Vec3 q, Vec3 p, Vec3 raw, double alpha,
-                                                  const GnState *st, const GnParams &prm, double u[12], double &r,
+                                                  const GnState *st, const GnParams &prm, int nmode, double u[12], double &r,
                                                   Vec3 &normal_out, double &a2d_out) {
+#pragma clang fp contract(off)
     if (n < prm.min_nb || n < 5) return false;               // :769 ; neighborhood.h:227-230
-    double dn = (double) n;
-    Vec3 mu{S.x / dn, S.y / dn, S.z / dn};                   // neighborhood.h:241
-    Sym3 C;                                                  // :242-243
-    C.xx = SS.xx / dn - mu.x * mu.x; C.xy = SS.xy / dn - mu.x * mu.y; C.xz = SS.xz / dn - mu.x * mu.z;
-    C.yy = SS.yy / dn - mu.y * mu.y; C.yz = SS.yz / dn - mu.y * mu.z; C.zz = SS.zz / dn - mu.z * mu.z;
     Vec3 nrm;
     double a2d;
-    sym3_normal_a2d(C, nrm, a2d);
-    Vec3 tb = st_tb(st);
-    if (dot(nrm, tb - p) < 0) nrm = Vec3{-nrm.x, -nrm.y, -nrm.z};      // :782-784
+    const Vec3 d = p - q;
+    bool exact = nmode == NORMALS_EXACT;
+    if (!exact) {
+        const double dn = (double) n;
+        const Vec3 mu{S.x / dn, S.y / dn, S.z / dn};         // neighborhood.h:241
+        Sym3 C;                                              // :242-243
+        C.xx = SS.xx / dn - mu.x * mu.x; C.xy = SS.xy / dn - mu.x * mu.y; C.xz = SS.xz / dn - mu.x * mu.z;
+        C.yy = SS.yy / dn - mu.y * mu.y; C.yz = SS.yz / dn - mu.y * mu.z; C.zz = SS.zz / dn - mu.z * mu.z;
+        sym3_normal_a2d(C, nrm, a2d);
+        if (nmode == NORMALS_HYBRID) {
+            const double dist_f = nrm.x * d.x + nrm.y * d.y + nrm.z * d.z;
+            exact = !(a2d >= 1e-2) || fabs(fabs(dist_f) - prm.max_dist) <= 1e-7;
+        }
+    }
+    if (exact) {
+        const double SS9[9] = {SS.xx, SS.xy, SS.xz, SS.xy, SS.yy, SS.yz, SS.xz, SS.yz, SS.zz};
+        normal_a2d_exact(n, S, SS9, nrm, a2d);               // neighborhood.h:236-244,293-311 in the reference build's arithmetic
+    }
+    const Vec3 tb = st_tb(st);
+    if (nrm.x * (tb.x - p.x) + (nrm.y * (tb.y - p.y) + nrm.z * (tb.z - p.z)) < 0) nrm = Vec3{-nrm.x, -nrm.y, -nrm.z};      // :782-784
     normal_out = nrm;
     a2d_out = a2d;
-    double w = a2d * a2d;                                              // :787-788
-    Vec3 m{w * nrm.x, w * nrm.y, w * nrm.z};                           // :789
-    Vec3 d = p - q;
-    double dist = nrm.x * d.x + nrm.y * d.y + nrm.z * d.z;             // :793-795
+    const double w = a2d * a2d;                                        // :787-788
+    const Vec3 m{w * nrm.x, w * nrm.y, w * nrm.z};                     // :789
+    const double dist = nrm.x * d.x + nrm.y * d.y + nrm.z * d.z;       // :793-795
     if (!(fabs(dist) < prm.max_dist)) return false;                    // :803
     r = m.x * d.x + m.y * d.y + m.z * d.z;                             // :805-807
-    Vec3 a = quat_rotate(st_qb(st), raw), e = quat_rotate(st_qe(st), raw);   // :813-816
-    double oma = 1.0 - alpha;
+    const Vec3 a = quat_rotate(st_qb(st), raw), e = quat_rotate(st_qe(st), raw);   // :813-816
+    const double oma = 1.0 - alpha;
     u[0] = oma * (a.y * m.z - a.z * m.y); u[1] = oma * (a.z * m.x - a.x * m.z); u[2] = oma * (a.x * m.y - a.y * m.x);
     u[3] = oma * m.x; u[4] = oma * m.y; u[5] = oma * m.z;
     u[6] = alpha * (e.y * m.z - e.z * m.y); u[7] = alpha * (e.z * m.x - e.x * m.z); u[8] = alpha * (e.x * m.y - e.y * m.x);
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
             Vec3 S{0, 0, 0}, q{0, 0, 0};
             Sym3 SS{0, 0, 0, 0, 0, 0};
             for (int j = n - 1; j >= 0; --j) {                              // farthest first: the reference's neighbour order (map.h:508-513),
+#pragma clang fp contract(off)
                 Vec3 c = map_point(map, ids[j * LANE_BLOCK + tid]);         // which is the order ComputeNeighborhood sums in (neighborhood.h:236-240)
                 S.x += c.x; S.y += c.y; S.z += c.z;
                 SS.xx += c.x * c.x; SS.xy += c.x * c.y; SS.xz += c.x * c.z;
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
             }
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
-            used = residual_jacobian(n, S, SS, q, p, raw, alpha, st, prm, u, r, nrm, a2d);
+            used = residual_jacobian(n, S, SS, q, p, raw, alpha, st, prm, CTGN_NORMALS_DEFAULT, u, r, nrm, a2d);
             if (dbg.n_nb) {
                 dbg.n_nb[i] = n;
                 dbg.normal[3 * i] = nrm.x; dbg.normal[3 * i + 1] = nrm.y; dbg.normal[3 * i + 2] = nrm.z;
@@ -483,10 +516,11 @@ __constant__ SweepOrder<2> c_sweep2 = make_sweep_order<2>();
 // Distance from q to the interval of coordinates that Voxel::Coordinates maps to index `vox` (int(p / res) truncates
 // toward zero, so index 0 is (-res, res) and a negative index v is ((v-1) res, v res]; src/SlamCore/types.cxx:13-20).
 __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
-    double lo, hi;
-    if (vox > 0) { lo = vox * res; hi = lo + res; }
-    else if (vox < 0) { hi = vox * res; lo = hi - res; }
-    else { lo = -res; hi = res; }
+    // index v > 0: [v res, (v + 1) res); v < 0: ((v - 1) res, v res]; 0: (-res, res). Branch-free (the three-way branch this replaces was
+    // divergent in every wave that straddles an axis plane and cost two exec save / restore pairs per axis and probe); the callers' 1e-8
+    // relative slack covers the last-bit difference between (v + 1) res and v res + res.
+    const int lo_i = vox - (vox <= 0 ? 1 : 0), hi_i = vox + (vox >= 0 ? 1 : 0);
+    const double lo = (double) lo_i * res, hi = (double) hi_i * res;
     return fmax(fmax(lo - q, q - hi), 0.0);
 }
 
@@ -823,6 +857,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     // pool: how many of a search's nearest candidates the keypoint's record keeps (the k neighbours + spare ones), see phase V
     const int pool_cap = (!POOLS || (ablate & 2048) || !kp.pools) ? k : min(KMAX, k + (((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : POOL_EXTRA));
     const bool pool_on = pool_cap > k;
+    // 27-voxel sweep, search without a carried-over bound (the first of a solve): after the first probe batch (the 16 nearest voxels) a row
+    // that holds k candidates finds its k-th best, and the second batch's voxels (far edges and corners) are streamed only if their box
+    // reaches inside it — what the 125-voxel sweep always does. On bounded searches the extra selection costs more than it saves (round 2).
+    const bool cull1 = NB == 1 && !kp.kth_valid && (((ablate >> 18) & 1) != CTGN_CULL1_DEFAULT);
     const int blk = map.blk;
     const char *pbase = reinterpret_cast<const char *>(map.blocks);       // 32-bit byte offsets: host keeps blocks < 4 GiB
     const uint32_t stride3 = 3u * (uint32_t) blk * 8u;                     // bytes per block; uniform base + 32-bit lane offset loads
@@ -1232,7 +1270,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // 125-voxel sweep (8 probe batches): on the 27-voxel sweep (2 batches) the extra selection costs more than the
                 // culled chunks save (B2: 0.094 -> 0.105 ms per launch), on the 125-voxel one it wins (D: 3.11 -> 2.31 ms).
                 bool within_kth = true;
-                if (NB == 2 && it > 0 && kth_d2 < map.r2thr) {
+                if ((NB == 2 || cull1) && it > 0 && kth_d2 < map.r2thr) {
                     const int vv = (cur_v == 255) ? 0 : cur_v;
                     const double gx = axis_gap(qx, kx + vv / (S * S) - NB, map.resolution), gy = axis_gap(qy, ky + (vv / S) % S - NB, map.resolution),
                                  gz = axis_gap(qz, kz + vv % S - NB, map.resolution);
@@ -1296,7 +1334,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
-                if (NB == 2 && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2thr))) {
+                if ((NB == 2 || cull1) && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2thr))) {
                     Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
                     if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
                     CTGN_TICK(3)
@@ -1431,12 +1469,16 @@ __host__ __device__ constexpr size_t rows_kernel_smem() {
 // all 64 lanes busy instead of the 4 x rounds owner lanes of a tile.
 // ================================================================================================
 constexpr int RES_BLOCK = 256;
-constexpr int GG = 8;                // neighbours gathered per group: 3 x GG independent loads in flight per lane
+constexpr int GG = 10;               // neighbours gathered per group: 2 x GG independent loads in flight per lane; k = 20 (every shipped profile) is two groups
+constexpr int NGROUPS = (KMAX + GG - 1) / GG;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // One wave, one keypoint per lane (position my_pos): neighbour set -> sums -> normal, gates, residual, u -> the wave's 13 x 13 product
 // U^T U added to accm (FP64 MFMA, fixed order). `rec` is this wave's 64 x 13 LDS staging area.
+// The dependent chain is what a 132 k-keypoint scan waits for (2 068 waves on 1 024 SIMDs: two per SIMD, little to overlap with), so
+// everything that does not depend on something else is requested up front: the dense count, the record's first 1 + k words (k is
+// wave-uniform: six 16-byte loads at k = 20, not nine) and the keypoint's own seven doubles go out together; then the gathers, GG at a time.
 __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
                                               int ablate, int my_pos, int lane, double *rec, d4_t &accm, int &n_used_wave, TieScratch &tie) {
     const char *pbase = reinterpret_cast<const char *>(map.blocks);
@@ -1450,48 +1492,54 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             bool fetch_rec;
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
-            // the dense count first; then, only for a keypoint the gates can keep (or under debug capture), the whole 144-byte
-            // record in nine independent 16-byte loads
             const uint32_t cnt_raw = kp.cnt[my_kp];
-            const int cnt_n = min((int) (cnt_raw & REC_N_MASK), KMAX);
-            fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
             uint32_t rec32[SEL_STRIDE];
-            rec32[0] = (uint32_t) cnt_n | (cnt_raw & TIE_FLAG);
-            if (fetch_rec) {
+            {
                 const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
+                const int nq = dbg.n_nb != nullptr ? SEL_STRIDE / 4 : min(SEL_STRIDE / 4, (prm.max_nb + 4) >> 2);      // words 0 .. k
 #pragma unroll
                 for (int q = 0; q < SEL_STRIDE / 4; ++q) {
-                    const uint4 v4 = in4[q];
+                    uint4 v4 = make_uint4(0u, 0u, 0u, 0u);
+                    if (q < nq) v4 = in4[q];
                     rec32[4 * q] = v4.x; rec32[4 * q + 1] = v4.y; rec32[4 * q + 2] = v4.z; rec32[4 * q + 3] = v4.w;
                 }
             }
+            const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+            const Vec3 p{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};       // written (or taken as given) by phase A of the search kernel
+            const double t_kp = kp.t[my_kp];
+            // a keypoint the gates drop on its count alone (fewer than min_number_neighbors, or 5: ct_icp.cpp:769, neighborhood.h:227) costs
+            // nothing further, unless debug capture wants its farthest neighbour
+            const int cnt_n = min((int) (cnt_raw & REC_N_MASK), KMAX);
+            fetch_rec = (cnt_n >= prm.min_nb && cnt_n >= 5) || dbg.n_nb != nullptr;
+            rec32[0] = (uint32_t) cnt_n | (cnt_raw & TIE_FLAG);
             resolve_ties(map, kp, my_kp, fetch_rec, rec32, tie, lane, prm.max_nb);      // rare: see TIE_FLAG
             res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
-            // a keypoint with fewer than min_number_neighbors (or 5) neighbours is dropped by the gates below whatever its
-            // sums are (ct_icp.cpp:769, neighborhood.h:227): do not gather for it, unless debug capture wants its farthest
-            // neighbour. On a street scan that is every second keypoint that has neighbours at all.
             const int gat_n = ((res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr) ? res_n : 0;
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
             // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240) — the
-            // record is nearest-first, so it is walked from entry n - 1 down to entry 0.
-            // Gathers in groups of eight (24 independent loads in flight), sums strictly in order.
+            // record is nearest-first, so it is walked from entry n - 1 down to entry 0. Sums strictly in order, products and sums
+            // rounded separately (no fused multiply-add: the reference build has none, and these sums feed the gates).
 #pragma unroll
-            for (int g = KMAX / GG - 1; g >= 0; --g) {
+            for (int g = NGROUPS - 1; g >= 0; --g) {
                 if (GG * g < gat_n) {
                     double gx[GG], gy[GG], gz[GG];
 #pragma unroll
                     for (int q = 0; q < GG; ++q) {
-                        const uint32_t off = (GG * g + q < gat_n) ? rec32[1 + GG * g + q] : 0u;
-                        load_point(pbase, off, gx[q], gy[q], gz[q]);          // one point = 24 contiguous bytes: two loads, one or two lines
+                        if (GG * g + q < KMAX) {
+                            const uint32_t off = (GG * g + q < gat_n) ? rec32[1 + GG * g + q] : 0u;
+                            load_point(pbase, off, gx[q], gy[q], gz[q]);          // one point = 24 contiguous bytes: two loads, one or two lines
+                        }
                     }
 #pragma unroll
                     for (int q = GG - 1; q >= 0; --q) {
-                        if (GG * g + q < gat_n) {
+                        if (GG * g + q < KMAX && GG * g + q < gat_n) {
+#pragma clang fp contract(off)
                             const double x = gx[q], y = gy[q], z = gz[q];
                             if (GG * g + q == gat_n - 1) res_q = Vec3{x, y, z};      // points[0]: the farthest kept (ct_icp.cpp:791)
                             res_S.x += x; res_S.y += y; res_S.z += z;
-                            res_SS.xx += x * x; res_SS.xy += x * y; res_SS.xz += x * z;
-                            res_SS.yy += y * y; res_SS.yz += y * z; res_SS.zz += z * z;
+                            const double xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+                            res_SS.xx += xx; res_SS.xy += xy; res_SS.xz += xz;
+                            res_SS.yy += yy; res_SS.yz += yz; res_SS.zz += zz;
                         }
                     }
                 }
@@ -1499,10 +1547,8 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
             if (fetch_rec && !(ablate & 8)) {
-                const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
-                const Vec3 p{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};       // written (or taken as given) by phase A
-                const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
-                used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, u, rr, nrm, a2d);
+                const double alpha = alpha_timestamp(t_kp, st->tbe[0], st->tbe[1]);
+                used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, normals_mode(ablate), u, rr, nrm, a2d);
             }
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;
@@ -1610,7 +1656,7 @@ struct SolveScratch {                 // LDS of the 12 x 12 solve (wave 0)
 // [96][2048]: the 96 columns lie 16 KB apart, which is one and the same L2 channel set for every one of them — each block's 96
 // eight-byte writes and every reader's loads queued there; found while timing the persistent kernel's exchange)
 // THREADS / 96 groups of 96 threads: thread (g, e) adds entry e of blocks g, g + G, g + 2G, ... in that order (coalesced across e,
-// eight loads in flight), the groups' sums are added in group order. Fixed order: deterministic. s_tmp: G x 96 doubles of LDS.
+// sixteen loads in flight), the groups' sums are added in group order. Fixed order: deterministic. s_tmp: G x 96 doubles of LDS.
 template <int THREADS>
 __device__ __forceinline__ void reduce_partials(const double *partials, int nblocks, int tid, double *sys_global, double *s_sys, double *s_tmp) {
     constexpr int G = THREADS / SYS_N;
@@ -1619,15 +1665,15 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
         const int g = tid / SYS_N, e = tid - g * SYS_N;
         const double *col = partials + e;
         double sum = 0.0;
-        int b = g;
-        for (; b + 7 * G < nblocks; b += 8 * G) {
-            double v[8];
+        // sixteen loads in flight per thread (a 132 k-keypoint scan leaves ~26 records per thread: two trips instead of four); the tail
+        // batch is masked — adding 0.0 keeps the order and the value of the sum
+        for (int b = g; b < nblocks; b += 16 * G) {
+            double v[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = col[(size_t) (b + q * G) * SYS_N];
+            for (int q = 0; q < 16; ++q) v[q] = (b + q * G < nblocks) ? col[(size_t) (b + q * G) * SYS_N] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sum += v[q];
+            for (int q = 0; q < 16; ++q) sum += v[q];
         }
-        for (; b < nblocks; b += G) sum += col[(size_t) b * SYS_N];
         s_tmp[g * SYS_N + e] = sum;
     }
     __syncthreads();

@@ -61,7 +61,7 @@ def test_radius_search_is_bit_exact(case_name, request):
     got = gm.ComputeNeighborhoods(qs, 20)
     n_full = 0
     for q, g in zip(qs, got):
-        want = om.radius_search(q, 0.0, 20, heap_mode=1)
+        want = om.radius_search(q, 0.0, 20, heap_mode=0)
         assert g.shape == want.shape and np.array_equal(g, want)
         assert np.array_equal(want, om.radius_search(q, 0.0, 20, heap_mode=0))      # no ties in this data
         n_full += len(g) == 20
@@ -74,7 +74,7 @@ def test_radius_search_is_bit_exact(case_name, request):
     # explicit radius selects another sweep width
     r = case["default_radius"] * 0.5
     for q, g in zip(qs[:50], gm.ComputeNeighborhoods(qs[:50], 12, radius=r)):
-        assert np.array_equal(g, om.radius_search(q, r, 12, heap_mode=1))
+        assert np.array_equal(g, om.radius_search(q, r, 12, heap_mode=0))
 
 
 # ------------------------------------------------------------------------------------------------- one accumulation
@@ -93,16 +93,17 @@ def test_accumulate_matches_oracle(case_name, voxel, variant, request):
     pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
     dbg = s.get_debug()
     A, b, n_used = s.get_system()
-    Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=1, debug=True)
+    Ao, bo, no, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
     assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
     has = info["n_neighbors"] >= max(o.min_number_neighbors, 5)
     assert has.sum() > 500
     assert np.array_equal(dbg["farthest"][has], info["farthest"][has])
     assert np.array_equal(dbg["used"], info["used"])
     assert n_used == no == summ.num_residuals_used
-    assert np.allclose(dbg["a2d"][has], info["a2d"][has], atol=1e-9)
-    planar = has & (info["a2d"] > 0.2)               # eigenvector conditioning ~ eps / gap: compare where it is defined
-    assert np.abs(dbg["normal"][planar] - info["normal"][planar]).max() < 1e-8
+    # round 4: the GN route sums without fused multiply-adds and runs Eigen's JacobiSVD restated operation for operation
+    # (normal_a2d_exact, neighborhood.h:236-244,293-311): a2D and normals are the oracle's bit for bit wherever a neighbourhood is valid
+    assert np.array_equal(dbg["a2d"][has], info["a2d"][has])
+    assert np.array_equal(dbg["normal"][has], info["normal"][has])
     scale = np.abs(Ao).max()
     assert np.abs(A - Ao).max() < 1e-10 * scale and np.abs(b - bo).max() < 1e-10 * max(np.abs(bo).max(), 1e-30) + 1e-14
     # and the solve that followed
@@ -123,7 +124,7 @@ def test_register_matches_oracle(case_name, voxel, iters, request):
     kps["raw_point"], kps["t"], kps["world_point"] = raw, t, world0
     frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
     summ = cia.CT_ICP_Registration(o).Register(gm, kps, frame, mm)
-    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
     assert summ.success and so.success
     assert summ.num_iters == so.num_iters and summ.num_residuals_used == so.num_residuals_used
     tr, rot = se3.pose_error(frame.pose14(), pose_o)
@@ -219,7 +220,7 @@ def test_float32_strided_keypoints(box_case):
     L.check(h, st)
     raw32, world32 = rec["raw"].astype(np.float64), world0.astype(np.float32).astype(np.float64)
     pose_o, world_o, so = orc.register_gn(om, raw.astype(np.float32).astype(np.float64), world32, t, pose0, sc.t_begin_end,
-                                          orc.Options(4, 20, 20, False, 0.3, 0.0), None, heap_mode=1)
+                                          orc.Options(4, 20, 20, False, 0.3, 0.0), None, heap_mode=0)
     assert summ.success and summ.num_residuals_used == so.num_residuals_used
     tr, rot = se3.pose_error(pose, pose_o)
     assert tr < 1e-7 and rot < 1e-7
@@ -235,7 +236,7 @@ def test_incremental_map_updates_reach_the_device(street_case):
     for j in range(3, 9):
         qs = case["scans"][j].world_gt[rng.choice(len(case["scans"][j].world_gt), 200, replace=False)]
         for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):            # forces residency / sync before the edits
-            assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+            assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=0))
         pts = case["scans"][j].world_gt
         gm.InsertPointCloud(pts)
         om.insert(pts)
@@ -245,7 +246,7 @@ def test_incremental_map_updates_reach_the_device(street_case):
         assert gm.NumPoints() == om.num_points()
     qs = case["scans"][9].world_gt[rng.choice(len(case["scans"][9].world_gt), 500, replace=False)]
     for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):
-        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=0))
 
 
 def test_stepwise_api_equals_fused_loop(box_case):
@@ -512,7 +513,7 @@ def test_config_c_nclt_profile_matches_oracle(nclt_case):
     s.set_debug(True)
     s.set_keypoints(raw, world0, t)
     pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o, mm)
-    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
     assert summ.success and so.success and summ.num_iters == so.num_iters
     assert summ.num_residuals_used == so.num_residuals_used > 300
     tr, rot = se3.pose_error(pose1, pose_o)
@@ -582,7 +583,7 @@ def test_home_voxel_ordering_changes_nothing_but_the_schedule(config_b_full, box
     sb.set_ordering(1)
     sb.set_keypoints(raw, worldb, t)
     pg, sg, _ = sb.solve(poseb, scb.t_begin_end, _opts())
-    po, _, so = orc.register_gn(om, raw, worldb.copy(), t, poseb, scb.t_begin_end, _oopts(_opts()), None, heap_mode=1)
+    po, _, so = orc.register_gn(om, raw, worldb.copy(), t, poseb, scb.t_begin_end, _oopts(_opts()), None, heap_mode=0)
     assert sg.success and sg.num_residuals_used == so.num_residuals_used and sg.num_iters == so.num_iters
     tr, rot = se3.pose_error(pg, po)
     assert tr < 1e-7 and rot < 1e-7
@@ -635,7 +636,7 @@ def test_device_resident_map_maintenance(street_case, box_case):
     assert gm.SearchParamsFromRadiusSearch() == om.search_params() == (1, 0.8, 2)
     qs = case["scans"][8].world_gt[rng.choice(len(case["scans"][8].world_gt), 400, replace=False)]
     for q, g in zip(qs, gm.ComputeNeighborhoods(qs, 20)):
-        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=1))
+        assert np.array_equal(g, om.radius_search(q, 0.0, 20, heap_mode=0))
     # float32 strided input goes through the same cast as the host path
     rec = np.zeros(3000, dtype=[("pad", "<f4"), ("xyz", "<f4", 3)])
     rec["xyz"] = case["scans"][9].world_gt[:3000]
@@ -646,7 +647,7 @@ def test_device_resident_map_maintenance(street_case, box_case):
     s = cia.GnSolver(gm)
     s.set_keypoints(raw, world0, t)
     pose1, summ, _ = s.solve(pose0, sc.t_begin_end, o)
-    pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+    pose_o, _, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
     assert summ.num_residuals_used == so.num_residuals_used and se3.pose_error(pose1, pose_o)[0] < 1e-7
     gm.ClearMap()
     assert gm.NumPoints() == 0 and len(gm.MapAsPointCloud(1)) == 0
@@ -776,7 +777,7 @@ def test_sequence_of_frames_end_to_end(street_case):
         frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
         summ = reg.Register(gm, kps, frame, mm)
         op = orc.MotionPrior(previous_begin_tr=prev_o[4:7], previous_end_tr=prev_o[11:14])
-        pose_o, _, so = orc.register_gn(om, raw[kp], world0, t[kp], pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+        pose_o, _, so = orc.register_gn(om, raw[kp], world0, t[kp], pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
         assert summ.success and so.success and summ.num_residuals_used == so.num_residuals_used and summ.num_iters == so.num_iters
         pose_g = frame.pose14()
         tr, rot = se3.pose_error(pose_g, pose_o)
@@ -1089,7 +1090,7 @@ def test_config_a_reference_scene_gpu_vs_oracle(config_a_case):
     kps["raw_point"], kps["t"], kps["world_point"] = raw, t, world0
     frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
     summ = cia.CT_ICP_Registration(o).Register(gm, kps, frame)
-    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+    pose_o, world_o, so = orc.register_gn(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
     tr, rot = se3.pose_error(frame.pose14(), pose_o)
     assert summ.success and so.success and summ.num_iters == so.num_iters and summ.num_residuals_used == so.num_residuals_used
     assert tr < 1e-7 and rot < 1e-7, (tr, rot)
@@ -1107,7 +1108,7 @@ def test_config_a_reference_scene_gpu_vs_oracle(config_a_case):
     q0 = pose0.copy()
     q0[0:4] /= np.linalg.norm(q0[0:4]); q0[7:11] /= np.linalg.norm(q0[7:11])
     oro = orc.RobustOptions(num_iters_icp=1, ls_max_num_iters=5)
-    want = orc.robust_build(om, raw, orc.transform_points(q0, sc.t_begin_end, t, raw), t, sc.t_begin_end, oro, heap_mode=1)
+    want = orc.robust_build(om, raw, orc.transform_points(q0, sc.t_begin_end, t, raw), t, sc.t_begin_end, oro, heap_mode=0)
     kp = want["keypoint"]
     assert summ_r.num_residuals_used == len(kp) and np.array_equal(np.nonzero(got["rank"] >= 0)[0], kp)
     assert np.array_equal(got["ref"][kp], want["ref"])
@@ -1122,7 +1123,7 @@ def test_config_a_reference_scene_gpu_vs_oracle(config_a_case):
     ro.num_iters_icp, oro.num_iters_icp = 30, 30
     frame_r = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
     summ_r = cia.CT_ICP_Registration(ro).Register(gm, kps, frame_r)
-    pose_ro, _, sro = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, oro, None, heap_mode=1)
+    pose_ro, _, sro = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, oro, None, heap_mode=0)
     tr, rot = se3.pose_error(frame_r.pose14(), pose_ro)
     assert summ_r.success and sro.success and summ_r.num_iters == sro.num_iters
     assert tr < POSE_TOL_M and rot < POSE_TOL_RAD, (tr, rot)           # the stated tolerance ...
@@ -1298,8 +1299,10 @@ def test_km_scale_world_coordinates(street_case, mode):
     assert np.array_equal(dbg["n_neighbors"], info["n_neighbors"])
     has = info["n_neighbors"] >= 20
     assert has.sum() > 500 and np.array_equal(dbg["farthest"][has], info["farthest"][has])
-    assert (dbg["used"] != info["used"]).sum() <= 2 and abs(n_used - no) <= 2      # |d| < 0.3 gate on a value conditioned ~1e-7
-    assert np.abs(dbg["a2d"][has] - info["a2d"][has]).max() < 1e-4
+    # gate decisions are index work: bit-exact (round 4: the sums, the covariance and the SVD run in the reference build's arithmetic, so
+    # the value the |d| < 0.3 gate tests is the oracle's own, however badly conditioned it is 5 km from the origin)
+    assert np.array_equal(dbg["used"], info["used"]) and n_used == no
+    assert np.array_equal(dbg["a2d"][has], info["a2d"][has]) and np.array_equal(dbg["normal"][has], info["normal"][has])
     assert np.abs(A - Ao).max() < 1e-4 * np.abs(Ao).max()
     o = _opts(num_iters_icp=6, threshold_orientation_norm=0.0)
     s.set_debug(False)
@@ -1336,7 +1339,7 @@ def test_k32_neighbours_and_64_point_voxels(box_case, mode):
         assert tr < TIGHT and rot < TIGHT
     got = gm.ComputeNeighborhoods(world0[:300], 32)
     for q, gq in zip(world0[:300], got):
-        assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=1))
+        assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=0))
 
 
 def test_config_d_ouster_scan_matches_oracle():

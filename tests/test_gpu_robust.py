@@ -68,7 +68,7 @@ def test_blocks_and_normal_equations_match_oracle(case_name, voxel, loss, reques
     assert np.allclose(pose1, q0, atol=1e-15)                              # no inner iteration: pose untouched
     world = orc.transform_points(q0, sc.t_begin_end, t, raw)
     assert np.abs(s.world_points() - world).max() < 1e-12
-    want = orc.robust_build(om, raw, world, t, sc.t_begin_end, _oopts(o), heap_mode=1)
+    want = orc.robust_build(om, raw, world, t, sc.t_begin_end, _oopts(o), heap_mode=0)
     got = s.robust_blocks()
     kp = want["keypoint"]
     assert len(kp) > 400 and summ.num_residuals_used == len(kp)
@@ -98,7 +98,7 @@ def test_inner_solve_matches_oracle(box_case, ls_iters):
     s = cia.GnSolver(gm)
     s.set_keypoints(raw, np.zeros_like(raw), t)
     pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o, mm)
-    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
     tr, rot = se3.pose_error(pose1, pose_o)
     assert tr < 1e-8 and rot < 1e-8, (tr, rot)
     assert summ.success and so.success and summ.num_residuals_used == so.num_residuals_used
@@ -124,7 +124,7 @@ def test_register_robust_matches_oracle(case_name, voxel, loss, prior, request):
     kp["raw_point"], kp["t"] = raw, t
     frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
     summ = cia.CT_ICP_Registration(o).Register(gm, kp, frame, mm)
-    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=1)
+    pose_o, world_o, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), op, heap_mode=0)
     tr, rot = se3.pose_error(frame.pose14(), pose_o)
     assert summ.success and so.success
     assert tr < 1e-6 and rot < 1e-6, (tr, rot)
@@ -144,7 +144,7 @@ def test_residual_cap_and_several_closest_neighbors(box_case):
     for kw in (dict(max_num_residuals=300), dict(num_closest_neighbors=3), dict(num_closest_neighbors=2, max_num_residuals=501)):
         o = _opts(num_iters_icp=2, ls_max_num_iters=3, **kw)
         pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o)
-        pose_o, _, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+        pose_o, _, so = orc.register_robust(om, raw, t, pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
         assert summ.num_residuals_used == so.num_residuals_used
         if "max_num_residuals" in kw:
             assert summ.num_residuals_used == kw["max_num_residuals"]
@@ -160,7 +160,7 @@ def test_soft_failure_and_errors(box_case):
     s.set_keypoints(far, np.zeros_like(far), t[:40])
     o = _opts(num_iters_icp=3, ls_max_num_iters=2)
     pose1, summ, _ = s.solve_robust(pose0, sc.t_begin_end, o)
-    _, _, so = orc.register_robust(om, far, t[:40], pose0, sc.t_begin_end, _oopts(o), None, heap_mode=1)
+    _, _, so = orc.register_robust(om, far, t[:40], pose0, sc.t_begin_end, _oopts(o), None, heap_mode=0)
     assert not summ.success and not so.success
     assert summ.error_log == so.error_log and "not enough keypoints" in summ.error_log
     assert summ.num_residuals_used == so.num_residuals_used
