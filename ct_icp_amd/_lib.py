@@ -170,6 +170,7 @@ SYMBOLS = {
     "ctgn_kernel_timing_split": (C.c_int, [_H, _dp, C.POINTER(C.c_int32), C.c_int32]),
     "ctgn_set_variant": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
+    "ctgn_set_normals": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_persistent": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_pools": (C.c_int, [_H, C.c_int32]),

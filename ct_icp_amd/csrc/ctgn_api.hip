@@ -137,6 +137,8 @@ struct ctgn_context {
     bool kth_fresh = false;             // the k-th distances on the device were written by the previous search of this solve
     int searches_in_solve = 0;          // neighbour searches launched since the solve began (the first one has no carried-over bound)
     int last_grid = 0;
+    int normals_mode = 0;               // ctgn_set_normals: 0 library default (hybrid), 1 exact, 2 hybrid, 3 fast
+    int fail_slot = 0;                  // which of the two fail-list counters the next split launch counts in (the other one is zeroed by it)
     bool gn_active = false;
     std::chrono::steady_clock::time_point gn_t0;
     double init_ms = 0.0;               // host time from the call to the first launch (ICPSummary::duration_init)
@@ -521,6 +523,10 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
     v.xcd_split = 0;                    // set per launch (needs the grid size)
     v.clk_iter_start = nullptr;         // set by launch_accumulate for the launch that opens an iteration
+    v.fail_list = h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 3);
+    v.fail_count = v.fail_count_next = nullptr;       // set per split launch
+    v.n_dev = nullptr;
+    v.resume = 0;
     return v;
 }
 
@@ -577,11 +583,12 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
         hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
     }
-    // A scan whose 256-thread tiles are all resident at once anyway (<= 3 blocks per CU) runs 512-thread blocks: the same waves on the same
-    // CUs, half as many per-block records for the solve kernel to sum (a 132 k-keypoint sweep: 259 instead of 518).
+    // 512-thread blocks halve the per-block records the solve kernel has to sum (a 132 k-keypoint sweep: 259 instead of 518).
     static const int env_blk = [] { const char *e = std::getenv("CTGN_RES_BLOCK"); return e ? std::atoi(e) : 0; }();              // measurement hook
     const int tiles256 = (h->n_kp + RES_BLOCK - 1) / RES_BLOCK;
-    if (env_blk ? env_blk == 512 : tiles256 <= 3 * h->num_cus) {
+    // (measured, B2: 259 blocks of 512 need a second round on 3 CUs — one 8-wave block per CU at 3 waves per SIMD — and the kernel loses
+    // 5 us where the solve kernel gains 3: off unless asked for)
+    if (env_blk == 512) {
         const int grid = std::max(1, std::min((h->n_kp + 511) / 512, h->res_grid_cap));
         hipLaunchKernelGGL(k_residual_reduce<512>, dim3(grid), dim3(512), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
@@ -624,6 +631,11 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     }
     int grid;
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
+    // From the third search of a solve on (nearly) every keypoint has a pool: the pool check runs as a kernel of its own and the search
+    // kernel only over the list of positions it could not certify (k_pool_check). Bit 19 of the ablation mask switches the split off (A/B).
+    static const int env_split = [] { const char *e = std::getenv("CTGN_SPLIT"); return e ? std::atoi(e) : -1; }();               // measurement hook
+    const bool split = rows_ok && h->variant == 0 && kv.kth_valid && kv.pools && h->searches_in_solve >= 3 && kv.order == nullptr &&
+                       h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : !(h->ablate & (1 << 19)));
     if (search_only && (h->variant == 1 || !rows_ok))
         return fail(h, CTGN_ERR_UNSUPPORTED, "the robust route needs the row kernel: voxel_neighborhood 1 or 2, <= 64 points per voxel");
     if (h->variant == 1 || !rows_ok) {
@@ -651,7 +663,36 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
             grid = launch_residual(h, mv, kv, dv);
         };
-        if (mv.nb == 1) {
+        if (split) {
+            static int rb_check = 0;
+            if (rb_check == 0) rb_check = std::min(resident_blocks(h, k_pool_check<true, CHECK_WPS>, ROW_BLOCK, sizeof(CheckScratch) * ROW_WAVES), 4 * MAX_PARTIAL_BLOCKS);
+            const int rounds_c = pick_rounds(h->n_kp, rb_check * ROW_WAVES);
+            const int ntiles_c = (h->n_kp + 4 * rounds_c - 1) / (4 * rounds_c);
+            int *counters = reinterpret_cast<int *>(h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 4));
+            kv.fail_count = counters + 4 * h->fail_slot;
+            kv.fail_count_next = counters + 4 * (h->fail_slot ^ 1);
+            h->fail_slot ^= 1;
+            hipLaunchKernelGGL((k_pool_check<true, CHECK_WPS>), dim3(std::max(1, std::min((ntiles_c + ROW_WAVES - 1) / ROW_WAVES, rb_check))), dim3(ROW_BLOCK),
+                               sizeof(CheckScratch) * ROW_WAVES, h->stream, mv, kv, h->d_state, h->prm, rounds_c, mv.nb);
+            KpView ks = kv;
+            ks.order = kv.fail_list;
+            ks.n_dev = kv.fail_count;
+            ks.resume = 1;
+            ks.clk_iter_start = nullptr;
+            auto search = [&](auto kernel, size_t smem) {
+                const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
+                hipLaunchKernelGGL(kernel, dim3(rb), dim3(ROW_BLOCK), smem, h->stream, mv, ks, h->d_state, h->prm, h->d_partials, dv, 0, 1,
+                                   (unsigned long long *) nullptr, h->ablate);
+            };
+            if (mv.nb == 1) search(k_accumulate_rows<1, true, false, 3>, rows_kernel_smem<1>());
+            else search(k_accumulate_rows<2, true, false, 3>, rows_kernel_smem<2>());
+            h->kth_fresh = true;
+            if (ev) (void) hipEventRecord(ev->stop, h->stream);
+            ev = nullptr;
+            kv.xcd_split = ((h->order_valid && !h->kp_coherent) || h->kp_presorted) ? 1 : 0;      // the residual kernel's tiles per XCD, as below
+            if (search_only) grid = 1;
+            else grid = launch_residual(h, mv, kv, dv);
+        } else if (mv.nb == 1) {
             const size_t sm = rows_kernel_smem<1>();
             switch (h->variant) {
                 case 2: launch(k_accumulate_rows<1, false, false, 3, false, false>, sm, nullptr); break;
@@ -764,6 +805,7 @@ void fill_params(ctgn_handle h, const ctgn_options *o, const ctgn_motion_prior *
         g.prev_b[c] = p ? p->previous_begin_tr[c] : 0.0;
         g.prev_e[c] = p ? p->previous_end_tr[c] : 0.0;
     }
+    g.normals = h->normals_mode;
 }
 
 // Fold the HIP-event times of the accumulate launches that did real work into the running average.
@@ -1138,7 +1180,9 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
         h->d_kp = nullptr; h->d_res = nullptr; h->h_kp = nullptr; h->cap_kp = 0;
         size_t cap = std::max<size_t>(n + n / 4, 4096);
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_kp), (cap * 7 + KP_TAIL) * sizeof(double)));
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 3 * cap) * sizeof(uint32_t)));   // records | counts | pool radius, k-th distance
+        // records | counts | pool radius, k-th distance | fail list of the split launches | its two counters (alternating per launch)
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 4 * cap + 16) * sizeof(uint32_t)));
+        HIPCHK(h, hipMemsetAsync(h->d_res + cap * (SEL_STRIDE + 4), 0, 16 * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }
@@ -2552,6 +2596,14 @@ ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
 ctgn_status ctgn_set_pools(ctgn_handle h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return CTGN_ERR_INVALID_ARGUMENT;
     h->pool_mode = mode;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_normals(ctgn_handle h, int32_t mode) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    if (mode < 0 || mode > 3) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_set_normals: mode 0 (default), 1 exact, 2 hybrid, 3 fast");
+    h->normals_mode = mode;
+    h->prm.normals = mode;
     return CTGN_OK;
 }
 

@@ -20,6 +20,13 @@ extern "C" {
  * switch exact optimisations off or tune them — and a starved solve keeps launching the search so that it can be timed (ablation
  * profiling, DESIGN.md sections 13 and 17, scripts/ablate2.sh, scripts/iter_times.py). */
 ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
+/* How the GN route solves a neighbourhood's 3 x 3 covariance (ctgn_kernels.hpp, residual_jacobian): 0 = the library default (2), 1 = exact
+ * (Eigen's JacobiSVD restated, correctly rounded: normals and a2D bit-identical to the reference build's; +11 % per iteration on a
+ * 132 k-keypoint sweep), 2 = hybrid (fast solver, the exact one only where a gate decision or a near-degenerate neighbourhood could depend
+ * on the difference: identical gate decisions and n_used, normals to ~1e-12), 3 = fast only. Takes effect at the next ctgn_gn_begin /
+ * solve. Bits 16-17 of the ablation mask override it; bit 18 toggles the first-search cull of the 27-voxel sweep's second probe batch,
+ * bit 19 switches the split pool-check launches off (A/B hooks; these bits leave results valid). */
+ctgn_status ctgn_set_normals(ctgn_handle h, int32_t mode);
 /* Shader-clock cycles summed over all waves of the variant-3 launches since the last reset, per phase:
  * 0 transform+voxel, 1 hash probes, 2 candidate streaming, 3 in-stream prunes, 4 final selection,
  * 5 covariance sums, 6 normal+residual+Jacobian, 7 u u^T accumulation; 8 = rounds that took the shared-home-voxel

@@ -65,6 +65,13 @@ struct KpView {
     int chunk;               // rounds of a tile that take consecutive positions (>= 1)
     int xcd_split;           // 1: the blocks of XCD x (blockIdx % 8) work inside the x-th eighth of the tiles (needs gridDim >= 8)
     unsigned long long *clk_iter_start;   // &GnState::clk_iter_start (the search kernels see the state read-only); nullptr = do not stamp
+    // split launches (k_pool_check in front of k_accumulate_rows, from the third search of a solve on):
+    uint32_t *fail_list;     // k_pool_check appends the positions whose pool did not certify their neighbours ...
+    int *fail_count;         // ... and counts them here (zero when the kernel starts); fail_count_next is zeroed for the next launch
+    int *fail_count_next;
+    const int *n_dev;        // k_accumulate_rows: the number of positions to work on lives on the device (min(*n_dev, n)); nullptr = n
+    int resume;              // k_accumulate_rows: 1 = the positions come from `order` (= a fail list), their world points are current (the
+                             // check kernel wrote them) and kth[1] is the bound to search within: no transform, nothing moved
 };
 
 // working copy of the keypoint block in position order (ctgn_api.hip, order_keypoints): dst[a][pos] = src[a][order[pos]]
@@ -83,6 +90,7 @@ struct GnParams {
     int has_prior;
     double beta_c, beta_e;
     double prev_b[3], prev_e[3];
+    int normals;             // 0: the library default; NORMALS_EXACT / NORMALS_HYBRID / NORMALS_FAST (residual_jacobian)
 };
 
 struct alignas(8) GnState {
@@ -192,23 +200,26 @@ __device__ __forceinline__ bool sweep_in_short_range(int k, int nb) {
     return (k - nb >= -32768) && (k + nb + 1 <= 32767);
 }
 
-// How k_residual_reduce gets a neighbourhood's normal and a2D (neighborhood.h:285-316):
-//   NORMALS_EXACT   Eigen's JacobiSVD restated operation for operation, correctly rounded division / square root, no fused multiply-add
-//                   (normal_a2d_exact, ctgn_math.hpp): normals and a2D bit-identical to the reference build's, at ~4x the instructions;
-//   NORMALS_HYBRID  the fast cyclic Jacobi (sym3_normal_a2d: hardware reciprocal seeds + Newton steps; agrees with the above to ~1e-16 /
-//                   a2D^2 on the normal), and the exact one only for a keypoint whose gate `|dist| < max_dist` (ct_icp.cpp:803) lies within
-//                   1e-7 of its threshold under the fast normal, or whose neighbourhood is close to rank-deficient (a2D < 1e-2: the normal
-//                   is then decided by roundings): the discrete outputs (gate decisions, n_used) are the exact route's;
+// How k_residual_reduce gets a neighbourhood's normal and a2D (neighborhood.h:285-316). In every mode the sums, the mean and the covariance
+// are the reference build's (no fused multiply-add, its order); the modes differ in the 3 x 3 solver:
+//   NORMALS_EXACT   Eigen's JacobiSVD restated operation for operation, correctly rounded division / square root (normal_a2d_exact,
+//                   ctgn_math.hpp): normals and a2D bit-identical to the reference build's. Measured on the B2 sweep: residual kernel
+//                   47 us instead of 30 (six IEEE divisions and three square roots per rotation), +11 % on the iteration.
+//   NORMALS_HYBRID  (default) the fast cyclic Jacobi (sym3_normal_a2d: hardware reciprocal seeds + Newton steps). Both solvers are
+//                   backward stable, so their normals differ by at most ~1e-15 |C| / (s1 - s2) <= 1e-15 / a2D^2; the exact one runs only
+//                   for a keypoint whose gate `|dist| < max_dist` (ct_icp.cpp:803) lies within 1e-7 of its threshold under the fast normal,
+//                   or whose a2D is below 1e-3 (normal decided by roundings: bound above > 1e-9). The discrete outputs — which keypoints
+//                   pass the gate, n_used — are therefore the exact route's; normals and a2D agree with it to ~1e-12.
 //   NORMALS_FAST    the fast solver only (rounds 1-3).
-// The default is a compile-time constant; bits 16-17 of the ablation mask select another one at run time (A/B, tests).
+// GnParams::normals selects the mode (ctgn_set_normals, ct_icp_amd/csrc/ctgn_internal.h); bits 16-17 of the ablation mask override it (A/B).
 constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
 #ifndef CTGN_CULL1_DEFAULT
 #define CTGN_CULL1_DEFAULT 0         // 1: the first search of a 27-voxel sweep culls its second probe batch's voxels (rows_tiles, cull1); bit 18 of the ablation mask flips it
 #endif
 #ifndef CTGN_NORMALS_DEFAULT
-#define CTGN_NORMALS_DEFAULT 1
+#define CTGN_NORMALS_DEFAULT 2
 #endif
-__device__ __forceinline__ int normals_mode(int ablate) { const int m = (ablate >> 16) & 3; return m ? m : CTGN_NORMALS_DEFAULT; }
+__device__ __forceinline__ int normals_mode(int ablate, int configured) { const int m = (ablate >> 16) & 3; return m ? m : (configured ? configured : CTGN_NORMALS_DEFAULT); }
 
 // Gates + residual + 12-vector u for one keypoint (ct_icp.cpp:769-841). n = neighbours kept,
 // S = sum p, SS = sum p p^T (6 unique), q = farthest kept neighbour (the reference's `closest_point`).
@@ -232,7 +243,7 @@ __device__ __forceinline__ bool residual_jacobian(int n, Vec3 S, Sym3 SS, Vec3 q
         sym3_normal_a2d(C, nrm, a2d);
         if (nmode == NORMALS_HYBRID) {
             const double dist_f = nrm.x * d.x + nrm.y * d.y + nrm.z * d.z;
-            exact = !(a2d >= 1e-2) || fabs(fabs(dist_f) - prm.max_dist) <= 1e-7;
+            exact = !(a2d >= 1e-3) || fabs(fabs(dist_f) - prm.max_dist) <= 1e-7;
         }
     }
     if (exact) {
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_accumulate_lane(MapView map, KpV
             }
             Vec3 nrm{0, 0, 0};
             double a2d = 0.0;
-            used = residual_jacobian(n, S, SS, q, p, raw, alpha, st, prm, CTGN_NORMALS_DEFAULT, u, r, nrm, a2d);
+            used = residual_jacobian(n, S, SS, q, p, raw, alpha, st, prm, normals_mode(0, prm.normals), u, r, nrm, a2d);
             if (dbg.n_nb) {
                 dbg.n_nb[i] = n;
                 dbg.normal[3 * i] = nrm.x; dbg.normal[3 * i + 1] = nrm.y; dbg.normal[3 * i + 2] = nrm.z;
@@ -445,7 +456,6 @@ inline size_t lane_kernel_smem() {
 constexpr int ROW_WAVES = 4;                 // waves per block
 constexpr int ROW_BLOCK = ROW_WAVES * 64;
 constexpr int LCAP = 96;                     // per-row candidate list capacity (>= KMAX + 2*16)
-constexpr int MAXOWN = LCAP / 16;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -560,11 +570,16 @@ __device__ __forceinline__ int max_over_rows(int v) {
 }
 
 // per-row candidate list (always live during phase B)
-struct RowList {
-    double d2[LCAP];
-    uint32_t vis[LCAP];       // (sweep voxel index << 6) | slot : the visit order, and the way back to the point
+template <int CAP>
+struct RowListT {
+    static constexpr int cap = CAP;
+    double d2[CAP];
+    uint32_t vis[CAP];        // (sweep voxel index << 6) | slot : the visit order, and the way back to the point
     uint32_t hist[16];
 };
+using RowList = RowListT<LCAP>;
+constexpr int PCAP = 48;                     // list capacity of the pool-check kernel: KMAX entries + the one a selection parks behind them, in whole rows of 16
+using PoolList = RowListT<PCAP>;
 // per-row probe scratch of the generic path
 template <int OCC>
 struct RowProbe {
@@ -619,8 +634,9 @@ constexpr double NEAR_TIE_REL = 0x1p-49;       // sqrt maps at most three adjace
 // squared distance may have the same sqrt, and one the reference visited EARLIER than the current k-th would have been kept by it
 __device__ __forceinline__ double kth_bound(double kth_sq, double r2thr) { return fmin(r2thr, kth_sq * (1.0 + 0x1p-48)); }
 
-template <bool HIST>
-__device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, int row, double hi, bool &near_tie) {
+template <bool HIST, typename RL>
+__device__ __forceinline__ int row_select(RL &R, int Ln, int k, int sub, int row, double hi, bool &near_tie) {
+    constexpr int MAXOWN = RL::cap / 16;         // entries a lane can own (the caller keeps Ln <= RL::cap)
     int maxLn = max_over_rows(Ln);
     if (maxLn == 0) return 0;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
@@ -669,9 +685,11 @@ __device__ __forceinline__ int row_select(RowList &R, int Ln, int k, int sub, in
         Ln = base;
         maxLn = max_over_rows(Ln);
     };
-    if (HIST && maxLn > 32) {
-        hist_pass(std::true_type{});
-        for (int pass = 1; pass < 3 && maxLn > 32; ++pass) hist_pass(std::false_type{});
+    if constexpr (HIST && RL::cap > 48) {        // (a pool-check list never exceeds 32 entries)
+        if (maxLn > 32) {
+            hist_pass(std::true_type{});
+            for (int pass = 1; pass < 3 && maxLn > 32; ++pass) hist_pass(std::false_type{});
+        }
     }
     if (HIST && maxLn <= 32) {
         // Fast rank for <= 32 surviving entries per row: every lane owns entries `sub` and `sub + 16` and keeps their
@@ -907,8 +925,12 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             if (first_iter) {
                 p = before;
             } else {
-                p = ct_transform(st, alpha, raw);
-                kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
+                if (kp.resume) {
+                    p = before;                                              // written by k_pool_check in this iteration
+                } else {
+                    p = ct_transform(st, alpha, raw);
+                    kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
+                }
                 if (kp.kth_valid && !(ablate & 256)) {
                     const double dx = p.x - before.x, dy = p.y - before.y, dz = p.z - before.z;
                     const double moved = sqrt(sq_norm3(dx, dy, dz));
@@ -1434,9 +1456,17 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
                                                                unsigned long long *prof = nullptr, int ablate = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (st->done && !ablate) return;                  // an ablated run starves the solve: keep timing the search anyway
+    if (st->done && !(ablate & 0xffff)) return;       // an ablated run starves the solve: keep timing the search anyway
     if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int wave = threadIdx.x >> 6;
+    if (kp.n_dev) {
+        // the positions to search were counted on the device (k_pool_check's fail list): tile shape from that count — every resident wave
+        // one tile, as few rounds as that allows
+        kp.n = min(*kp.n_dev, kp.n);
+        if (kp.n <= 0) return;
+        const int waves = (int) gridDim.x * ROW_WAVES;
+        rounds = max(1, min(16, (kp.n + 4 * waves - 1) / (4 * waves)));
+    }
     const int ntiles = (kp.n + 4 * rounds - 1) / (4 * rounds);
     // Tile hand-out. Default: wave w of block b starts at tile 4 b + w and strides by the grid. With kp.xcd_split (sorted
     // positions over a map larger than the caches) the tiles are cut into eight contiguous ranges and the blocks that land on
@@ -1451,6 +1481,173 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         tile_step = blocks_on_x * ROW_WAVES;
     }
     rows_tiles<NB, HIST, PROF, SHARED, POOLS>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
+}
+
+// ================================================================================================
+// k_pool_check — phases A and V of the row search as a kernel of their own (round 4), for the launches in which (nearly) every
+// keypoint has a pool: from the third search of a solve on. What that buys:
+//   * occupancy. The pool check is a chain of latencies (record -> pool members -> distances -> rank -> rewrite) with ~250 vector
+//     instructions per round of four keypoints; inside k_accumulate_rows it runs at that kernel's 3 waves per SIMD (165 registers,
+//     10 KB of LDS per wave for the candidate lists and probe tables it does not use). On its own it needs a third of the registers and
+//     a quarter of the LDS, so twice as many waves hide each other's waits.
+//   * dense search rounds. A keypoint the certificate does not cover used to be searched by its own wave right away, in rounds of four
+//     filled from that wave's 4 x rounds keypoints only: at 5 % failures nearly every wave ran one round with two of its four rows idle,
+//     and the launch waited for the waves that ran two or three. Here the failing positions of all waves go to ONE list (a wave-aggregated
+//     atomic append; the order is irrelevant: every keypoint's result is independent, and the sums are taken later in a fixed order)
+//     and k_accumulate_rows then runs over that list with every row busy and the rounds spread over the whole chip (KpView::n_dev,
+//     resume): same probes, same stream, same selection, same record per keypoint.
+// The certificate and its arithmetic are phase V's (rows_tiles), statement for statement; a failing keypoint leaves with the bound its
+// search starts from in kth[1] (a DISTANCE: its (k + POOL_REFILL)-th pool member's, else the previous k-th distance + the distance moved)
+// and kth[0] = 0 (no pool to check again).
+// ================================================================================================
+constexpr int CHECK_WPS = 5;                 // waves per SIMD the pool-check kernel is compiled for (<= 96 registers; at 6 it spills)
+struct CheckScratch {
+    double px[64], py[64], pz[64];     // world point of the tile's keypoints
+    int id[64];                        // position in the working arrays; -1 = none
+    float kb[64], rr2[64];             // as WaveScratch
+    uint8_t todo[64];
+    PoolList list[4];
+    uint32_t T[4][32];                 // the row's pool: point byte offsets by pool index
+};
+
+template <bool HIST, int WPS>
+__global__ __launch_bounds__(ROW_BLOCK, WPS) void k_pool_check(MapView map, KpView kp, const GnState *st, GnParams prm, int rounds, int nb_sweep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
+        *kp.fail_count_next = 0;                       // last touched by the search kernel of the previous iteration: stream order
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, sub = lane & 15;
+    CheckScratch &W = reinterpret_cast<CheckScratch *>(smem)[wave];
+    PoolList &R = W.list[row];
+    uint32_t *T = W.T[row];
+    const int k = prm.max_nb;
+    const char *pbase = reinterpret_cast<const char *>(map.blocks);
+    const int kp_per_wave = 4 * rounds;
+    const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
+    for (int tile = blockIdx.x * ROW_WAVES + wave; tile < ntiles; tile += gridDim.x * ROW_WAVES) {
+        // ---------------- phase A (rows_tiles): lane (row, sub < rounds) owns position (sub * ntiles + tile) * 4 + row
+        int my_kp = -1;
+        if (sub < rounds) {
+            const int pos = sub * ntiles * 4 + tile * 4 + row;
+            if (pos < kp.n) my_kp = pos;
+        }
+        const bool own = my_kp >= 0;
+        {
+            Vec3 p{0, 0, 0};
+            float kbv = __int_as_float(0x7f800000), rr2v = 0.f;
+            if (own) {
+                const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
+                const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
+                const Vec3 before{kp.wx[my_kp], kp.wy[my_kp], kp.wz[my_kp]};
+                p = ct_transform(st, alpha, raw);
+                kp.wx[my_kp] = p.x; kp.wy[my_kp] = p.y; kp.wz[my_kp] = p.z;
+                const double dx = p.x - before.x, dy = p.y - before.y, dz = p.z - before.z;
+                const double moved = sqrt(sq_norm3(dx, dy, dz));
+                const double rprev = (double) kp.kth[2 * my_kp], kprev = (double) kp.kth[2 * my_kp + 1];
+                if (kprev > 0.0) {
+                    const double reach = kprev + moved;
+                    kbv = __double2float_ru(reach * reach * (1.0 + 1e-9));
+                }
+                const double rnow = rprev - moved * (1.0 + 1e-9) - 1e-12;
+                if (rnow > 0.0) rr2v = __double2float_rd(rnow * rnow * (1.0 - 1e-9));
+                const int a = voxel_coord(p.x, map.resolution), b = voxel_coord(p.y, map.resolution), c = voxel_coord(p.z, map.resolution);
+                if (!(sweep_in_short_range(a, nb_sweep) && sweep_in_short_range(b, nb_sweep) && sweep_in_short_range(c, nb_sweep))) rr2v = 0.f;
+            }
+            W.px[lane] = p.x; W.py[lane] = p.y; W.pz[lane] = p.z;
+            W.id[lane] = my_kp;
+            W.kb[lane] = kbv;
+            W.rr2[lane] = rr2v;
+            W.todo[lane] = own ? 1 : 0;
+        }
+        // ---------------- phase V (rows_tiles)
+        if (any64(W.rr2[lane] > 0.f)) {
+            struct PoolRec { uint32_t hdr, o0, o1; };
+            struct PoolPts { double x0, y0, z0, x1, y1, z1; };
+            auto request = [&](int r, PoolRec &q) {
+                const int id = W.id[row * 16 + min(r, rounds - 1)];
+                const uint32_t *o = kp.sel + (size_t) max(id, 0) * SEL_STRIDE;
+                q.hdr = o[0]; q.o0 = o[1 + sub]; q.o1 = o[17 + sub];
+            };
+            auto pool_size = [&](int r, const PoolRec &q) {
+                return (r < rounds && W.rr2[row * 16 + min(r, rounds - 1)] > 0.f) ? (int) ((q.hdr >> 8) & REC_N_MASK) : 0;
+            };
+            auto gather = [&](int m, const PoolRec &q, PoolPts &t) {
+                load_point(pbase, sub < m ? q.o0 : 0u, t.x0, t.y0, t.z0);
+                load_point(pbase, sub + 16 < m ? q.o1 : 0u, t.x1, t.y1, t.z1);
+            };
+            PoolRec rec_cur{0u, 0u, 0u}, rec_nxt{0u, 0u, 0u};
+            PoolPts pts_cur{0, 0, 0, 0, 0, 0};
+            request(0, rec_cur);
+            request(1, rec_nxt);
+            gather(pool_size(0, rec_cur), rec_cur, pts_cur);
+            for (int r = 0; r < rounds; ++r) {
+                const int src = row * 16 + r;
+                const float rr2 = W.rr2[src];
+                const bool vrow = rr2 > 0.f;                                  // row-uniform
+                const bool work = any64(vrow);
+                const int m = pool_size(r, rec_cur);
+                const bool v0 = sub < m, v1 = sub + 16 < m;
+                if (work) {
+                    const double qx = W.px[src], qy = W.py[src], qz = W.pz[src];
+                    R.d2[sub] = sq_norm3(pts_cur.x0 - qx, pts_cur.y0 - qy, pts_cur.z0 - qz); R.vis[sub] = (uint32_t) sub;
+                    R.d2[sub + 16] = sq_norm3(pts_cur.x1 - qx, pts_cur.y1 - qy, pts_cur.z1 - qz); R.vis[sub + 16] = (uint32_t) (sub + 16);
+                    T[sub] = rec_cur.o0; T[sub + 16] = rec_cur.o1;
+                }
+                // round r's points and record words are in LDS now: their registers take the next round's points (in flight while this
+                // round is ranked) and the record after that — one set of point registers instead of two
+                PoolRec rec_far;
+                request(r + 2, rec_far);
+                gather(pool_size(r + 1, rec_nxt), rec_nxt, pts_cur);
+                if (work) {
+                    bool tie = false;
+                    row_select<HIST>(R, m, KMAX, sub, row, map.r2thr, tie);
+                    const double s0 = R.d2[sub], s1 = R.d2[sub + 16];
+                    const int n_in = row_sum_i32(((v0 && s0 <= map.r2thr) ? 1 : 0) + ((v1 && s1 <= map.r2thr) ? 1 : 0));   // map.h:491-493
+                    const int n = min(n_in, k);
+                    const double need2 = n_in >= k ? R.d2[k - 1] : map.r2thr;
+                    const bool pass = vrow && need2 * (1.0 + 1e-8) < (double) rr2;
+                    const int kp_r = W.id[src];
+                    if (pass) {
+                        uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
+                        if (sub == 0) {
+                            const uint32_t flagged = (uint32_t) n | ((uint32_t) m << 8) | (tie ? TIE_FLAG : 0u);
+                            o[0] = flagged; kp.cnt[kp_r] = flagged;
+                            kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
+                            kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
+                            W.todo[src] = 0;
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int e = sub + 16 * h;
+                            if (e < m) o[1 + e] = T[R.vis[e]];                    // nearest first: the n neighbours, then the rest of the pool
+                        }
+                    } else if (vrow && sub == 0 && n_in >= k + POOL_REFILL) {
+                        W.kb[src] = __double2float_ru(R.d2[k + POOL_REFILL - 1] * (1.0 + 0x1p-40));
+                    }
+                }
+                rec_cur = rec_nxt; rec_nxt = rec_far;
+            }
+        }
+        // ---------------- the keypoints still to be searched: one append per wave
+        {
+            const bool fail = own && W.todo[lane] != 0;
+            const unsigned long long fm = ballot64(fail);
+            if (fm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(kp.fail_count, (int) __popcll(fm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (fail) {
+                    kp.fail_list[base + (int) __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t) my_kp;
+                    const float kbv = W.kb[lane];
+                    // the search's bound as a distance, rounded up (+inf: the radius only)
+                    kp.kth[2 * my_kp] = 0.f;
+                    kp.kth[2 * my_kp + 1] = kbv < __int_as_float(0x7f800000) ? __double2float_ru(sqrt((double) kbv) * (1.0 + 1e-12)) : 0.f;
+                }
+            }
+        }
+    }
 }
 
 template <int NB>
@@ -1548,7 +1745,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             double a2d = 0.0;
             if (fetch_rec && !(ablate & 8)) {
                 const double alpha = alpha_timestamp(t_kp, st->tbe[0], st->tbe[1]);
-                used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, normals_mode(ablate), u, rr, nrm, a2d);
+                used = residual_jacobian(res_n, res_S, res_SS, res_q, p, raw, alpha, st, prm, normals_mode(ablate, prm.normals), u, rr, nrm, a2d);
             }
             if (dbg.n_nb) {
                 dbg.n_nb[my_kp] = res_n;

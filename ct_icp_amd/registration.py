@@ -498,6 +498,10 @@ class GnSolver:
         out = out[:n.value]
         return out[out[:, 1] > 0]
 
+    def set_normals(self, mode: int):
+        """0 library default (hybrid), 1 exact (bit-identical normals, slower), 2 hybrid, 3 fast: ct_icp_amd/csrc/ctgn_internal.h."""
+        L.check(self._h, L.lib().ctgn_set_normals(self._h, mode))
+
     def set_ablation(self, mask: int):
         L.check(self._h, L.lib().ctgn_set_ablation(self._h, mask))
 

@@ -100,10 +100,20 @@ def test_accumulate_matches_oracle(case_name, voxel, variant, request):
     assert np.array_equal(dbg["farthest"][has], info["farthest"][has])
     assert np.array_equal(dbg["used"], info["used"])
     assert n_used == no == summ.num_residuals_used
-    # round 4: the GN route sums without fused multiply-adds and runs Eigen's JacobiSVD restated operation for operation
-    # (normal_a2d_exact, neighborhood.h:236-244,293-311): a2D and normals are the oracle's bit for bit wherever a neighbourhood is valid
-    assert np.array_equal(dbg["a2d"][has], info["a2d"][has])
-    assert np.array_equal(dbg["normal"][has], info["normal"][has])
+    # round 4: sums, mean and covariance in the reference build's arithmetic (no fused multiply-add). Default solver mode (hybrid): the
+    # gate decisions above are the oracle's, normals and a2D to rounding; exact mode (Eigen's JacobiSVD restated, normal_a2d_exact,
+    # neighborhood.h:236-244,293-311): a2D and normals are the oracle's bit for bit wherever a neighbourhood is valid
+    assert np.abs(dbg["a2d"][has] - info["a2d"][has]).max() < 1e-9
+    planar = has & (info["a2d"] > 1e-3)
+    assert np.abs(dbg["normal"][planar] - info["normal"][planar]).max() < 1e-9
+    s.set_normals(1)
+    s.set_keypoints(raw, world0, t)
+    s.solve(pose0, sc.t_begin_end, o)
+    dbx = s.get_debug()
+    s.set_normals(0)
+    assert np.array_equal(dbx["used"], info["used"])
+    assert np.array_equal(dbx["a2d"][has], info["a2d"][has])
+    assert np.array_equal(dbx["normal"][has], info["normal"][has])
     scale = np.abs(Ao).max()
     assert np.abs(A - Ao).max() < 1e-10 * scale and np.abs(b - bo).max() < 1e-10 * max(np.abs(bo).max(), 1e-30) + 1e-14
     # and the solve that followed
@@ -319,9 +329,12 @@ def test_pools_give_the_same_neighbours_as_searching_every_iteration(box_case, n
                   _opts(num_iters_icp=8, min_number_neighbors=10, threshold_orientation_norm=0.0), _prior(nclt_case, 8)[0]))
     for gmap, sc, raw, t, pose0, world0, o, prior in cases:
         runs = []
-        for pools in (0, 1):
+        # pools off | pools on (round 4: from the third search on the check is a kernel of its own, k_pool_check, and the search kernel runs
+        # over the list of positions it could not certify) | pools on with that split switched off (phase V inside the search kernel)
+        for pools, mask in ((0, 0), (1, 0), (1, 1 << 19)):
             s = cia.GnSolver(gmap)
             s.set_pools(pools)
+            s.set_ablation(mask)
             s.set_debug(True)
             s.set_keypoints(raw, world0, t)
             s.gn_begin(pose0, sc.t_begin_end, o, prior)
@@ -332,13 +345,14 @@ def test_pools_give_the_same_neighbours_as_searching_every_iteration(box_case, n
                 per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["normal"].copy(), d["a2d"].copy(), d["farthest"].copy(), d["used"].copy()))
             pose, summ, _ = s.gn_end()
             runs.append((pose, summ, s.world_points(), per_iter))
-        (pose_a, summ_a, w_a, it_a), (pose_b, summ_b, w_b, it_b) = runs
-        assert summ_a.success and summ_a.num_iters == summ_b.num_iters == o.num_iters_icp and summ_a.num_residuals_used == summ_b.num_residuals_used
-        assert np.array_equal(pose_a, pose_b) and np.array_equal(w_a, w_b)
-        for k_it, (a, b) in enumerate(zip(it_a, it_b)):
-            assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and a[0][2] == b[0][2], k_it
-            for x, y in zip(a[1:], b[1:]):
-                assert np.array_equal(x, y), k_it
+        pose_a, summ_a, w_a, it_a = runs[0]
+        for which, (pose_b, summ_b, w_b, it_b) in enumerate(runs[1:]):
+            assert summ_a.success and summ_a.num_iters == summ_b.num_iters == o.num_iters_icp and summ_a.num_residuals_used == summ_b.num_residuals_used
+            assert np.array_equal(pose_a, pose_b) and np.array_equal(w_a, w_b), which
+            for k_it, (a, b) in enumerate(zip(it_a, it_b)):
+                assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and a[0][2] == b[0][2], (which, k_it)
+                for x, y in zip(a[1:], b[1:]):
+                    assert np.array_equal(x, y), (which, k_it)
         # the instrumented instantiation says how many keypoints the pools certified per iteration
         s = cia.GnSolver(gmap)
         s.set_pools(1); s.set_variant(3)
@@ -1302,7 +1316,15 @@ def test_km_scale_world_coordinates(street_case, mode):
     # gate decisions are index work: bit-exact (round 4: the sums, the covariance and the SVD run in the reference build's arithmetic, so
     # the value the |d| < 0.3 gate tests is the oracle's own, however badly conditioned it is 5 km from the origin)
     assert np.array_equal(dbg["used"], info["used"]) and n_used == no
-    assert np.array_equal(dbg["a2d"][has], info["a2d"][has]) and np.array_equal(dbg["normal"][has], info["normal"][has])
+    # default (hybrid) solver: same covariance bits, solver difference ~1e-15 / a2D^2; exact mode: the oracle's bits
+    assert np.abs(dbg["a2d"][has] - info["a2d"][has]).max() < 1e-8
+    s.set_normals(1)
+    s.set_keypoints(raw, world0, t)
+    s.solve(pose0, sc.t_begin_end, o)
+    dbx = s.get_debug()
+    s.set_normals(0)
+    assert np.array_equal(dbx["used"], info["used"])
+    assert np.array_equal(dbx["a2d"][has], info["a2d"][has]) and np.array_equal(dbx["normal"][has], info["normal"][has])
     assert np.abs(A - Ao).max() < 1e-4 * np.abs(Ao).max()
     o = _opts(num_iters_icp=6, threshold_orientation_norm=0.0)
     s.set_debug(False)
@@ -1601,9 +1623,9 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
            "--d-sweeps", "1", "--d-radius", "45", "--no-pmc"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = r.stdout.strip().splitlines()
-    assert len(lines) == 1 and len(lines[0]) < 4096, [len(ln) for ln in lines]      # stdout is the one compact line and nothing else
-    d = json.loads(lines[0])
+    lines = r.stdout.strip().splitlines()           # (torch's gloo backend announces its ranks on stdout; the line the driver parses is the LAST one)
+    assert len(lines[-1]) < 4096 and sum(ln.startswith("{") for ln in lines) == 1, [len(ln) for ln in lines]
+    d = json.loads(lines[-1])
     full = json.load(open(os.path.join(root, "bench_detail.json")))                 # everything else: the detail file
     assert full["value"] == d["value"]
     d["parity"] = full["parity"]
