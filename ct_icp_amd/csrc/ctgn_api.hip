@@ -633,9 +633,13 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
     // From the third search of a solve on (nearly) every keypoint has a pool: the pool check runs as a kernel of its own and the search
     // kernel only over the list of positions it could not certify (k_pool_check). Bit 19 of the ablation mask switches the split off (A/B).
+    // (measured: the 132 k-keypoint sweep loses 25 us per launch to the split — its pool check is bound by the scattered gathers of the pool
+    // members, which the fused kernel overlaps with the search rounds of the waves that are done checking; config D, whose 14 k waves queue
+    // anyway, gains 2.6 % per step)
+    constexpr int SPLIT_MIN_KEYPOINTS = 400000;
     static const int env_split = [] { const char *e = std::getenv("CTGN_SPLIT"); return e ? std::atoi(e) : -1; }();               // measurement hook
     const bool split = rows_ok && h->variant == 0 && kv.kth_valid && kv.pools && h->searches_in_solve >= 3 && kv.order == nullptr &&
-                       h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : !(h->ablate & (1 << 19)));
+                       h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : (h->n_kp >= SPLIT_MIN_KEYPOINTS && !(h->ablate & (1 << 19))));
     if (search_only && (h->variant == 1 || !rows_ok))
         return fail(h, CTGN_ERR_UNSUPPORTED, "the robust route needs the row kernel: voxel_neighborhood 1 or 2, <= 64 points per voxel");
     if (h->variant == 1 || !rows_ok) {
@@ -1172,6 +1176,9 @@ ctgn_status ctgn_map_radius_search(ctgn_handle h, const double *queries, size_t 
 // ---------------------------------------------------------------------------------------- keypoints
 // (re)size the keypoint arrays for n keypoints and reset the per-upload state
 static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
+    // a solve begun but not yet launched may still point at the pose behind the keypoint arrays (ctgn_register uploads it there, and the
+    // state initialisation is deferred to the solve's first launch): consume it in stream order before the arrays are replaced
+    { ctgn_status fs = flush_state_init(h); if (fs != CTGN_OK) return fs; }
     if ((int) n > h->cap_kp) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_kp) HIPCHK(h, hipFree(h->d_kp));
@@ -1367,6 +1374,7 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
         // the same initial pose as the last upload (a registration retried / repeated on the same keypoints): it is on the device already
     } else {
         if (h->gn_active) HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->pose_in_valid = false;                     // h_pose_in changes now; valid again only once the copy is enqueued
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->pose_in_valid = true;
@@ -1655,45 +1663,57 @@ ctgn_status ctgn_set_keypoints_sharded(ctgn_handle h, ctgn_view raw, ctgn_view w
     return save_world0(h);
 }
 
+// A rank that cannot go on (its gn_begin failed: a timestamp of ITS shard outside the frame; a launch or a map view failed mid-loop) while
+// its peers, whose shards are fine, wait in the all-reduce: it still takes part in every remaining exchange, with a poisoned count — every
+// rank's solve kernel sees the negative sum, stops before the pose changes and reports GN_FAILED_PEER. All ranks fail together.
+static void join_remaining_exchanges_poisoned(ctgn_handle h, int remaining) {
+    if (remaining <= 0 || !h->d_sys || !h->comm) return;
+    double poison[CTGN_SYSTEM_DOUBLES] = {0.0};
+    poison[90] = GN_PEER_POISON;
+    bool ok = true;
+    for (int it = 0; ok && it < remaining; ++it) {
+        // (re-poisoned every time: the sum of the previous exchange is what the buffer holds now, and it must stay negative whatever the peers add)
+        ok = hipMemcpyAsync(h->d_sys, poison, sizeof(poison), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+             hipStreamSynchronize(h->stream) == hipSuccess &&
+             rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess;
+    }
+    hipStreamSynchronize(h->stream);
+}
+
 ctgn_status ctgn_solve_sharded(ctgn_handle h, double pose_io[14], const double tbe[2], const ctgn_options *opts,
                                const ctgn_motion_prior *prior, ctgn_summary *summary) {
     NEED_DEVICE(h);
     if (!h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
-    ctgn_status st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
-    if (st != CTGN_OK && opts && opts->num_iters_icp > 0 && opts->num_iters_icp <= 1000 && h->d_sys) {
-        // This rank cannot start (a timestamp of ITS shard outside the frame, a failed launch ...) while its peers, whose shards were
-        // fine, are about to wait in the all-reduce. Fail together: take part in every exchange with a poisoned count; every rank's
-        // solve kernel sees the negative sum, stops before the pose changes and reports GN_FAILED_PEER.
+    // the options are the same on every rank: rejecting them here stops all ranks before any of them waits for another
+    if (!opts || !pose_io || !tbe || opts->num_iters_icp < 0) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_solve_sharded: pose, frame times and options are required");
+    const int iters = opts->num_iters_icp;
+    auto give_up = [&](ctgn_status st, int exchanges_left) {
         const std::string own_error = ctgn_last_error(h);
-        double poison[CTGN_SYSTEM_DOUBLES] = {0.0};
-        poison[90] = GN_PEER_POISON;
-        bool ok = hipMemcpyAsync(h->d_sys, poison, sizeof(poison), hipMemcpyHostToDevice, h->stream) == hipSuccess;
-        for (int it = 0; ok && it < opts->num_iters_icp; ++it)
-            ok = rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream) == ncclSuccess;
-        hipStreamSynchronize(h->stream);
+        join_remaining_exchanges_poisoned(h, exchanges_left);
         h->gn_active = false;
         fail(h, st, own_error);
         if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", own_error.c_str()); }
         return st;
-    }
+    };
+    ctgn_status st = ctgn_gn_begin(h, pose_io, tbe, opts, prior);
+    if (st != CTGN_OK) return give_up(st, iters);
     MapView mv;
-    if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
-    for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {
+    st = make_map_view(h, -1.0, &mv);
+    if (st != CTGN_OK) return give_up(st, iters);
+    for (int it = 0; it < iters; ++it) {
         st = launch_accumulate(h, mv, it == 0);                    // this rank's shard -> per-block partials
-        if (st != CTGN_OK) break;
+        if (st != CTGN_OK) return give_up(st, iters - it);
         h->launched_iters++;
         st = launch_reduce_solve(h, 1);                             // -> packed system (96 doubles) in d_sys
-        if (st != CTGN_OK) break;
+        if (st != CTGN_OK) return give_up(st, iters - it);
         // the one exchange of the path: 78 J^T J | 12 J^T r | count | pad, summed over the ranks, in place, on this stream
         const ncclResult_t r = rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream);
-        if (r != ncclSuccess) { st = fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclAllReduce: ") + rccl_api().GetErrorString(r)); break; }
+        if (r != ncclSuccess) {                                     // the communicator itself failed: nothing left to take part in
+            fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclAllReduce: ") + rccl_api().GetErrorString(r));
+            return give_up(CTGN_ERR_HIP, 0);
+        }
         st = launch_reduce_solve(h, 2);                             // identical input on every rank -> identical pose, no broadcast
-    }
-    if (st != CTGN_OK) {
-        h->gn_active = false;
-        hipStreamSynchronize(h->stream);
-        if (summary) { std::memset(summary, 0, sizeof(*summary)); std::snprintf(summary->error_log, sizeof(summary->error_log), "%s", ctgn_last_error(h)); }
-        return st;
+        if (st != CTGN_OK) return give_up(st, iters - it - 1);
     }
     return ctgn_gn_end(h, pose_io, summary);
 }
@@ -1790,6 +1810,10 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         if (gs == CTGN_OK) gs = device_minmax(h, h->d_tp + 3 * c, n, &lo, &hi);
         if (gs != CTGN_OK) return gs;
         if (!(tbe[0] <= lo && hi <= tbe[1])) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+        // a solve begun but not yet launched still points at d_pose_in (its state initialisation is deferred to its first launch):
+        // consume that pose in stream order before it is overwritten
+        { ctgn_status fs = flush_state_init(h); if (fs != CTGN_OK) return fs; }
+        h->pose_in_valid = false;
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->pose_in_valid = true;
@@ -1826,6 +1850,18 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     auto tp_now = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp_t0).count(); };
     double tp_gather = 0;
     bool in_range = true;
+    // an error in the middle of the pipeline must not return while copies into the pinned staging (and from it into the caller's
+    // buffers) are still in flight on either stream: drain both first
+#define TPCHK(call)                                                                                                  \
+    do {                                                                                                             \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess) {                                                                                      \
+            (void) hipStreamSynchronize(h->stream);                                                                  \
+            (void) hipStreamSynchronize(h->stream_down);                                                             \
+            return fail(h, e_ == hipErrorOutOfMemory ? CTGN_ERR_OUT_OF_MEMORY : CTGN_ERR_HIP,                        \
+                        std::string("[HIP] ") + #call + " -> " + hipGetErrorString(e_));                             \
+        }                                                                                                            \
+    } while (0)
     for (size_t k = 0; k < nchunks && in_range; ++k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
         const double tg = tp_timing ? tp_now() : 0;
@@ -1840,16 +1876,17 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
         if (tp_timing) tp_gather += tp_now() - tg;
         if (!in_range) break;
         const size_t lo = k == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;                       // the first chunk carries the pose
-        HIPCHK(h, hipMemcpyAsync(d_in + lo, h_in + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        TPCHK(hipMemcpyAsync(d_in + lo, h_in + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_transform_points, dim3(grid_for(j1 - j0)), dim3(256), 0, h->stream, d_in + 16 + 4 * j0, d_out + 3 * j0, (int) (j1 - j0), (size_t) 1,
                            d_in, tbe[0], tbe[1], (const uint32_t *) nullptr, (size_t) 0, (size_t) 4, 1);
-        HIPCHK(h, hipGetLastError());
+        TPCHK(hipGetLastError());
         // the result travels back on a second stream, beside the uploads of the chunks behind it
-        HIPCHK(h, hipEventRecord(h->tp_events[nchunks + k], h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->stream_down, h->tp_events[nchunks + k], 0));
-        HIPCHK(h, hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream_down));
-        HIPCHK(h, hipEventRecord(h->tp_events[k], h->stream_down));
+        TPCHK(hipEventRecord(h->tp_events[nchunks + k], h->stream));
+        TPCHK(hipStreamWaitEvent(h->stream_down, h->tp_events[nchunks + k], 0));
+        TPCHK(hipMemcpyAsync(h_out + 3 * j0, d_out + 3 * j0, 3 * (j1 - j0) * sizeof(double), hipMemcpyDeviceToHost, h->stream_down));
+        TPCHK(hipEventRecord(h->tp_events[k], h->stream_down));
     }
+#undef TPCHK
     const double tp_enq = tp_timing ? tp_now() : 0;
     if (!in_range) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2307,6 +2344,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
         d_pose = h->d_kp + 7 * (size_t) h->kp_stride;
         h->pose_on_device = false;
     } else {
+        h->pose_in_valid = false;
         for (int i = 0; i < 14; ++i) h->h_pose_in[i] = pose_io[i];
         HIPCHK(h, hipMemcpyAsync(h->d_pose_in, h->h_pose_in, 14 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->pose_in_valid = true;

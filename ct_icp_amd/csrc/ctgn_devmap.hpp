@@ -20,7 +20,6 @@ namespace ctgn {
 struct SortScratch {
     uint32_t *hist = nullptr;                  // [256][columns] digit counts -> exclusive offsets
     unsigned long long *bits = nullptr;        // [2]: OR of all keys, AND of all keys
-    size_t cap = 0;
 };
 
 struct DevCounters {

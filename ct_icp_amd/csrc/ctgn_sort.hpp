@@ -28,13 +28,17 @@ constexpr int SORT_SMALL_THREADS = 1024;
 constexpr int SORT_MAX_COLS = 512;             // per-wave tiles of the large path (columns of the histogram matrix): the tile grows with n
 
 inline hipError_t sort_scratch_reserve(SortScratch &S, size_t n) {
-    if (S.hist) return hipSuccess;               // fixed size: the tile grows with n so that the columns stay <= SORT_MAX_COLS
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&S.hist), (size_t) 256 * SORT_MAX_COLS * sizeof(uint32_t));
-    if (e != hipSuccess) return e;
-    e = hipMalloc(reinterpret_cast<void **>(&S.bits), 2 * sizeof(unsigned long long));
-    if (e != hipSuccess) return e;
-    S.cap = std::max<size_t>(n, 1);
-    return hipSuccess;
+    (void) n;
+    if (S.hist && S.bits) return hipSuccess;     // fixed size: the tile grows with n so that the columns stay <= SORT_MAX_COLS
+    hipError_t e = hipSuccess;
+    if (!S.hist) e = hipMalloc(reinterpret_cast<void **>(&S.hist), (size_t) 256 * SORT_MAX_COLS * sizeof(uint32_t));
+    if (e == hipSuccess && !S.bits) e = hipMalloc(reinterpret_cast<void **>(&S.bits), 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) {                       // all or nothing: a half-reserved scratch must not look reserved to the next call
+        if (S.hist) (void) hipFree(S.hist);
+        if (S.bits) (void) hipFree(S.bits);
+        S.hist = nullptr; S.bits = nullptr;
+    }
+    return e;
 }
 
 inline void sort_scratch_free(SortScratch &S) {

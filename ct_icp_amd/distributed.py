@@ -109,18 +109,31 @@ class ShardedGnSolver:
         s = self.solver
         if self.library_collective:
             return s.solve_sharded(pose14, t_begin_end, options, motion_model)
+        # fail TOGETHER (as ctgn_solve_sharded does): a rank that cannot start, or that fails in the middle of the loop, still takes part
+        # in every remaining exchange with a poisoned count (-1e300) — the peers' solve step sees the negative sum and stops with an
+        # error too instead of waiting in the all-reduce for ever
+        def join_poisoned(exchanges_left):
+            for _ in range(exchanges_left):
+                self.system.zero_()
+                self.system[90] = -1e300
+                allreduce_system(self.system, self.group)
+
+        iters = int(options.num_iters_icp)
         try:
             s.gn_begin(pose14, t_begin_end, options, motion_model)
         except Exception:
-            # fail TOGETHER (as ctgn_solve_sharded does): the peers are about to wait in the all-reduce, so take part in every
-            # exchange with a poisoned count (-1e300): their solve step sees the negative sum and stops with an error too
-            self.system.zero_()
-            self.system[90] = -1e300
-            for _ in range(options.num_iters_icp):
-                allreduce_system(self.system, self.group)
+            join_poisoned(iters)
             raise
-        for _ in range(options.num_iters_icp):
-            s.gn_accumulate()                      # local shard -> packed system in self.system
+        for it in range(iters):
+            try:
+                s.gn_accumulate()                  # local shard -> packed system in self.system
+            except Exception:
+                join_poisoned(iters - it)
+                raise
             allreduce_system(self.system, self.group)
-            s.gn_solve_update()                    # identical on every rank
+            try:
+                s.gn_solve_update()                # identical on every rank
+            except Exception:
+                join_poisoned(iters - it - 1)
+                raise
         return s.gn_end()

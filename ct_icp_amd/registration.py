@@ -125,7 +125,11 @@ def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end, out=No
     fresh 3 MB array costs its page faults on every call."""
     if L.is_device_tensor(raw):
         import torch
-        out = torch.empty((len(raw), 3), dtype=torch.float64, device=raw.device)
+        if out is None:
+            out = torch.empty((len(raw), 3), dtype=torch.float64, device=raw.device)
+        elif not (L.is_device_tensor(out) and out.dtype == torch.float64 and tuple(out.shape) == (len(raw), 3) and out.is_contiguous()
+                  and out.device == raw.device):
+            raise ValueError("transform_points: `out` for device inputs must be a contiguous N x 3 float64 tensor on the same device")
         pose = np.ascontiguousarray(pose14, dtype=np.float64)
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
         dp = C.POINTER(C.c_double)

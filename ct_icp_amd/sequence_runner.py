@@ -37,15 +37,18 @@ def _se3_advance(a7: np.ndarray, b7: np.ndarray) -> np.ndarray:
     return np.concatenate([q, t])
 
 
-def constant_velocity_guess(prev_pose14: np.ndarray, prev_prev_pose14: np.ndarray | None = None) -> np.ndarray:
+def constant_velocity_guess(prev_pose14: np.ndarray, prev_prev_pose14: np.ndarray | None = None, third_frame: bool = False) -> np.ndarray:
     """Odometry::InitializeMotion with INIT_CONSTANT_VELOCITY and CONTINUOUS motion compensation (odometry.cpp:293-325):
     end = T_end(k-1) T_end(k-2)^-1 T_end(k-1) (a full SE(3) product: the previous translation increment is ROTATED by the relative
     rotation); begin = T_end(k-1) for the second registered frame (:294-300), T_begin(k-1) T_begin(k-2)^-1 T_begin(k-1) afterwards
-    (:311-316). Without the frame before the previous one, the previous frame's own begin pose stands in for T_end(k-2)."""
+    (:311-316); the third frame (index 2, `third_frame`) starts at T_end(1) and ends at T_end(1) T_end(0)^-1 T_end(1) (:296-300).
+    Without the frame before the previous one, the previous frame's own begin pose stands in for T_end(k-2)."""
     pb, pe = prev_pose14[0:7], prev_pose14[7:14]
     if prev_prev_pose14 is None:
         return np.concatenate([pe, _se3_advance(pe, pb)])
     ppb, ppe = prev_prev_pose14[0:7], prev_prev_pose14[7:14]
+    if third_frame:                       # odometry.cpp:296-300: begin = T_end(1), end = T_end(1) T_end(0)^-1 T_end(1)
+        return np.concatenate([pe, _se3_advance(pe, ppe)])
     return np.concatenate([_se3_advance(pb, ppb), _se3_advance(pe, ppe)])
 
 
@@ -83,7 +86,9 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
             r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, override_timestamp=override, want_all=False)
         else:
             # odometry.cpp:293-300: the frame right after the bootstrap starts at the previous end pose; later ones extrapolate both ends
-            guess = constant_velocity_guess(prev, prev2 if j >= init_frames + 1 and j >= 3 else None)
+            # (frame index 2 uses T_end(0), :296-300; a frame right after a ground-truth bootstrap keeps starting at the previous end pose)
+            use_prev2 = j >= 2 and (init_poses is None or j >= init_frames + 1)
+            guess = constant_velocity_guess(prev, prev2 if use_prev2 else None, third_frame=(j == 2))
             mm.previous_frame = TrajectoryFrame.from_pose14(prev, tbe[0] - frame_period, tbe[0])
             r = fp.frame(raw, t, guess, tbe, options, max_distance, motion_model=mm if use_motion_model else None, order=order,
                          override_timestamp=override, want_all=False)

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r.get("Kernel_Name", "")
-    if "k_accumulate" not in k and "k_reduce" not in k and "k_residual" not in k:
+    if "k_accumulate" not in k and "k_reduce" not in k and "k_residual" not in k and "k_pool_check" not in k:
         continue
     agg[k.split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
