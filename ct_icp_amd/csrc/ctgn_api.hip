@@ -110,6 +110,7 @@ struct ctgn_context {
     size_t tp_cap = 0;
     std::vector<hipEvent_t> tp_events;  // per 32 k-point chunk of a host-view ctgn_transform_points: its result has arrived | its kernel is done
     hipStream_t stream_down = nullptr;  // results travel back on their own stream, beside the uploads of the chunks behind them
+    hipEvent_t ev_frame = nullptr;      // frame pipeline: the undistorted frame is ready (the outputs' stream waits for it)
     HostPool pool;                      // helper threads of the scan-sized host loops (created on first use)
 
     // solver
@@ -957,6 +958,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->h_tp) hipHostFree(h->h_tp);
         for (auto &e : h->tp_events) hipEventDestroy(e);
         if (h->stream_down) hipStreamDestroy(h->stream_down);
+        if (h->ev_frame) hipEventDestroy(h->ev_frame);
         if (h->d_res) hipFree(h->d_res);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
@@ -995,6 +997,11 @@ ctgn_status ctgn_map_set_update_mode(ctgn_handle h, int32_t device_updates) {
         h->devlevels.resize(h->levels.size());
         for (size_t i = 0; i < h->levels.size(); ++i)
             DMCHK(h, devmap_level_init(h->devlevels[i], h->levels[i].resolution, h->levels[i].min_distance, h->levels[i].blk, h->stream));
+    }
+    if (device_updates == 1) {
+        // the frame pipeline's second stream and its event: created here, not inside the first frame (a stream costs ~0.3 ms to create)
+        if (!h->stream_down) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+        if (!h->ev_frame) HIPCHK(h, hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
     }
     h->update_mode = device_updates;
     return CTGN_OK;
@@ -1967,10 +1974,45 @@ static ctgn_status frame_reserve(ctgn_handle h, size_t n) {
 }
 
 
+// `fused_max_distance` (ctgn_frame on the GN route): the map update of this frame — far-voxel eviction round the NEW end pose, then
+// the insertion of the undistorted sampled frame unless the registration failed — is enqueued right behind the undistortion, with the
+// location and the gate read from the device's own state, while the frame's outputs travel to the host on a second stream and are
+// handed over there: the update no longer waits for a host round trip, and the hand-over no longer waits for the update.
+static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance);
+
 ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
                                 const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
                                 const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
                                 ctgn_frame_outputs *out, ctgn_summary *summary) {
+    return frame_register_impl(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, nullptr);
+}
+
+// the read-backs a fused map update deferred: counters of every level, then the checks devmap_insert_staged makes
+static ctgn_status frame_finish_map_update(ctgn_handle h) {
+    bool range_error = false, overflow = false;
+    hipError_t e = hipStreamSynchronize(h->stream);
+    for (auto &DL : h->devlevels) {
+        if (e == hipSuccess) e = devmap_level_read_counters(DL, h->stream);
+        range_error = range_error || DL.host.range_error;
+        overflow = overflow || DL.host.overflow;
+    }
+    if (e != hipSuccess) return fail(h, CTGN_ERR_HIP, std::string("[HIP] frame map update -> ") + hipGetErrorString(e));
+    if (overflow) return fail(h, CTGN_ERR_HIP, "device map capacity exhausted (internal sizing error)");
+    if (range_error) {
+        for (auto &DL : h->devlevels) (void) hipMemsetAsync(&DL.counters->range_error, 0, sizeof(unsigned int), h->stream);
+        h->insert_calls_with_skips++;
+        h->last_error = "a point fell outside the 21-bit voxel key range (or was not finite) and was skipped";
+    }
+    return CTGN_OK;
+}
+
+static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
     NEED_DEVICE(h);
     if (summary) std::memset(summary, 0, sizeof(*summary));
     if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
@@ -2146,19 +2188,63 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
     if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1, d_pose,
                                      tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4);
     HIPCHK(h, hipGetLastError());
-    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const bool fuse = fused_max_distance != nullptr && !robust && h->update_mode == 1;
+    hipStream_t s_out = h->stream;
+    if (fuse) {
+        // the outputs go home on the second stream; the map update follows the undistortion on the first
+        if (!h->stream_down) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+        if (!h->ev_frame) HIPCHK(h, hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_frame, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_down, h->ev_frame, 0));
+        s_out = h->stream_down;
+    }
+    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_world_base && n1)
-        HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_indices && n1)
-        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
     if (out && out->keypoint_indices && n2)
-        HIPCHK(h, hipMemcpyAsync(F.h_sel + c, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    mark(4);                                          // undistortion + read-backs enqueued
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    mark(5);                                          // everything on the host
+        HIPCHK(h, hipMemcpyAsync(F.h_sel + c, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
+    bool update_pending = false;
+    if (fuse) {
+        // odometry.cpp:936-952 on the device's own copy of the new pose: eviction round its end translation, then the sampled frame —
+        // unless the registration failed (GnState::failed, read by the insert kernel itself)
+        const int *d_failed = reinterpret_cast<const int *>(reinterpret_cast<const char *>(h->d_state) + offsetof(GnState, failed));
+        h->kth_fresh = false;
+        update_pending = true;
+        hipError_t e = hipSuccess;
+        for (auto &DL : h->devlevels)
+            if (e == hipSuccess) e = devmap_level_remove_far_enqueue(DL, d_pose + 11, *fused_max_distance, h->stream);
+        if (e == hipSuccess && n1) {
+            DevMapScratch &S = h->dm;
+            double *own_pts = S.pts;
+            const size_t own_stride = S.stride;
+            S.pts = F.d_corr;                          // the undistorted sampled frame is the batch: nothing is copied
+            S.stride = F.stride;
+            e = hipMemsetAsync(S.inserted, 0, n1, h->stream);
+            for (auto &DL : h->devlevels)
+                if (e == hipSuccess) e = devmap_level_insert_enqueue(DL, S, n1, d_failed, h->stream);
+            S.pts = own_pts;
+            S.stride = own_stride;
+        }
+        if (e != hipSuccess) {
+            (void) hipStreamSynchronize(h->stream_down);
+            (void) frame_finish_map_update(h);
+            return fail(h, CTGN_ERR_HIP, std::string("[HIP] frame map update -> ") + hipGetErrorString(e));
+        }
+    }
+    mark(4);                                          // undistortion + read-backs (+ map update) enqueued
+    // the final state was enqueued before the undistortion: with its event complete it is on the host (a stream that holds nothing
+    // but a wait is not a reliable thing to synchronise with); then the outputs
+    if (fuse) HIPCHK(h, hipEventSynchronize(h->ev_frame));
+    HIPCHK(h, hipStreamSynchronize(s_out));           // the outputs — and, enqueued before them, the final state — are on the host
+    mark(5);
     if (!robust) {
         st = gn_collect(h, pose_io, summary);
-        if (st != CTGN_OK) return st;
+        if (st != CTGN_OK) {
+            if (update_pending) (void) frame_finish_map_update(h);
+            return st;
+        }
     }
     if (summary) summary->duration_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     if (out) {
@@ -2194,6 +2280,10 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
             for (size_t k = 0; k < n2; ++k) out->keypoint_indices[k] = order ? order[F.h_sel[c + k]] : F.h_sel[c + k];
     }
     F.valid = true;
+    if (update_pending) {                             // (the hand-over above ran beside it)
+        st = frame_finish_map_update(h);
+        if (st != CTGN_OK) return st;
+    }
     if (timing) {
         mark(6);
         std::fprintf(stderr, "[ctgn] frame_register us: stage+upload enqueue %.0f | enqueue samplers %.0f | wait counts %.0f | keypoints+registration "
@@ -2240,6 +2330,9 @@ ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, con
     if (!summary) summary = &local;
     if (h && h->update_mode != 1)
         return fail(h, CTGN_ERR_UNSUPPORTED, "the frame pipeline updates the device-resident map (ctgn_map_set_update_mode(h, 1))");
+    static const bool unfused = std::getenv("CTGN_FRAME_UNFUSED") != nullptr;        // measurement hook: the two calls one after the other, as until round 3
+    if (!robust && !unfused)       // GN route: the map update is enqueued inside, behind the undistortion (frame_register_impl)
+        return frame_register_impl(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, &max_distance);
     ctgn_status st = ctgn_frame_register(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary);
     if (st != CTGN_OK) return st;
     return ctgn_frame_update_map(h, pose_io + 11, max_distance, summary->success, nullptr);

@@ -44,7 +44,8 @@ __global__ void k_dm_keys(const double *pts, size_t cap, size_t n, double resolu
 // order (the sort is stable), with the reference's rule (map.h:261-293).
 __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk, uint32_t nblocks_cap, uint32_t *free_list,
                             DevCounters *cnt, const uint64_t *keys, const uint32_t *idx, size_t n, const double *pts, size_t cap,
-                            double min_dist_sq, uint8_t *inserted) {
+                            double min_dist_sq, uint8_t *inserted, const int *skip) {
+    if (skip && *skip) return;                            // the frame pipeline's gate: the registration that produced the batch failed
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i];
@@ -111,7 +112,8 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
 
 // RemoveElementsFarFromLocation (map.h:305-322): voxel removed iff ||first point - location|| > distance.
 __global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *blocks, int blk, uint32_t *free_list, DevCounters *cnt,
-                                double lx, double ly, double lz, double distance, double resolution) {
+                                double lx, double ly, double lz, double distance, double resolution, const double *loc_dev) {
+    if (loc_dev) { lx = loc_dev[0]; ly = loc_dev[1]; lz = loc_dev[2]; }      // the location lives on the device (a pose the host has not seen yet)
     for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         const Slot s = slots[i];
         if (s.key == KEY_EMPTY || s.key == KEY_TOMB) continue;
@@ -399,8 +401,10 @@ static hipError_t ensure_capacity(DevLevel &L, size_t n, hipStream_t stream) {
         uint32_t *nf = nullptr;
         DM_CHK(hipMalloc(reinterpret_cast<void **>(&nb), want * 3 * L.blk * sizeof(double)));
         DM_CHK(hipMalloc(reinterpret_cast<void **>(&nf), want * sizeof(uint32_t)));
-        DM_CHK(hipMemcpyAsync(nb, L.blocks, (size_t) L.host.next_block * 3 * L.blk * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        if (free_blocks) DM_CHK(hipMemcpyAsync(nf, L.free_list, free_blocks * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        // the WHOLE old pool and free list, not just what the last counter read-back knew of: the frame pipeline plans an insertion
+        // while the eviction in front of it (which pushes onto the free list) is still in flight, its counters unread
+        DM_CHK(hipMemcpyAsync(nb, L.blocks, (size_t) L.nblocks_cap * 3 * L.blk * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        DM_CHK(hipMemcpyAsync(nf, L.free_list, (size_t) L.nblocks_cap * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         DM_CHK(hipStreamSynchronize(stream));
         DM_CHK(hipFree(L.blocks));
         DM_CHK(hipFree(L.free_list));
@@ -413,6 +417,16 @@ static hipError_t ensure_capacity(DevLevel &L, size_t n, hipStream_t stream) {
 
 hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    DM_CHK(devmap_level_insert_enqueue(L, S, n, nullptr, stream));
+    return read_counters(L, stream);
+}
+
+hipError_t devmap_level_read_counters(DevLevel &L, hipStream_t stream) { return read_counters(L, stream); }
+
+// The kernels of an insertion without the counter read-back (the caller reads them later: devmap_level_read_counters). Capacity is
+// planned from the counters as last read — every removal since then only freed room. `skip` (device, may be null): non-zero = leave the map alone.
+hipError_t devmap_level_insert_enqueue(DevLevel &L, DevMapScratch &S, size_t n, const int *skip, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
     DM_CHK(ensure_capacity(L, n, stream));
     const unsigned grid = (unsigned) ((n + 255) / 256);
     hipLaunchKernelGGL(k_dm_keys, dim3(grid), dim3(256), 0, stream, S.pts, S.stride, n, L.resolution, S.keys, S.idx, L.counters);
@@ -420,9 +434,8 @@ hipError_t devmap_level_insert(DevLevel &L, DevMapScratch &S, size_t n, hipStrea
     // stable: the points of a voxel stay in batch order, which is what the insert rule walks (map.h:261-293)
     DM_CHK(sort_pairs<uint64_t>(S.sort, S.keys, S.keys_alt, S.idx, S.idx_alt, n, 64, true, stream));
     hipLaunchKernelGGL(k_dm_insert, dim3(grid), dim3(256), 0, stream, L.slots, (uint32_t) (L.slots_cap - 1), L.blocks, L.blk, L.nblocks_cap,
-                       L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.stride, L.min_distance * L.min_distance, S.inserted);
-    DM_CHK(hipGetLastError());
-    return read_counters(L, stream);
+                       L.free_list, L.counters, S.keys_alt, S.idx_alt, n, S.pts, S.stride, L.min_distance * L.min_distance, S.inserted, skip);
+    return hipGetLastError();
 }
 
 hipError_t devmap_grid_sampling(DevMapScratch &S, size_t n, double voxel_size, uint32_t *out_idx_host, size_t *out_count,
@@ -602,9 +615,16 @@ hipError_t devmap_test_compact(const uint8_t *flags_host, size_t n, uint32_t *ou
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {
     hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
-                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution);
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution, (const double *) nullptr);
     DM_CHK(hipGetLastError());
     return read_counters(L, stream);
+}
+
+// the same with the location read from device memory (3 doubles) and no counter read-back
+hipError_t devmap_level_remove_far_enqueue(DevLevel &L, const double *loc_dev, double distance, hipStream_t stream) {
+    hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, 0.0, 0.0, 0.0, distance, L.resolution, loc_dev);
+    return hipGetLastError();
 }
 
 hipError_t devmap_level_export(DevLevel &L, double *out_xyz, uint64_t cap_points, uint64_t *out_n, hipStream_t stream) {

@@ -214,7 +214,8 @@ class FramePipeline:
         self._h = voxel_map.handle
         self.frame_voxel_size, self.sample_voxel_size, self.max_num_keypoints = frame_voxel_size, sample_voxel_size, max_num_keypoints
 
-    def _call(self, fn, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all, want_sampled, extra):
+    def _call(self, fn, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all, want_sampled, extra,
+              all_world_out=None):
         raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
         t = np.ascontiguousarray(t, dtype=np.float64).ravel()
         n = len(raw)
@@ -226,9 +227,20 @@ class FramePipeline:
         out = L.FrameOutputs()
         res = {}
         if want_all:
-            res["all_world"] = np.zeros((n, 3))
+            # `all_world_out` (N x 3 float64, C-contiguous): write the undistorted scan there — the reference undistorts in place
+            # (odometry.cpp:461-486), and a fresh 3 MB array costs its page faults on every frame
+            if all_world_out is not None:
+                if not (isinstance(all_world_out, np.ndarray) and all_world_out.dtype == np.float64 and all_world_out.shape == (n, 3)
+                        and all_world_out.flags.c_contiguous):
+                    raise ValueError("all_world_out must be a C-contiguous N x 3 float64 array")
+                res["all_world"] = all_world_out
+            else:
+                res["all_world"] = np.zeros((n, 3))
             out.all_world_base, out.all_world_stride_bytes, out.all_world_dtype = res["all_world"].ctypes.data, 24, L.CTGN_F64
-        sampled_idx, kp_idx = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        if getattr(self, "_idx_cap", 0) < n:               # index staging, reused across frames (results are copied out below)
+            self._idx = np.zeros((2, max(n, 1)), dtype=np.uint32)
+            self._idx_cap = n
+        sampled_idx, kp_idx = self._idx[0], self._idx[1]
         out.sampled_indices, out.keypoint_indices = sampled_idx.ctypes.data, kp_idx.ctypes.data
         if want_sampled:
             sw = np.zeros((n, 3))
@@ -258,11 +270,11 @@ class FramePipeline:
         return res
 
     def register(self, raw, t, pose14, t_begin_end, options: CTICPOptions, motion_model=None, order=None, override_timestamp=None,
-                 want_all=True, want_sampled=True) -> dict:
+                 want_all=True, want_sampled=True, all_world_out=None) -> dict:
         """Sampling -> keypoints -> registration -> undistortion. Returns pose (14), summary, sampled_indices, keypoint_indices and
         (as asked) all_world / sampled_world."""
         return self._call(L.lib().ctgn_frame_register, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp,
-                          want_all, want_sampled, ())
+                          want_all, want_sampled, (), all_world_out)
 
     def update_map(self, location, max_distance: float, add_points: bool = True) -> np.ndarray | None:
         """UpdateMap for the frame register() left on the device; returns the `inserted` mask of the sampled frame."""
@@ -273,10 +285,11 @@ class FramePipeline:
         return mask[:getattr(self, "_last_n1", 0)] if add_points else None
 
     def frame(self, raw, t, pose14, t_begin_end, options: CTICPOptions, max_distance: float, motion_model=None, order=None,
-              override_timestamp=None, want_all=True, want_sampled=False) -> dict:
-        """register() + update_map(end translation, max_distance, success) in one call (always_insert policy)."""
+              override_timestamp=None, want_all=True, want_sampled=False, all_world_out=None) -> dict:
+        """register() + update_map(end translation, max_distance, success) in one call (always_insert policy). On the GN route the map
+        update is enqueued behind the undistortion and runs beside the hand-over of the outputs (ctgn_frame, round 4)."""
         return self._call(L.lib().ctgn_frame, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all,
-                          want_sampled, (C.c_double(float(max_distance)),))
+                          want_sampled, (C.c_double(float(max_distance)),), all_world_out)
 
 
 class GnSolver:

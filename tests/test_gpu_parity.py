@@ -905,6 +905,40 @@ def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
     assert np.array_equal(b["all_world"], want)
 
 
+def test_frame_call_with_a_failed_registration_leaves_the_map_to_the_eviction(street_case):
+    """Round 4: ctgn_frame enqueues the map update behind the undistortion with the gate read on the device (GnState::failed): a frame
+    whose registration fails softly (fewer than 100 keypoints pass, ct_icp.cpp:860-871) must not be inserted — exactly what the two
+    separate calls do with add_points = success — while the eviction round the (unchanged) pose still runs."""
+    case = street_case
+    mk = lambda: cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75, device_updates=True))
+    ga, gb = mk(), mk()
+    for j in range(4):
+        ga.InsertPointCloud(case["scans"][j].world_gt)
+        gb.InsertPointCloud(case["scans"][j].world_gt)
+    sc = case["scans"][4]
+    far = sc.pose_gt.copy(); far[4:7] += 500.0; far[11:14] += 500.0          # nowhere near the map: no neighbours, soft failure
+    o = _opts(num_iters_icp=3)
+    fa, fb = cia.FramePipeline(ga, 0.5, 1.5), cia.FramePipeline(gb, 0.5, 1.5)
+    ra = fa.register(sc.raw, sc.t, far, sc.t_begin_end, o, want_all=False, want_sampled=False)
+    assert not ra["summary"].success
+    fa.update_map(ra["pose"][11:14], 60.0, False)
+    rb = fb.frame(sc.raw, sc.t, far, sc.t_begin_end, o, 60.0, want_all=False, want_sampled=False)
+    assert not rb["summary"].success and np.array_equal(ra["pose"], rb["pose"])
+    assert ga.NumPoints() == gb.NumPoints() == 0              # everything lies farther than 60 m from the failed frame's pose: evicted, nothing inserted
+    # and a frame that succeeds on the same handle afterwards is inserted
+    for g in (ga, gb):
+        for j in range(4):
+            g.InsertPointCloud(case["scans"][j].world_gt)
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=5)
+    ra = fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, o, want_all=False, want_sampled=False)
+    fa.update_map(ra["pose"][11:14], 60.0, True)
+    rb = fb.frame(sc.raw, sc.t, pose0, sc.t_begin_end, o, 60.0, want_all=False, want_sampled=False)
+    assert ra["summary"].success and rb["summary"].success and np.array_equal(ra["pose"], rb["pose"])
+    assert ga.NumPoints() == gb.NumPoints() > 0
+    pa, pb = ga.MapAsPointCloud(), gb.MapAsPointCloud()
+    assert np.array_equal(pa[np.lexsort(pa.T[::-1])], pb[np.lexsort(pb.T[::-1])])
+
+
 def test_map_or_keypoints_changed_inside_a_stepwise_solve_drop_the_carried_bound(street_case):
     """Every search after the first of a solve is bounded by the previous search's k-th neighbour distance —
     valid only while map and keypoints stay what they were. The stepwise API lets a caller change either between two accumulate
