@@ -630,6 +630,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic, wait fractions)")
     ap.add_argument("--no-extras", action="store_true", help="skip frames/s, robust route, frame stages")
     ap.add_argument("--detail-stdout", action="store_true", help="also print the full detail object as an EARLIER stdout line (default: files only)")
+    ap.add_argument("--config-e-scale", type=int, default=100,
+                    help="config E (BASELINE.json configs[4]) on this one GPU inside the default line: 11 sequences, seeds 10-20, KITTI lengths / "
+                         "this (100 = 233 frames, ~20 s with scan generation; 10 = the size SURVEY.md 8d defines: scripts/sequence_run.py "
+                         "--config-e, profiles/r04_config_e_n1.json); 0 = skip")
     ap.add_argument("--clock-warm", type=int, default=CLOCK_WARM)
     ap.add_argument("--inner", action="store_true", help="the run the PMC passes profile: timed loop only, no extras")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -724,6 +728,15 @@ def main():
             # the same frame as ONE ctgn_frame_register + ctgn_frame_update_map (scan resident on the device)
             result["frame_pipeline"] = fs.pop("frame_pipeline")
             result["frame_pipeline"]["frames_per_sec"] = 1e3 / result["frame_pipeline"]["frame_ms"]
+            if default_line and args.config_e_scale > 0:
+                # config E on one GPU (no 8-GPU number is asked of this run): the 11 sequences back to back, one ctgn_frame call per frame
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("ctgn_sequence_run", os.path.join(ROOT, "scripts", "sequence_run.py"))
+                seq_mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(seq_mod)
+                ce = seq_mod.run_config_e(scale=args.config_e_scale, device=local_rank)
+                ce.pop("per_sequence_detail", None)
+                result["config_e"] = ce
         if not args.no_cpu_baseline and args.workload in ("B2", "B2-small") and world == 1:      # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(inp, W["pose0"], W["world0"], args, om)
             if result["cpu_baseline"]["value"]:
@@ -872,7 +885,7 @@ def compact_line(result) -> str:
     if isinstance(result.get("frame_pipeline"), dict):
         line["frame_pipeline"] = _pick(result["frame_pipeline"], "frame_ms", "register_ms", "update_map_ms", "frames_per_sec")
     if isinstance(result.get("config_e"), dict):
-        line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures")
+        line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures", "scale")
     for k in ("strong_scaling_single_gpu_reference", "weak_scaling_line"):
         if isinstance(result.get(k), dict):
             line[k] = _pick(result[k], "value", "ms_per_step", "keypoints", "keypoints_per_gpu", "scaling")

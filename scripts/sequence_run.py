@@ -215,8 +215,83 @@ def run_sequence_pipeline(seq, args, device: int):
                 err_rot_max=float(errs[:, 1].max()), map_points=r["map_points"])
 
 
+def config_e_sequences(scale: int = 10, azimuth_steps: int = None):
+    """SURVEY.md 8d config E = BASELINE.json configs[4] as defined: 11 synthetic sequences from the config-B generator (HDL-64E pattern,
+    procedural street, 10 m/s with a slow yaw oscillation), seeds 10-20, lengths = the KITTI odometry sequence lengths (reference
+    src/ct_icp/dataset.cpp:49-50) divided by `scale`. Yields (sequence id, frames, maker) longest first; maker() ray-casts the scans
+    (torch broadcast ray-caster: on the GPU when there is one) — one sequence in memory at a time (the longest is ~2 GB of points)."""
+    from ct_icp_amd import sequence_runner as sr
+    lengths = [max(3, int(round(L / scale))) for L in sr.KITTI_LENGTHS]
+    order, _ = sr.deal_sequences(lengths, 1)
+
+    def maker(sid):
+        frames, seed = lengths[sid], 10 + sid
+        scene = syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
+        dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps)
+        knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0)
+        scans = []
+        for j in range(frames):
+            sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=1000 * seed + j,
+                                   use_torch=True)
+            scans.append((sc.raw, sc.t, (0.1 * j, 0.1 * (j + 1))))
+        return scans, knots
+    return [(sid, lengths[sid], maker) for sid in order], lengths
+
+
+def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, init_frames: int = 5, solver_name: str = "GN", log=None,
+                 only=None, per_frame: bool = False, use_motion_model=None):
+    """One GPU, world size 1: the 11 sequences back to back, longest first, every frame ONE ctgn_frame call
+    (ct_icp_amd.sequence_runner.run_sequence). Aggregate frames/s = all frames / the sum of the sequences' loop times (what a rank of
+    run_batch reports); scan generation is outside the timed loops."""
+    from ct_icp_amd import sequence_runner as sr
+    seqs, lengths = config_e_sequences(scale, azimuth_steps)
+    solver = cia.GN if solver_name == "GN" else cia.CERES
+    results, t_gen = [], 0.0
+    warm = True
+    for sid, frames, maker in seqs:
+        if only is not None and sid not in only:
+            continue
+        t0 = time.perf_counter()
+        scans, knots = maker(sid)
+        t_gen += time.perf_counter() - t0
+        gt = [syn.frame_pose14(knots, j) for j in range(frames)]
+        kw = dict(device=device, solver=solver, voxel_size=0.5, sample_voxel_size=1.5, max_distance=100.0, init_poses=gt,
+                  init_frames=min(init_frames, frames), use_motion_model=use_motion_model)
+        if warm:                                        # first touches of the library (code objects, pinned staging): not a sequence's cost
+            sr.run_sequence(scans[:min(8, frames)], **kw)
+            warm = False
+        r = sr.run_sequence(scans, **kw)
+        errs = np.array([se3.pose_error(r["poses"][j], gt[j]) for j in range(kw["init_frames"], frames)] or [(0.0, 0.0)])
+        results.append(dict(sequence=sid, seed=10 + sid, frames=frames, seconds=r["seconds"], frames_per_sec=frames / r["seconds"],
+                            registered=frames - kw["init_frames"], failures=int(np.count_nonzero(~r["success"])),
+                            keypoints_mean=float(r["keypoints"][kw["init_frames"]:].mean()) if frames > kw["init_frames"] else 0.0,
+                            points_per_frame=float(np.mean([len(s[1]) for s in scans])),
+                            err_tr_max=float(errs[:, 0].max()), err_tr_mean=float(errs[:, 0].mean()), err_rot_max=float(errs[:, 1].max()),
+                            map_points=r["map_points"]))
+        if per_frame:
+            results[-1].update(err_tr=[float(e) for e in errs[:, 0]], success=[bool(v) for v in r["success"]],
+                               keypoints=[int(v) for v in r["keypoints"]], sampled=[int(v) for v in r["sampled"]])
+        if log:
+            log(f"config E: sequence {sid} ({frames} frames): {results[-1]['frames_per_sec']:.0f} frames/s, failures {results[-1]['failures']}, "
+                f"max |dt| {results[-1]['err_tr_max']:.3f} m")
+        del scans
+    frames = sum(r["frames"] for r in results)
+    seconds = sum(r["seconds"] for r in results)
+    return dict(metric="frames/s, whole per-frame loop (one ctgn_frame call per frame), config E on one GPU", frames_per_sec=frames / seconds,
+                frames=frames, sequences=len(results), wall_seconds=seconds, failures=sum(r["failures"] for r in results),
+                err_tr_max=max(r["err_tr_max"] for r in results), lengths=lengths, scale=f"KITTI lengths / {scale}", solver=solver_name,
+                bootstrap=f"the first {init_frames} frames of a sequence enter the map with their ground-truth poses",
+                scan_generation_seconds=t_gen, per_sequence=results)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config-e", action="store_true", help="BASELINE.json configs[4] as defined, on one GPU: 11 sequences, seeds 10-20, "
+                                                             "KITTI lengths / --scale, longest first")
+    ap.add_argument("--scale", type=int, default=10)
+    ap.add_argument("--only", default=None, help="config E: comma-separated sequence ids to run (diagnosis)")
+    ap.add_argument("--per-frame", action="store_true", help="config E: per-frame error / success / keypoint counts in the output")
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--sequences", type=int, default=1)
     ap.add_argument("--azimuth-steps", type=int, default=1000, help="4500 = the full 0.08 deg HDL-64E sweep")
@@ -233,6 +308,17 @@ def main():
     ap.add_argument("--host-map", action="store_true", help="maintain the map on the host mirror instead of the device")
     ap.add_argument("--pipeline", action="store_true", help="one ctgn_frame call per frame (scan resident on the device) instead of the stage calls")
     args = ap.parse_args()
+    if args.config_e:
+        res = run_config_e(scale=args.scale, azimuth_steps=None if args.azimuth_steps == 1000 else args.azimuth_steps, solver_name=args.solver,
+                           init_frames=args.init_frames, log=lambda m: print(m, file=sys.stderr, flush=True),
+                           only=None if args.only is None else [int(v) for v in args.only.split(",")], per_frame=args.per_frame,
+                           use_motion_model=True if args.gn_prior else None)
+        line = json.dumps(res)
+        if args.out:
+            with open(args.out, "w") as f:
+                f.write(line + "\n")
+        print(line)
+        return
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = int(os.environ.get("LOCAL_RANK", "0"))
     # KITTI-like relative lengths (src/ct_icp/dataset.cpp:49-50), longest first, dealt round-robin

@@ -1072,6 +1072,23 @@ def test_config_e_two_sequences_on_one_gpu(street_case):
         assert tr < 0.3 and rot < 5e-3, (j, tr, rot)
 
 
+def test_config_e_two_gloo_ranks_share_one_gpu():
+    """Config E as SURVEY.md 8d defines it (11 sequences, seeds 10-20, lengths proportional to the KITTI sequences, dealt longest first) at
+    1/400 of the lengths with a coarse scan pattern, as TWO gloo ranks on the one GPU: each rank generates and runs only its share, one
+    ctgn_frame call per frame, nothing is exchanged while they run; the gathered result holds every frame once and no registration fails.
+    (The size the survey defines runs through scripts/sequence_run.py --config-e: profiles/r04_config_e_n1.json.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29567",
+           os.path.join(root, "tests", "config_e_worker.py")]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["sequences"] == list(range(11)) and d["frames"] == sum(d["lengths"]) and len(d["shares"]) == 2
+    assert d["failures"] == 0 and d["err_max"] < 1.0, d
+
+
 # ------------------------------------------------------------------------------------------------- device-memory views
 def test_device_memory_views_match_host_views(street_case):
     """Every entry point that takes point views also takes them in device memory (torch CUDA tensors here): identical results,
