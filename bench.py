@@ -44,10 +44,15 @@ def _rocprof():
     return shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
 
 
-def collect_pmc(args, timeout: int = 300):
-    """Counters of the dominant kernel, collected LIVE by rocprofv3 passes (`--kernel-trace --pmc ...`, one pass per counter group,
+SEARCH_KERNELS = ("k_accumulate_rows", "k_pool_check", "k_accumulate_lane")      # what one neighbour search of an iteration launches
+
+
+def collect_pmc(args, workload=None, groups=None, steps=None, timeout: int = 300):
+    """Counters of the neighbour search, collected LIVE by rocprofv3 passes (`--kernel-trace --pmc ...`, one pass per counter group,
     no other trace domain — MI355X_MICROARCH.md "rocprofv3 PMC slots") over a short inner run of this same script and workload.
-    Returns (dict of per-launch means, source / reason string)."""
+    Per ITERATION: the counters of every search-kernel launch (k_accumulate_rows; from the third search of a solve on a 400 k-keypoint
+    frame also k_pool_check in front of it) summed over the second half of the inner run's iterations and divided by their number (one
+    k_residual_reduce launch = one iteration). Returns (dict of per-iteration means, source / reason string)."""
     import csv
     import glob
     import shutil
@@ -56,35 +61,50 @@ def collect_pmc(args, timeout: int = 300):
     exe = _rocprof()
     if exe is None:
         return {}, "rocprofv3 not found"
-    kernel = "k_accumulate_lane" if args.variant == 1 else "k_accumulate_rows"
-    groups = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"],
-              ["SQ_INSTS_VALU", "SQ_INSTS_SALU"]]
+    workload = workload or args.workload
+    if groups is None:
+        groups = [["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+                  ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"],
+                  ["SQ_INSTS_VALU", "SQ_INSTS_SALU"]]
+    optional = ("SQ_INSTS", "TCC_")
     vals = {}
     for counters in groups:
         out_dir = tempfile.mkdtemp(prefix="ctgn_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--inner", "--steps", str(min(args.steps, 20)), "--warmup", "0", "--workload", args.workload,
-               "--variant", str(args.variant), "--map-frames", str(args.map_frames), "--order", args.order]
+               sys.executable, os.path.join(ROOT, "bench.py"), "--inner", "--steps", str(steps or min(args.steps, 20)), "--warmup", "0", "--workload", workload,
+               "--variant", str(args.variant), "--map-frames", str(args.map_frames), "--order", args.order, "--d-sweeps", str(args.d_sweeps),
+               "--d-radius", str(args.d_radius)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, check=False)
-            got = {c: [] for c in counters}
+            rows = []                                           # (dispatch id, kernel kind, counter, value)
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") in got:
-                        got[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            for c, rows in got.items():
-                if not rows:
-                    if c.startswith("SQ_INSTS"):
-                        continue                                 # a nicety: the other passes stand without it
-                    return vals, f"rocprofv3 --pmc {c}: no rows for {kernel}"
-                rows = rows[len(rows) // 2:]                 # the second half of the inner run: clocks and caches are warm
-                vals[c] = sum(rows) / len(rows)
+                    name = r.get("Kernel_Name", "")
+                    kind = "search" if any(k in name for k in SEARCH_KERNELS) else "residual" if "k_residual_reduce" in name else None
+                    if kind:
+                        rows.append((int(r.get("Dispatch_Id", 0) or 0), kind, r.get("Counter_Name"), float(r["Counter_Value"])))
+            rows.sort(key=lambda x: x[0])
+            res_ids = sorted({d for d, kind, _, _ in rows if kind == "residual"})
+            if len(res_ids) < 2:
+                if all(c.startswith(optional) for c in counters):
+                    continue
+                return vals, f"rocprofv3 --pmc {' '.join(counters)}: no rows"
+            first = res_ids[len(res_ids) // 2 - 1]                 # iterations of the second half: clocks and caches are warm
+            n_iter = len(res_ids) - len(res_ids) // 2
+            for c in counters:
+                tot = sum(v for d, kind, cn, v in rows if kind == "search" and cn == c and first < d <= res_ids[-1])
+                if tot == 0 and not any(cn == c for _, _, cn, _ in rows):
+                    if c.startswith(optional):
+                        continue
+                    return vals, f"rocprofv3 --pmc {c}: no rows"
+                vals[c] = tot / n_iter
         except Exception as e:        # noqa: BLE001 — measurement nicety: never fail the bench over it
             return vals, f"rocprofv3 --pmc {' '.join(counters)}: {type(e).__name__}"
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
-    return vals, "live: rocprofv3 --kernel-trace --pmc, 4 passes (FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_INSTS_*), means over the second half of the launches"
+    return vals, (f"live: rocprofv3 --kernel-trace --pmc, {len(groups)} passes ({' | '.join(' '.join(g) for g in groups)}), per search iteration "
+                  "(all search-kernel launches of an iteration), means over the second half of the inner run")
 
 
 def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
@@ -413,11 +433,13 @@ def roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep,
                 roof[key]["pool_certified_frac"] = r["pool_certified_frac"]
     if "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
         wc = pmc["SQ_WAVE_CYCLES"]
-        roof.update({"wait_frac": pmc["SQ_WAIT_ANY"] / wc, "issue_stall_frac": pmc["SQ_WAIT_INST_ANY"] / wc,
-                     "active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc, "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / wc,
-                     "waves_per_launch": pmc.get("SQ_WAVES")})
+        roof.update({"wait_frac": pmc["SQ_WAIT_ANY"] / wc, "valu_busy": pmc["SQ_ACTIVE_INST_VALU"] / wc, "waves_per_launch": pmc.get("SQ_WAVES")})
+        if "SQ_WAIT_INST_ANY" in pmc:
+            roof.update({"issue_stall_frac": pmc["SQ_WAIT_INST_ANY"] / wc, "active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc})
         if "SQ_INSTS_VALU" in pmc:
             roof["valu_instructions_per_keypoint"] = pmc["SQ_INSTS_VALU"] / n_kp
+    if pmc.get("TCC_HIT_sum", 0) + pmc.get("TCC_MISS_sum", 0) > 0:
+        roof["tcc_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
     return roof
 
 
@@ -482,7 +504,12 @@ def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_wa
         req = R.requested()
     pmc, pmc_src = ({}, "not collected for this workload (the headline workload's passes: profiles/)")
     if pmc_live:
-        pmc, pmc_src = collect_pmc(args)
+        if W["name"] == args.workload:
+            pmc, pmc_src = collect_pmc(args)
+        else:                                              # a sub-workload: the HBM and wait counters only (three short inner runs)
+            pmc, pmc_src = collect_pmc(args, workload=W["name"], steps=10,
+                                       groups=[["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+                                               ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"]])
     traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None
     roof = roofline_object(W, n_kp, timing, req, traffic, pmc, pmc_src, alg_all, sweep, args.variant)
     prof_step = prof_dt / steps * 1e3                      # ms per step of the pass that carried the event pairs (this rank)
@@ -628,6 +655,8 @@ def main():
     ap.add_argument("--order", default="auto", choices=["auto", "on", "off"],
                     help="home-voxel ordering of the GN kernels' work (ctgn_set_ordering); auto = the library's cost model")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic, wait fractions)")
+    ap.add_argument("--sub-pmc", default="D", help="comma-separated sub-workloads whose HBM / wait counters are collected too (three short "
+                                                    "rocprofv3 passes each; default D — the configuration whose map exceeds the caches; 'C,D' for both)")
     ap.add_argument("--no-extras", action="store_true", help="skip frames/s, robust route, frame stages")
     ap.add_argument("--detail-stdout", action="store_true", help="also print the full detail object as an EARLIER stdout line (default: files only)")
     ap.add_argument("--config-e-scale", type=int, default=100,
@@ -766,7 +795,7 @@ def main():
             small = name in ("B1", "C")
             sub_steps = {"B1": 200, "C": 200, "D": 20}.get(name, 50)
             sres, som = measure_workload(Ws, args, cia, torch, None, False, sub_steps, 10 if small else 5, 100 if small else 10, want_steady=True,
-                                         cpu_seconds=8.0, register_extras=small)
+                                         cpu_seconds=8.0, register_extras=small, pmc_live=(name in args.sub_pmc.split(",") and not args.no_pmc))
             sres["config"] = NAMES[name]
             if name == "D":
                 sres["config_detail"] = {"rays": int(Ws["inp"]["rays"]), "returns": int(Ws["inp"]["returns"])}

@@ -213,6 +213,9 @@ __device__ __forceinline__ bool sweep_in_short_range(int k, int nb) {
 //   NORMALS_FAST    the fast solver only (rounds 1-3).
 // GnParams::normals selects the mode (ctgn_set_normals, ct_icp_amd/csrc/ctgn_internal.h); bits 16-17 of the ablation mask override it (A/B).
 constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
+#ifndef CTGN_SHARED2_DEFAULT_OFF
+#define CTGN_SHARED2_DEFAULT_OFF 0   // 0: the 125-voxel sweep probes a round's shared home voxel once per wave (rows_tiles, shared2); bit 22 of the ablation mask flips it
+#endif
 #ifndef CTGN_CULL1_DEFAULT
 #define CTGN_CULL1_DEFAULT 0         // 1: the first search of a 27-voxel sweep culls its second probe batch's voxels (rows_tiles, cull1); bit 18 of the ablation mask flips it
 #endif
@@ -539,14 +542,15 @@ __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
 // bound on the k-th neighbour's distance carried over from the previous search (exact: no point of such a voxel can be
 // among the k nearest within the radius, map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
 template <int NB>
-__device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
-                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound, uint32_t mreach) {
+__device__ __forceinline__ bool batch_reach(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
+                                            double qx, double qy, double qz, int &v_out, int &vx, int &vy, int &vz, int ablate, double r2bound,
+                                            uint32_t mreach) {
     constexpr int S = 2 * NB + 1;
     const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
     v_out = v;
     const int vv = (v == 255) ? 0 : v;
     const int ox = vv / (S * S) - NB, oy = (vv / S) % S - NB, oz = vv % S - NB;
-    const int vx = kx + ox, vy = ky + oy, vz = kz + oz;
+    vx = kx + ox; vy = ky + oy; vz = kz + oz;
     // per-axis slab test first (the keypoint's reach mask, phase A: three bit tests): a voxel outside the box of reachable slabs is
     // outside the sphere; only the others pay for the exact test. With a carried-over bound most of a 125-voxel sweep stops here.
     bool reachable = searching && v != 255 &&
@@ -555,6 +559,13 @@ __device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, 
         const double gx = axis_gap(qx, vx, m.resolution), gy = axis_gap(qy, vy, m.resolution), gz = axis_gap(qz, vz, m.resolution);
         reachable = gx * gx + gy * gy + gz * gz <= r2bound * (1.0 + 1e-8) + 1e-12;
     }
+    return reachable;
+}
+template <int NB>
+__device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
+                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound, uint32_t mreach) {
+    int vx, vy, vz;
+    const bool reachable = batch_reach<NB>(m, it, sub, searching, kx, ky, kz, qx, qy, qz, v_out, vx, vy, vz, ablate, r2bound, mreach);
     return probe_issue(m, reachable && !(ablate & 16), vx, vy, vz);
 }
 
@@ -608,6 +619,7 @@ struct WaveScratch {
     uint16_t mr[64];                   // per axis, which voxel offsets -2 .. +2 of its home voxel reach inside that bound (bit 5 a + o + 2)
     uint8_t todo[64];                  // 1: the keypoint needs a search this iteration (no pool, or its pool could not be certified)
     uint8_t slot[64];                  // round r, row j of the search phase works on the keypoint of lane slot[4 r + j] (255: nothing)
+    uint32_t socc[OCC >= 128 ? 128 : 4];   // 125-voxel sweep: block*128 + count of every sweep voxel of the round's SHARED home voxel, probed once per wave
     union {
         struct {
             RowList list[4];
@@ -1255,7 +1267,45 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             st_kx = INT_MIN;                      // the shared stage aliases the per-row probe scratch
             const double r2bound = kth_d2;        // the probes are culled against the bound the round starts with (27-voxel sweep: both batches)
             const uint32_t mreach = W.mr[src];
-            if (nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
+            // 125-voxel sweep, the (active) keypoints of the round in ONE home voxel — the rule on an upload sorted by home voxel (config D):
+            // the 125 hash probes are issued once for the wave, two per lane, all in flight together, instead of eight dependent batches of
+            // 16 per row (into a table far larger than the caches a first search spends 44 % of its wave time there); the rows then take
+            // their sweep voxels from the wave's table, each with its own reach test against its own current bound, as before.
+            bool shared2 = false;
+            if (NB == 2 && (((ablate >> 22) & 1) != CTGN_SHARED2_DEFAULT_OFF)) {
+                int hx = INT_MIN, hy = 0, hz = 0;
+                bool same = true;
+#pragma unroll
+                for (int l = 0; l < 64; l += 16) {
+                    const int x = __builtin_amdgcn_readlane(kx, l), y = __builtin_amdgcn_readlane(ky, l), z = __builtin_amdgcn_readlane(kz, l);
+                    if (x != INT_MIN) {
+                        if (hx == INT_MIN) { hx = x; hy = y; hz = z; }
+                        else same = same && x == hx && y == hy && z == hz;
+                    }
+                }
+                shared2 = same && hx != INT_MIN;
+                if (shared2) {
+                    // which sweep voxels some row can reach (slab masks only: a superset of the rows' exact tests)
+                    const uint32_t m0 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 0);
+                    const uint32_t m1 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 16);
+                    const uint32_t m2 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 32);
+                    const uint32_t m3 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 48);
+                    auto wanted = [&](int v) {
+                        const int ox = v / (S * S), oy = (v / S) % S, oz = v % S;            // offsets + NB: bit positions 0 .. 4
+                        auto t = [&](uint32_t mr) { return ((mr >> ox) & (mr >> (5 + oy)) & (mr >> (10 + oz)) & 1u) != 0u; };
+                        return v < V && (t(m0) || t(m1) || t(m2) || t(m3));
+                    };
+                    const int v0 = lane, v1 = lane + 64;
+                    const bool w0 = wanted(v0) && !(ablate & 16), w1 = wanted(v1) && !(ablate & 16);
+                    Probe p0 = probe_issue(map, w0, hx + v0 / (S * S) - NB, hy + (v0 / S) % S - NB, hz + v0 % S - NB);
+                    Probe p1 = probe_issue(map, w1, hx + (v1 % V) / (S * S) - NB, hy + ((v1 % V) / S) % S - NB, hz + (v1 % V) % S - NB);
+                    if (PROF) pc[10] += (unsigned long long) (__popcll(ballot64(w0)) + __popcll(ballot64(w1)));
+                    const uint32_t b0 = probe_resolve(map, p0), b1 = probe_resolve(map, p1);
+                    W.socc[v0] = b0;
+                    W.socc[v1] = b1;
+                }
+            }
+            if (!shared2 && nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
@@ -1267,7 +1317,15 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
                 // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
                 Probe cur = nxt;
-                const int cur_v = nxt_v;
+                int cur_v = nxt_v;
+                uint32_t bc_shared = 0u;
+                if (shared2) {
+                    // the row's own reach test for its lane's voxel of this batch (slab mask, then the exact box-to-sphere test against
+                    // the row's CURRENT bound), the voxel's slot from the wave's table
+                    int vx_, vy_, vz_;
+                    cur.active = batch_reach<NB>(map, it, sub, searching, kx, ky, kz, qx, qy, qz, cur_v, vx_, vy_, vz_, ablate, fmin(r2bound, kth_d2), mreach);
+                    bc_shared = cur.active ? W.socc[cur_v == 255 ? 0 : cur_v] : 0u;
+                } else
                 if (it + 1 < VIT) {
                     // (against the row's CURRENT bound: on the 125-voxel sweep a first search knows its k-th best after the first batch or
                     // two, and the remaining batches then probe only the voxels that bound can still reach instead of every voxel
@@ -1281,10 +1339,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                                           fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
-                if (PROF) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
+                if (PROF && !shared2) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
                 // a batch none of whose voxels any row can reach (most batches of a bounded 125-voxel sweep): nothing to resolve or stream
                 if (any64(cur.active)) {
-                const uint32_t bc = probe_resolve(map, cur);
+                const uint32_t bc = shared2 ? bc_shared : probe_resolve(map, cur);
                 if (bc) RP.occ[cur_v] = bc;
                 // Once the row holds k candidates and knows its k-th best distance, a voxel that lies entirely farther away cannot
                 // contribute (its points would fail `d2 <= kth_d2` one by one): skip its chunks. The sweep goes nearest voxels

@@ -1,5 +1,5 @@
 """Worker of test_config_e_two_gloo_ranks_share_one_gpu: one rank of a 2-rank gloo job running its share of a tiny config E
-(11 sequences, seeds 10-20, KITTI lengths / 400, coarse HDL-64E pattern) through ct_icp_amd.sequence_runner.run_batch on the one GPU."""
+(11 sequences, seeds 10-20, KITTI lengths / 400, a 1000-column HDL-64E pattern) through ct_icp_amd.sequence_runner.run_batch on the one GPU."""
 import importlib.util
 import json
 import os
@@ -20,7 +20,7 @@ def main():
     spec.loader.exec_module(mod)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    seqs, lengths = mod.config_e_sequences(scale=400, azimuth_steps=500)
+    seqs, lengths = mod.config_e_sequences(scale=400, azimuth_steps=1000)
     _, shares = sr.deal_sequences(lengths, world)
     makers = {sid: maker for sid, _, maker in seqs}
     mine, gts = {}, {}

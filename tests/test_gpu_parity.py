@@ -512,6 +512,48 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
             dist.destroy_process_group()
 
 
+def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
+    """Round 4: on the 125-voxel sweep a round whose (active) keypoints live in one home voxel probes its 125 voxels once per wave
+    (rows_tiles, shared2) instead of eight dependent batches per row. Dense keypoints (every return of the scan) worked through in
+    home-voxel order make that the rule; with pools on and off, four iterations: counts, farthest neighbours, gates and packed system
+    are the ones of the per-row probes (bit 22 of the ablation mask switches the shared stage off) after every iteration, and the first
+    accumulation's neighbour sets are the oracle's."""
+    case = nclt_case
+    om, gm = build_maps(case, 8, with_gpu=True)
+    sc = case["scans"][8]
+    raw, t = sc.raw[:12000], sc.t[:12000]
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.01, 0.05, seed=9)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, t, raw)
+    o = _opts(num_iters_icp=4, min_number_neighbors=10, threshold_orientation_norm=0.0)
+    for pools in (0, 1):
+        runs = []
+        for mask in (0, 1 << 22):
+            s = cia.GnSolver(gm)
+            s.set_ordering(1)
+            s.set_pools(pools)
+            s.set_ablation(mask)
+            s.set_debug(True)
+            s.set_keypoints(raw, world0, t)
+            s.gn_begin(pose0, sc.t_begin_end, o, None)
+            per_iter = []
+            for _ in range(o.num_iters_icp):
+                s.gn_iterate(1)
+                d = s.get_debug()
+                per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["farthest"].copy(), d["used"].copy(), d["a2d"].copy()))
+            pose, summ, _ = s.gn_end()
+            runs.append((pose, per_iter))
+        assert np.array_equal(runs[0][0], runs[1][0])
+        for k_it, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
+            assert np.array_equal(a[0][0], b[0][0]) and a[0][2] == b[0][2], k_it
+            for x, y in zip(a[1:], b[1:]):
+                assert np.array_equal(x, y), k_it
+    _, _, _, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
+    first = runs[0][1][0]
+    assert np.array_equal(first[1], info["n_neighbors"])
+    has = info["n_neighbors"] >= 10
+    assert has.sum() > 2000 and np.array_equal(first[2][has], info["farthest"][has]) and np.array_equal(first[3], info["used"])
+
+
 def test_config_c_nclt_profile_matches_oracle(nclt_case):
     case = nclt_case
     om, gm = build_maps(case, 8, with_gpu=True)
