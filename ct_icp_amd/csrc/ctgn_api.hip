@@ -638,6 +638,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     // members, which the fused kernel overlaps with the search rounds of the waves that are done checking; config D, whose 14 k waves queue
     // anyway, gains 2.6 % per step)
     constexpr int SPLIT_MIN_KEYPOINTS = 400000;
+    constexpr int FUSE_SMALL_MAX = 4096;
     static const int env_split = [] { const char *e = std::getenv("CTGN_SPLIT"); return e ? std::atoi(e) : -1; }();               // measurement hook
     const bool split = rows_ok && h->variant == 0 && kv.kth_valid && kv.pools && h->searches_in_solve >= 3 && kv.order == nullptr &&
                        h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : (h->n_kp >= SPLIT_MIN_KEYPOINTS && !(h->ablate & (1 << 19))));
@@ -668,7 +669,29 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             // second half: lane per keypoint (neighbour sets -> normal, residual, Jacobian, packed block sums)
             grid = launch_residual(h, mv, kv, dv);
         };
-        if (split) {
+        // small frames: search + residual part in ONE launch (k_search_residual) — opt-in (CTGN_FUSE_SMALL=1), measured and not adopted:
+        // B1 (1 024 keypoints, 27-voxel sweep) 0.0327 -> 0.0343 ms per iteration, C (1 500 keypoints, 125-voxel sweep) 0.0385 -> 0.0366 ms;
+        // its packed sums run per wave and search block, a different (fixed) order than the residual kernel's, so switching it by size
+        // would make poses depend on the path in the last bit. Not under per-launch profiling: the event pair brackets the SEARCH kernel.
+        static const int env_fuse = [] { const char *e = std::getenv("CTGN_FUSE_SMALL"); return e ? std::atoi(e) : -1; }();
+        const bool fuse_small = !search_only && h->variant == 0 && h->n_kp <= FUSE_SMALL_MAX && !kv.pools && kv.order == nullptr && !h->profiling &&
+                                (h->ablate & 0xffff) == 0 && env_fuse == 1;
+        if (fuse_small) {
+            auto go = [&](auto kernel, size_t smem) {
+                static int rb_cached[2] = {0, 0};
+                int &rb = rb_cached[mv.nb == 1 ? 0 : 1];
+                if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
+                const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
+                const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
+                grid = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0, rounds);
+            };
+            if (mv.nb == 1) go(k_search_residual<1>, search_residual_smem<1>());
+            else go(k_search_residual<2>, search_residual_smem<2>());
+            h->kth_fresh = true;
+            if (ev) (void) hipEventRecord(ev->stop, h->stream);
+            ev = nullptr;
+        } else if (split) {
             static int rb_check = 0;
             if (rb_check == 0) rb_check = std::min(resident_blocks(h, k_pool_check<true, CHECK_WPS>, ROW_BLOCK, sizeof(CheckScratch) * ROW_WAVES), 4 * MAX_PARTIAL_BLOCKS);
             const int rounds_c = pick_rounds(h->n_kp, rb_check * ROW_WAVES);

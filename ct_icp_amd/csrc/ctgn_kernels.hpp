@@ -1884,6 +1884,48 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
 }
 
 // ================================================================================================
+// k_search_residual — small frames (round 4): the search of a tile and, in the same wave right behind it, the residual part for the same
+// keypoints (rows_tiles' after_tile hook, as in k_gn_persistent, without that kernel's in-kernel barrier and solve): an iteration is two
+// launches instead of three, and a keypoint's neighbour record never leaves the CU that wrote it. For frames the three-launch loop
+// spreads thinly anyway (a few waves per CU: nothing for a separate, fuller residual kernel to gain); 255 registers, two waves per SIMD.
+// Same per-keypoint arithmetic; the packed sums are taken per wave, per block, blocks in index order (a fixed order of its own).
+// ================================================================================================
+struct SearchResidualShared {
+    double comb[ROW_WAVES][SYS_N];
+    TieScratch tie[ROW_WAVES];
+};
+template <int NB>
+inline size_t search_residual_smem() { return rows_kernel_smem<NB>() + sizeof(SearchResidualShared); }
+
+template <int NB>
+__global__ __launch_bounds__(ROW_BLOCK, 2) void k_search_residual(MapView map, KpView kp, const GnState *st, GnParams prm, double *partials,
+                                                                  DebugView dbg, int first_iter, int rounds) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SearchResidualShared &P = *reinterpret_cast<SearchResidualShared *>(smem + rows_kernel_smem<NB>());
+    constexpr int OCC = ((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3;
+    WaveScratch<OCC> &W = reinterpret_cast<WaveScratch<OCC> *>(smem)[wave];
+    const int ntiles = (kp.n + 4 * rounds - 1) / (4 * rounds);
+    d4_t accm = {0.0, 0.0, 0.0, 0.0};
+    int n_used_wave = 0;
+    rows_tiles<NB, true, false, false, false>(map, kp, st, prm, dbg, first_iter, rounds, nullptr, 0, smem, blockIdx.x * ROW_WAVES + wave, ntiles,
+                                       gridDim.x * ROW_WAVES, [&](int) {
+        const int id = W.id[lane];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2
+        residual_tile(map, kp, st, prm, dbg, 0, id < 0 ? kp.n : id, lane, W.rec, accm, n_used_wave, P.tie[wave]);
+    });
+    unpack_wave_sums(lane, accm, n_used_wave, P.comb[wave]);
+    __syncthreads();
+    for (int e = tid; e < SYS_N; e += ROW_BLOCK) {
+        double sum = 0.0;
+        for (int w = 0; w < ROW_WAVES; ++w) sum += P.comb[w][e];
+        partials[(size_t) blockIdx.x * SYS_N + e] = sum;
+    }
+}
+
+// ================================================================================================
 // k_reduce_solve — partials -> packed system -> (normalise, motion prior, LDL^T, pose update, stop test)
 //   mode 0: reduce + solve   1: reduce only (multi-GPU: the all-reduce sits in between)   2: solve only
 // One block of 1024 threads. Reduction: wave w sums entries w, w+16, ... over the blocks with a fixed

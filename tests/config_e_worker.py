@@ -31,8 +31,8 @@ def main():
     # this rank's sequences back to back (what run_batch does for a rank; every sequence bootstraps from its own ground-truth poses)
     results = []
     for sid in shares[rank]:
-        r = sr.run_sequence(mine[sid], device=0, solver=cia.GN, init_poses=gts[sid], init_frames=min(3, len(mine[sid])), max_distance=100.0)
-        err = max([se3.pose_error(r["poses"][j], gts[sid][j])[0] for j in range(min(3, len(mine[sid])), len(mine[sid]))] or [0.0])
+        r = sr.run_sequence(mine[sid], device=0, solver=cia.GN, init_poses=gts[sid], init_frames=min(5, len(mine[sid])), max_distance=100.0)
+        err = max([se3.pose_error(r["poses"][j], gts[sid][j])[0] for j in range(min(5, len(mine[sid])), len(mine[sid]))] or [0.0])
         results.append(dict(sequence=sid, frames=int(r["frames"]), failures=int(np.count_nonzero(~r["success"])), err=float(err), seconds=float(r["seconds"])))
     gathered = [None] * world
     dist.all_gather_object(gathered, results)
