@@ -171,6 +171,7 @@ SYMBOLS = {
     "ctgn_set_variant": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_ablation": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_normals": (C.c_int, [_H, C.c_int32]),
+    "ctgn_set_search_guess": (C.c_int, [_H, C.c_double]),
     "ctgn_set_ordering": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_persistent": (C.c_int, [_H, C.c_int32]),
     "ctgn_set_pools": (C.c_int, [_H, C.c_int32]),

@@ -138,6 +138,7 @@ struct ctgn_context {
     bool kth_fresh = false;             // the k-th distances on the device were written by the previous search of this solve
     int searches_in_solve = 0;          // neighbour searches launched since the solve began (the first one has no carried-over bound)
     int last_grid = 0;
+    double guess_factor = -1.0;         // ctgn_set_search_guess: < 0 automatic, 0 off, > 0 forced factor on r_k (launch_accumulate)
     int normals_mode = 0;               // ctgn_set_normals: 0 library default (hybrid), 1 exact, 2 hybrid, 3 fast
     int fail_slot = 0;                  // which of the two fail-list counters the next split launch counts in (the other one is zeroed by it)
     bool gn_active = false;
@@ -528,6 +529,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.fail_count = v.fail_count_next = nullptr;       // set per split launch
     v.n_dev = nullptr;
     v.resume = 0;
+    v.guess2 = 0.f;                     // set per launch (launch_accumulate: first searches over a dense level)
     return v;
 }
 
@@ -632,6 +634,27 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     }
     int grid;
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
+    // A search without a carried-over bound (the first of a solve) over a level that is DENSE for its radius starts from a guess: with
+    // ppv points per voxel on a surface, k neighbours fill a disc of radius r_k = res sqrt(k / (pi ppv)); when 1.2 r_k is well inside
+    // the radius the search admits and streams what lies within that instead of everything within the radius (config D: ~45 candidates
+    // instead of ~175, an eighth of the sweep's volume), and the few keypoints the guess fails — fewer than k candidates inside it — are
+    // searched again on the radius in the same launch (rows_tiles, pass 1). Exact either way. Bit 24 of the ablation mask: off.
+    // (config D, step ms by factor: off 0.844 | 0.9: 0.936 | 1.05: 0.806 | 1.15: 0.766 | 1.3: 0.777 | 1.6: 0.796 | 2.0: 0.828)
+    if (rows_ok && !kv.kth_valid && !(h->ablate & (1 << 24)) && h->variant != 1) {
+        static const double env_factor = [] { const char *e = std::getenv("CTGN_GUESS_FACTOR"); return e ? std::atof(e) : 1.2; }();  // measurement hook
+        const bool forced = h->guess_factor > 0.0;            // ctgn_set_search_guess: a test forces guesses that mostly fail
+        const double factor = h->guess_factor >= 0.0 ? h->guess_factor : env_factor;
+        int map_id, nb_;
+        double res_;
+        search_params(h->levels, h->opts.default_radius, &map_id, &res_, &nb_);
+        const double npts = h->update_mode == 1 ? (double) h->devlevels[map_id].host.num_points : (double) h->levels[map_id].num_points;
+        const double nvox = h->update_mode == 1 ? (double) h->devlevels[map_id].host.num_voxels : (double) h->levels[map_id].num_voxels;
+        if (factor > 0.0 && nvox > 0.0 && npts > 0.0) {
+            const double ppv = npts / nvox;
+            const double g = factor * mv.resolution * std::sqrt((double) h->prm.max_nb / (3.14159265358979323846 * ppv));
+            if (g * g < (forced ? 1.0 : 0.5) * mv.r2thr) kv.guess2 = (float) (g * g * (1.0 + 1e-6));
+        }
+    }
     // From the third search of a solve on (nearly) every keypoint has a pool: the pool check runs as a kernel of its own and the search
     // kernel only over the list of positions it could not certify (k_pool_check). Bit 19 of the ablation mask switches the split off (A/B).
     // (measured: the 132 k-keypoint sweep loses 25 us per launch to the split — its pool check is bound by the scattered gathers of the pool
@@ -2750,6 +2773,12 @@ ctgn_status ctgn_set_persistent(ctgn_handle h, int32_t mode) {
 ctgn_status ctgn_set_pools(ctgn_handle h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return CTGN_ERR_INVALID_ARGUMENT;
     h->pool_mode = mode;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_search_guess(ctgn_handle h, double factor) {
+    if (!h) return CTGN_ERR_INVALID_ARGUMENT;
+    h->guess_factor = factor;
     return CTGN_OK;
 }
 

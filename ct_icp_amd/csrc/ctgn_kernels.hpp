@@ -70,6 +70,8 @@ struct KpView {
     int *fail_count;         // ... and counts them here (zero when the kernel starts); fail_count_next is zeroed for the next launch
     int *fail_count_next;
     const int *n_dev;        // k_accumulate_rows: the number of positions to work on lives on the device (min(*n_dev, n)); nullptr = n
+    float guess2;            // > 0: a search that has no carried-over bound (the first of a solve) starts from this squared distance instead of the
+                             // radius; a keypoint it leaves with fewer than k candidates is searched again on the radius (rows_tiles, pass 1)
     int resume;              // k_accumulate_rows: 1 = the positions come from `order` (= a fail list), their world points are current (the
                              // check kernel wrote them) and kth[1] is the bound to search within: no transform, nothing moved
 };
@@ -619,6 +621,7 @@ struct WaveScratch {
     uint16_t mr[64];                   // per axis, which voxel offsets -2 .. +2 of its home voxel reach inside that bound (bit 5 a + o + 2)
     uint8_t todo[64];                  // 1: the keypoint needs a search this iteration (no pool, or its pool could not be certified)
     uint8_t slot[64];                  // round r, row j of the search phase works on the keypoint of lane slot[4 r + j] (255: nothing)
+    uint8_t gs[64];                    // 1: its bound (kb) is a GUESS, not a proven upper bound of its k-th neighbour's distance (KpView::guess2)
     uint32_t socc[OCC >= 128 ? 128 : 4];   // 125-voxel sweep: block*128 + count of every sweep voxel of the round's SHARED home voxel, probed once per wave
     union {
         struct {
@@ -930,6 +933,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         Vec3 p{0, 0, 0};
         int kxv = INT_MIN, kyv = 0, kzv = 0;
         float kbv = __int_as_float(0x7f800000), rr2v = 0.f;
+        bool guessv = false;
+        if (own && kp.guess2 > 0.f && !(kp.kth_valid && !first_iter) && !(ablate & 256)) { kbv = kp.guess2; guessv = true; }
         if (own) {
             const Vec3 raw{kp.rx[my_kp], kp.ry[my_kp], kp.rz[my_kp]};
             const double alpha = alpha_timestamp(kp.t[my_kp], st->tbe[0], st->tbe[1]);
@@ -976,6 +981,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         W.kb[lane] = kbv;
         W.rr2[lane] = rr2v;
         W.todo[lane] = own ? 1 : 0;
+        W.gs[lane] = guessv ? 1 : 0;
         }
         CTGN_TICK(0)
         // ---------------- phase V: pools. The previous bounded search (or pool check) of this solve left the keypoint a POOL — its nearest
@@ -1057,6 +1063,17 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             CTGN_TICK(6)
         }
 
+        // Two passes at most: pass 0 = the tile's rounds; pass 1 (only after a guessed bound, KpView::guess2) = the keypoints whose guess admitted
+        // fewer than k candidates — or whose k-th lies within rounding of the guess —, compacted into rounds and searched on the radius.
+#pragma nounroll
+        for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            const bool again = W.todo[lane] == 2;
+            if (!any64(again)) break;
+            W.todo[lane] = again ? 1 : 0;
+            if (again) { W.kb[lane] = __int_as_float(0x7f800000); W.gs[lane] = 0; }
+            compact = true;
+        }
         // ---------------- phase A2: the keypoints that are searched
         {
         const bool searched = W.todo[lane] != 0;
@@ -1131,7 +1148,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             // A search that starts with a bound (carried over from the previous one) keeps a pool: its bound exceeds the new k-th distance by
             // about the distance the keypoint has moved, so nearly everything it admits comes for free. A search bounded by the radius only
             // would have to carry the spare members through every cut of its long stream: it keeps the k neighbours and leaves no pool.
-            const int kpool = (double) W.kb[src] < map.r2thr ? pool_cap : k;
+            const bool guessed = W.gs[src] != 0;         // (a guessed search keeps no pool: like the radius-only search it stands in for)
+            const int kpool = (!guessed && (double) W.kb[src] < map.r2thr) ? pool_cap : k;
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
@@ -1448,13 +1466,20 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             if (!(ablate & 2) && any64(row_needed)) Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
             const int m = min(Ln, kpool);          // pool: what the record keeps, sorted nearest first
             const int n = min(Ln, k);              // the neighbours (every list entry lies within the radius, map.h:491-493)
+            // a guessed bound proves its result only if it admitted k candidates with the k-th clear of the guess: anything else is
+            // searched again on the radius (pass 1) and hands nothing over now
+            bool retry = false;
+            if (guessed && searching) {
+                retry = admitted < k || !(R.d2[k - 1] * (1.0 + 0x1p-48) < (double) W.kb[src]);
+                if (retry && sub == 0) W.todo[src] = 2;
+            }
             CTGN_TICK(4)
             // B4: hand the keypoint's neighbour set over: the block-storage byte offsets of the n kept points, nearest first
             // (the reference's neighbour vector is the same set farthest first: its readers walk the record backwards), in a
             // per-keypoint record; behind them the rest of the pool (phase V of the next iteration). The covariance sums are then
             // taken by the residual kernel — no cross-lane reductions and no point loads here.
             {
-                const int kp_r = idle ? -1 : W.id[src];
+                const int kp_r = (idle || retry) ? -1 : W.id[src];
                 if (kp_r >= 0 && !(ablate & 4)) {
                     uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
                     const bool sorted = row_needed && !(ablate & 2);
@@ -1489,6 +1514,8 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 }
             }
             CTGN_TICK(5)
+        }
+        if (!(kp.guess2 > 0.f)) break;                // no guesses: nothing to search again
         }
         after_tile(tile);
     }

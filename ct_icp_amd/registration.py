@@ -515,6 +515,10 @@ class GnSolver:
         out = out[:n.value]
         return out[out[:, 1] > 0]
 
+    def set_search_guess(self, factor: float):
+        """< 0 automatic, 0 off, > 0 forced factor of the first search's guessed bound: ct_icp_amd/csrc/ctgn_internal.h."""
+        L.check(self._h, L.lib().ctgn_set_search_guess(self._h, float(factor)))
+
     def set_normals(self, mode: int):
         """0 library default (hybrid), 1 exact (bit-identical normals, slower), 2 hybrid, 3 fast: ct_icp_amd/csrc/ctgn_internal.h."""
         L.check(self._h, L.lib().ctgn_set_normals(self._h, mode))

@@ -1457,6 +1457,58 @@ def test_k32_neighbours_and_64_point_voxels(box_case, mode):
         assert np.array_equal(gq, om.radius_search(q, 0.0, 32, heap_mode=0))
 
 
+def test_guessed_first_search_bound_changes_nothing_but_the_work(box_case):
+    """Round 4: over a level that is dense for its radius the first search of a solve starts from a guess (1.3 x the radius k neighbours
+    fill on a surface at the level's points-per-voxel) instead of the radius, and the keypoints the guess leaves with fewer than k
+    candidates are searched again on the radius in the same launch (rows_tiles, pass 1). Forced here (ctgn_set_search_guess) with three
+    factors — from "most guesses hold" to "most fail and take the second pass": the instrumented instantiation confirms the guess is
+    in use, and counts, farthest neighbours, gates, system and poses are identical to the unguessed search's for
+    every factor, with pools on and off, after every iteration — and the oracle's on the first accumulation."""
+    case = dict(box_case, resolutions=[(0.5, 0.02, 64)])
+    om, gm = build_maps(case, 6, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(case, 6, 0.25)
+    o = _opts(num_iters_icp=3, threshold_orientation_norm=0.0)
+    streamed = {}
+    for factor in (0.0, 1.3):
+        s = cia.GnSolver(gm)
+        s.set_variant(3)
+        s.set_search_guess(factor)
+        s.set_keypoints(raw, world0, t)
+        s.gn_begin(pose0, sc.t_begin_end, o, None)
+        s.traffic_counters(reset=True)
+        s.gn_iterate(1)
+        streamed[factor] = s.traffic_counters(reset=True)[1]
+        s.gn_end()
+    assert streamed[1.3] != streamed[0.0], streamed          # the guess is in use (how much it saves is the map's business: bench.py, workload D)
+    for pools in (0, 1):
+        runs = []
+        for factor in (0.0, 1.3, 0.7, 0.3):
+            s = cia.GnSolver(gm)
+            s.set_pools(pools)
+            s.set_search_guess(factor)
+            s.set_debug(True)
+            s.set_keypoints(raw, world0, t)
+            s.gn_begin(pose0, sc.t_begin_end, o, None)
+            per_iter = []
+            for _ in range(o.num_iters_icp):
+                s.gn_iterate(1)
+                d = s.get_debug()
+                per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["farthest"].copy(), d["used"].copy(), d["a2d"].copy()))
+            pose, summ, _ = s.gn_end()
+            runs.append((pose, per_iter))
+        for other in runs[1:]:
+            assert np.array_equal(runs[0][0], other[0])
+            for k_it, (a, b) in enumerate(zip(runs[0][1], other[1])):
+                assert np.array_equal(a[0][0], b[0][0]) and a[0][2] == b[0][2], k_it
+                for x, y in zip(a[1:], b[1:]):
+                    assert np.array_equal(x, y), k_it
+    _, _, _, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
+    first = runs[1][1][0]
+    assert np.array_equal(first[1], info["n_neighbors"])
+    has = info["n_neighbors"] >= 20
+    assert has.sum() > 1000 and np.array_equal(first[2][has], info["farthest"][has]) and np.array_equal(first[3], info["used"])
+
+
 def test_config_d_ouster_scan_matches_oracle():
     """BASELINE.json configs[3] as SURVEY.md section 8d defines it (sharded across GPUs in production; here the single-GPU kernel instantiation
     it uses): an Ouster-128-style scan — 128 beams x 2048 columns x 8 accumulated sub-sweeps = 2.1 M rays RAY-CAST against the residential
