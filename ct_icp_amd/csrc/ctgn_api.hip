@@ -635,13 +635,14 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     int grid;
     const bool rows_ok = (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64;
     // A search without a carried-over bound (the first of a solve) over a level that is DENSE for its radius starts from a guess: with
-    // ppv points per voxel on a surface, k neighbours fill a disc of radius r_k = res sqrt(k / (pi ppv)); when 1.2 r_k is well inside
+    // ppv points per voxel on a surface, k neighbours fill a disc of radius r_k = res sqrt(k / (pi ppv)); when 1.25 r_k is inside
     // the radius the search admits and streams what lies within that instead of everything within the radius (config D: ~45 candidates
     // instead of ~175, an eighth of the sweep's volume), and the few keypoints the guess fails — fewer than k candidates inside it — are
     // searched again on the radius in the same launch (rows_tiles, pass 1). Exact either way. Bit 24 of the ablation mask: off.
-    // (config D, step ms by factor: off 0.844 | 0.9: 0.936 | 1.05: 0.806 | 1.15: 0.766 | 1.3: 0.777 | 1.6: 0.796 | 2.0: 0.828)
+    // (config D, step ms by factor: off 0.844 | 0.9: 0.936 | 1.05: 0.806 | 1.15: 0.766 | 1.3: 0.777 | 1.6: 0.796 | 2.0: 0.828;
+    //  B2, first search ms: off 0.133 | 1.1: 0.127 | 1.2: 0.116 | 1.25: 0.112 | 1.4: 0.113)
     if (rows_ok && !kv.kth_valid && !(h->ablate & (1 << 24)) && h->variant != 1) {
-        static const double env_factor = [] { const char *e = std::getenv("CTGN_GUESS_FACTOR"); return e ? std::atof(e) : 1.2; }();  // measurement hook
+        static const double env_factor = [] { const char *e = std::getenv("CTGN_GUESS_FACTOR"); return e ? std::atof(e) : 1.25; }(); // measurement hook
         const bool forced = h->guess_factor > 0.0;            // ctgn_set_search_guess: a test forces guesses that mostly fail
         const double factor = h->guess_factor >= 0.0 ? h->guess_factor : env_factor;
         int map_id, nb_;
@@ -652,7 +653,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (factor > 0.0 && nvox > 0.0 && npts > 0.0) {
             const double ppv = npts / nvox;
             const double g = factor * mv.resolution * std::sqrt((double) h->prm.max_nb / (3.14159265358979323846 * ppv));
-            if (g * g < (forced ? 1.0 : 0.5) * mv.r2thr) kv.guess2 = (float) (g * g * (1.0 + 1e-6));
+            static const double env_frac = [] { const char *e = std::getenv("CTGN_GUESS_MAXFRAC"); return e ? std::atof(e) : 0.8; }();      // measurement hook
+            if (g * g < (forced ? 1.0 : env_frac) * mv.r2thr) kv.guess2 = (float) (g * g * (1.0 + 1e-6));
         }
     }
     // From the third search of a solve on (nearly) every keypoint has a pool: the pool check runs as a kernel of its own and the search

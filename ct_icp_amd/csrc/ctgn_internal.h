@@ -27,8 +27,8 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * solve. Bits 16-17 of the ablation mask override it; bit 18 toggles the first-search cull of the 27-voxel sweep's second probe batch,
  * bit 19 switches the split pool-check launches off (A/B hooks; these bits leave results valid). */
 ctgn_status ctgn_set_normals(ctgn_handle h, int32_t mode);
-/* The guessed bound of a first search (ctgn_api.hip, launch_accumulate; rows_tiles pass 1): factor < 0 = automatic (1.2 x the radius k
- * neighbours fill on a surface at the searched level's points per voxel, used only when that lies well inside the search radius), 0 = off,
+/* The guessed bound of a first search (ctgn_api.hip, launch_accumulate; rows_tiles pass 1): factor < 0 = automatic (1.25 x the radius k
+ * neighbours fill on a surface at the searched level's points per voxel, used only when its square is below 0.8 of the squared search radius), 0 = off,
  * > 0 = that factor, used whenever the guess is inside the radius (tests force small factors so that most guesses fail and the second
  * pass runs). Results do not depend on it. Bit 24 of the ablation mask also switches it off. */
 ctgn_status ctgn_set_search_guess(ctgn_handle h, double factor);
