@@ -218,6 +218,15 @@ constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
 #ifndef CTGN_SHARED2_DEFAULT_OFF
 #define CTGN_SHARED2_DEFAULT_OFF 0   // 0: the 125-voxel sweep probes a round's shared home voxel once per wave (rows_tiles, shared2); bit 22 of the ablation mask flips it
 #endif
+// Stream loop of the generic path: keep the next chunk's loads IN FRONT of the current chunk's test in the instruction stream. Left to
+// itself the scheduler starts the test (whose first instructions wait for the current chunk) before it has issued the next chunk's
+// loads, so only one chunk is ever in flight; with the fence the next chunk's loads are out before the wait.
+#ifndef CTGN_STREAM_DEPTH
+#define CTGN_STREAM_DEPTH 2          // register sets of the stream loop (3: measured)
+#endif
+#ifndef CTGN_STREAM_FENCE
+#define CTGN_STREAM_FENCE __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef CTGN_CULL1_DEFAULT
 #define CTGN_CULL1_DEFAULT 0         // 1: the first search of a 27-voxel sweep culls its second probe batch's voxels (rows_tiles, cull1); bit 18 of the ablation mask flips it
 #endif
@@ -1412,12 +1421,38 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     }
                     Ln += __popc(pm);
                 };
+#if CTGN_STREAM_DEPTH == 3
+                // three register sets: two chunks' loads are in flight while the third is tested (a list takes three chunks' admissions
+                // between two capacity checks: 48 entries)
+                Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false}, cc{0, 0, 0, 0, false};
+                fetch(0, ca);
+                fetch(1, cb);
+                for (int c = 0; !(ablate & 1) && any64(c < nchunk); c += 3) {
+                    fetch(c + 2, cc);
+                    CTGN_STREAM_FENCE
+                    test(ca);
+                    fetch(c + 3, ca);
+                    CTGN_STREAM_FENCE
+                    test(cb);
+                    fetch(c + 4, cb);
+                    CTGN_STREAM_FENCE
+                    test(cc);
+                    if (any64(Ln > LCAP - 48)) {
+                        CTGN_TICK(2)
+                        Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
+                        CTGN_TICK(3)
+                    }
+                }
+#else
                 Cand ca{0, 0, 0, 0, false}, cb{0, 0, 0, 0, false};
                 fetch(0, ca);
                 for (int c = 0; !(ablate & 1) && any64(c < nchunk); c += 2) {
                     fetch(c + 1, cb);
+                    CTGN_STREAM_FENCE
                     test(ca);
                     fetch(c + 2, ca);
+                    CTGN_STREAM_FENCE
                     test(cb);
                     if (any64(Ln > LCAP - 32)) {
                         // list nearly full somewhere in the wave: cut every row back to its k best
@@ -1427,6 +1462,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         CTGN_TICK(3)
                     }
                 }
+#endif
                 }
                 CTGN_TICK(2)
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
