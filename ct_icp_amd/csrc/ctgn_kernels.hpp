@@ -222,7 +222,9 @@ constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
 // itself the scheduler starts the test (whose first instructions wait for the current chunk) before it has issued the next chunk's
 // loads, so only one chunk is ever in flight; with the fence the next chunk's loads are out before the wait.
 #ifndef CTGN_STREAM_DEPTH
-#define CTGN_STREAM_DEPTH 2          // register sets of the stream loop (3: measured)
+#define CTGN_STREAM_DEPTH 2          // register sets of the stream loop. 3 (two chunks in flight) fits the registers without spills and
+                                     // was measured: B2 0.1250 -> 0.1273 ms per iteration (the bounded searches stream 2-4 chunks per
+                                     // batch: rounding those up to threes costs more than the deeper prefetch hides), D 0.7555 -> 0.7542
 #endif
 #ifndef CTGN_STREAM_FENCE
 #define CTGN_STREAM_FENCE __builtin_amdgcn_sched_barrier(0);
