@@ -658,7 +658,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         }
     }
     // From the third search of a solve on (nearly) every keypoint has a pool: the pool check runs as a kernel of its own and the search
-    // kernel only over the list of positions it could not certify (k_pool_check). Bit 19 of the ablation mask switches the split off (A/B).
+    // kernel only over the list of positions it could not certify (k_pool_check). Bit 19 of the ablation mask switches the split off (A/B),
+    // bit 25 forces it on below the size threshold (tests).
     // (measured: the 132 k-keypoint sweep loses 25 us per launch to the split — its pool check is bound by the scattered gathers of the pool
     // members, which the fused kernel overlaps with the search rounds of the waves that are done checking; config D, whose 14 k waves queue
     // anyway, gains 2.6 % per step)
@@ -666,7 +667,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     constexpr int FUSE_SMALL_MAX = 4096;
     static const int env_split = [] { const char *e = std::getenv("CTGN_SPLIT"); return e ? std::atoi(e) : -1; }();               // measurement hook
     const bool split = rows_ok && h->variant == 0 && kv.kth_valid && kv.pools && h->searches_in_solve >= 3 && kv.order == nullptr &&
-                       h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : (h->n_kp >= SPLIT_MIN_KEYPOINTS && !(h->ablate & (1 << 19))));
+                       h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : ((h->n_kp >= SPLIT_MIN_KEYPOINTS || (h->ablate & (1 << 25))) && !(h->ablate & (1 << 19))));
     if (search_only && (h->variant == 1 || !rows_ok))
         return fail(h, CTGN_ERR_UNSUPPORTED, "the robust route needs the row kernel: voxel_neighborhood 1 or 2, <= 64 points per voxel");
     if (h->variant == 1 || !rows_ok) {

@@ -329,9 +329,10 @@ def test_pools_give_the_same_neighbours_as_searching_every_iteration(box_case, n
                   _opts(num_iters_icp=8, min_number_neighbors=10, threshold_orientation_norm=0.0), _prior(nclt_case, 8)[0]))
     for gmap, sc, raw, t, pose0, world0, o, prior in cases:
         runs = []
-        # pools off | pools on (round 4: from the third search on the check is a kernel of its own, k_pool_check, and the search kernel runs
-        # over the list of positions it could not certify) | pools on with that split switched off (phase V inside the search kernel)
-        for pools, mask in ((0, 0), (1, 0), (1, 1 << 19)):
+        # pools off | pools on, phase V inside the search kernel | pools on with the split launches forced (round 4: from the third search on
+        # the check is a kernel of its own, k_pool_check, and the search kernel runs over the list of positions it could not certify;
+        # by default only from 400 k keypoints)
+        for pools, mask in ((0, 0), (1, 0), (1, 1 << 25)):
             s = cia.GnSolver(gmap)
             s.set_pools(pools)
             s.set_ablation(mask)
