@@ -2234,8 +2234,11 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
     const bool want_all = out && out->all_world_base && n;
     if (n1) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, d_recs, F.d_corr, (int) n1, (size_t) 1, d_pose,
                                tbe[0], tbe[1], F.d_sel1, c, (size_t) 4);
+    // every scan point: as x y z rows when that is what the caller's array holds (float64 rows of 24 bytes, no `order`): the copy then
+    // lands in the final layout and the hand-over is a straight memcpy; as three planes otherwise
+    const bool all_rows = want_all && !order && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
     if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1, d_pose,
-                                     tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4);
+                                     tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, all_rows ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     const bool fuse = fused_max_distance != nullptr && !robust && h->update_mode == 1;
     hipStream_t s_out = h->stream;
@@ -2247,7 +2250,7 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
         HIPCHK(h, hipStreamWaitEvent(h->stream_down, h->ev_frame, 0));
         s_out = h->stream_down;
     }
-    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, s_out));
+    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_world_base && n1)
         HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_indices && n1)
@@ -2306,7 +2309,9 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
             const bool o64 = out->all_world_dtype == CTGN_F64;
             h->pool.run((n + CHUNK - 1) / CHUNK, [&](size_t k) {           // the rows of the caller's array, a chunk per thread
                 const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
-                if (o64) {
+                if (all_rows) {
+                    std::memcpy(ob + j0 * os, F.h_out + 3 * j0, (j1 - j0) * 3 * sizeof(double));
+                } else if (o64) {
                     for (size_t j = j0; j < j1; ++j) {
                         double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
                         q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];

@@ -242,12 +242,14 @@ def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, in
                  only=None, per_frame: bool = False, use_motion_model=None):
     """One GPU, world size 1: the 11 sequences back to back, longest first, every frame ONE ctgn_frame call
     (ct_icp_amd.sequence_runner.run_sequence). Aggregate frames/s = all frames / the sum of the sequences' loop times (what a rank of
-    run_batch reports); scan generation is outside the timed loops."""
+    run_batch reports); scan generation is outside the timed loops. solver_name "GN", "CERES" or "GN,CERES" (both routes on the same
+    scans, each sequence ray-cast once): with two routes the result carries one block per route, the first one's at the top level."""
     from ct_icp_amd import sequence_runner as sr
     seqs, lengths = config_e_sequences(scale, azimuth_steps)
-    solver = cia.GN if solver_name == "GN" else cia.CERES
-    results, t_gen = [], 0.0
-    warm = True
+    routes = [r.strip() for r in solver_name.split(",")]
+    results = {r: [] for r in routes}
+    t_gen = 0.0
+    warm = {r: True for r in routes}
     for sid, frames, maker in seqs:
         if only is not None and sid not in only:
             continue
@@ -255,33 +257,44 @@ def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, in
         scans, knots = maker(sid)
         t_gen += time.perf_counter() - t0
         gt = [syn.frame_pose14(knots, j) for j in range(frames)]
-        kw = dict(device=device, solver=solver, voxel_size=0.5, sample_voxel_size=1.5, max_distance=100.0, init_poses=gt,
-                  init_frames=min(init_frames, frames), use_motion_model=use_motion_model)
-        if warm:                                        # first touches of the library (code objects, pinned staging): not a sequence's cost
-            sr.run_sequence(scans[:min(8, frames)], **kw)
-            warm = False
-        r = sr.run_sequence(scans, **kw)
-        errs = np.array([se3.pose_error(r["poses"][j], gt[j]) for j in range(kw["init_frames"], frames)] or [(0.0, 0.0)])
-        results.append(dict(sequence=sid, seed=10 + sid, frames=frames, seconds=r["seconds"], frames_per_sec=frames / r["seconds"],
-                            registered=frames - kw["init_frames"], failures=int(np.count_nonzero(~r["success"])),
-                            keypoints_mean=float(r["keypoints"][kw["init_frames"]:].mean()) if frames > kw["init_frames"] else 0.0,
-                            points_per_frame=float(np.mean([len(s[1]) for s in scans])),
-                            err_tr_max=float(errs[:, 0].max()), err_tr_mean=float(errs[:, 0].mean()), err_rot_max=float(errs[:, 1].max()),
-                            map_points=r["map_points"]))
-        if per_frame:
-            results[-1].update(err_tr=[float(e) for e in errs[:, 0]], success=[bool(v) for v in r["success"]],
-                               keypoints=[int(v) for v in r["keypoints"]], sampled=[int(v) for v in r["sampled"]])
-        if log:
-            log(f"config E: sequence {sid} ({frames} frames): {results[-1]['frames_per_sec']:.0f} frames/s, failures {results[-1]['failures']}, "
-                f"max |dt| {results[-1]['err_tr_max']:.3f} m")
+        for route in routes:
+            kw = dict(device=device, solver=cia.GN if route == "GN" else cia.CERES, voxel_size=0.5, sample_voxel_size=1.5, max_distance=100.0,
+                      init_poses=gt, init_frames=min(init_frames, frames), use_motion_model=use_motion_model)
+            if warm[route]:                                 # first touches of the library (code objects, pinned staging): not a sequence's cost
+                sr.run_sequence(scans[:min(8, frames)], **kw)
+                warm[route] = False
+            r = sr.run_sequence(scans, **kw)
+            errs = np.array([se3.pose_error(r["poses"][j], gt[j]) for j in range(kw["init_frames"], frames)] or [(0.0, 0.0)])
+            rec = dict(sequence=sid, seed=10 + sid, frames=frames, seconds=r["seconds"], frames_per_sec=frames / r["seconds"],
+                       registered=frames - kw["init_frames"], failures=int(np.count_nonzero(~r["success"])),
+                       keypoints_mean=float(r["keypoints"][kw["init_frames"]:].mean()) if frames > kw["init_frames"] else 0.0,
+                       points_per_frame=float(np.mean([len(s[1]) for s in scans])),
+                       err_tr_max=float(errs[:, 0].max()), err_tr_mean=float(errs[:, 0].mean()), err_rot_max=float(errs[:, 1].max()),
+                       map_points=r["map_points"])
+            if per_frame:
+                rec.update(err_tr=[float(e) for e in errs[:, 0]], success=[bool(v) for v in r["success"]],
+                           keypoints=[int(v) for v in r["keypoints"]], sampled=[int(v) for v in r["sampled"]])
+            results[route].append(rec)
+            if log:
+                log(f"config E [{route}]: sequence {sid} ({frames} frames): {rec['frames_per_sec']:.0f} frames/s, failures {rec['failures']}, "
+                    f"max |dt| {rec['err_tr_max']:.3f} m")
         del scans
-    frames = sum(r["frames"] for r in results)
-    seconds = sum(r["seconds"] for r in results)
-    return dict(metric="frames/s, whole per-frame loop (one ctgn_frame call per frame), config E on one GPU", frames_per_sec=frames / seconds,
-                frames=frames, sequences=len(results), wall_seconds=seconds, failures=sum(r["failures"] for r in results),
-                err_tr_max=max(r["err_tr_max"] for r in results), lengths=lengths, scale=f"KITTI lengths / {scale}", solver=solver_name,
-                bootstrap=f"the first {init_frames} frames of a sequence enter the map with their ground-truth poses",
-                scan_generation_seconds=t_gen, per_sequence=results)
+
+    def block(route):
+        rs = results[route]
+        frames = sum(r["frames"] for r in rs)
+        seconds = sum(r["seconds"] for r in rs)
+        return dict(metric="frames/s, whole per-frame loop (one ctgn_frame call per frame), config E on one GPU", frames_per_sec=frames / seconds,
+                    frames=frames, sequences=len(rs), wall_seconds=seconds, failures=sum(r["failures"] for r in rs),
+                    sequences_without_failure=sum(1 for r in rs if r["failures"] == 0),
+                    err_tr_max=max(r["err_tr_max"] for r in rs), lengths=lengths, scale=f"KITTI lengths / {scale}", solver=route,
+                    bootstrap=f"the first {init_frames} frames of a sequence enter the map with their ground-truth poses",
+                    per_sequence=rs)
+    out = block(routes[0])
+    out["scan_generation_seconds"] = t_gen
+    for route in routes[1:]:
+        out["route_" + route] = block(route)
+    return out
 
 
 def main():
@@ -295,7 +308,7 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--sequences", type=int, default=1)
     ap.add_argument("--azimuth-steps", type=int, default=1000, help="4500 = the full 0.08 deg HDL-64E sweep")
-    ap.add_argument("--solver", default="GN", choices=["GN", "CERES"])
+    ap.add_argument("--solver", default="GN", choices=["GN", "CERES", "GN,CERES"])
     ap.add_argument("--voxel-size", type=float, default=0.5)
     ap.add_argument("--sample-voxel-size", type=float, default=1.5)
     ap.add_argument("--sampling", default="GRID", choices=["GRID", "ADAPTIVE"],
