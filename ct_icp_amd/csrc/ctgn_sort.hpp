@@ -25,14 +25,14 @@ namespace ctgn {
 
 constexpr int SORT_SMALL_MAX = 16384;
 constexpr int SORT_SMALL_THREADS = 1024;
-constexpr int SORT_MAX_COLS = 512;             // per-wave tiles of the large path (columns of the histogram matrix): the tile grows with n
+constexpr int SORT_MAX_COLS = 1024;            // per-wave tiles of the large path (columns of the histogram matrix): the tile grows with n
 
 inline hipError_t sort_scratch_reserve(SortScratch &S, size_t n) {
     (void) n;
     if (S.hist && S.bits) return hipSuccess;     // fixed size: the tile grows with n so that the columns stay <= SORT_MAX_COLS
     hipError_t e = hipSuccess;
     if (!S.hist) e = hipMalloc(reinterpret_cast<void **>(&S.hist), (size_t) 256 * SORT_MAX_COLS * sizeof(uint32_t));
-    if (e == hipSuccess && !S.bits) e = hipMalloc(reinterpret_cast<void **>(&S.bits), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess && !S.bits) e = hipMalloc(reinterpret_cast<void **>(&S.bits), (2 + 128) * sizeof(unsigned long long));     // OR | AND | 256 digit totals
     if (e != hipSuccess) {                       // all or nothing: a half-reserved scratch must not look reserved to the next call
         if (S.hist) (void) hipFree(S.hist);
         if (S.bits) (void) hipFree(S.bits);
@@ -153,13 +153,20 @@ __global__ __launch_bounds__(SORT_SMALL_THREADS) void k_sort_small(K *keys, K *k
 // ------------------------------------------------------------------------------------------------ larger n: three kernels per pass
 template <typename K>
 __global__ __launch_bounds__(256) void k_sort_bits(const K *keys, size_t n, unsigned long long *bits) {
+    __shared__ unsigned long long s_or[4], s_and[4];
     unsigned long long vo = 0ull, va = ~0ull;
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
         const unsigned long long k = (unsigned long long) keys[i];
         vo |= k; va &= k;
     }
     for (int d = 32; d >= 1; d >>= 1) { vo |= __shfl_xor(vo, d); va &= __shfl_xor(va, d); }
-    if ((threadIdx.x & 63) == 0) { atomicOr(&bits[0], vo); atomicAnd(&bits[1], va); }
+    if ((threadIdx.x & 63) == 0) { s_or[threadIdx.x >> 6] = vo; s_and[threadIdx.x >> 6] = va; }
+    __syncthreads();
+    // one pair of atomics per BLOCK (round 3 issued one per wave from 1 024 blocks: 8 k atomics on two addresses, 96 us at 0.9 M keys)
+    if (threadIdx.x == 0) {
+        atomicOr(&bits[0], s_or[0] | s_or[1] | s_or[2] | s_or[3]);
+        atomicAnd(&bits[1], s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+    }
 }
 
 // wave (blockIdx * 4 + wave) owns elements [col * tile, (col + 1) * tile): its digit counts go to hist[digit][col]
@@ -185,42 +192,51 @@ __global__ __launch_bounds__(256) void k_sort_hist(const K *k0, const K *k1, siz
     }
 }
 
-// exclusive scan of hist[256 * cols] in place (digit-major: all columns of digit 0, then digit 1, ...): one block, strips of 4096
-// entries — a 16-byte load per thread (coalesced), prefix of the four, wave scan by shuffles, wave totals through LDS, running carry.
-// (`total` is a multiple of 4: 256 digits x cols.)
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *hist, int total, int p, const unsigned long long *bits) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+// Exclusive scan of hist[256][cols] (digit-major), in two levels: block d scans ROW d (all columns of digit d; cols <= 1024: one uint4 per
+// thread) in place and leaves the row's total in totals[d]; the scatter kernel adds the exclusive scan of the 256 totals itself. (Round 3
+// scanned all 256 x cols counters with one block, strip after strip: 35 us per pass at 0.9 M keys.)
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *hist, int cols, int p, const unsigned long long *bits, uint32_t *totals) {
+    __shared__ uint32_t s_wave[4];
     const unsigned long long varying = bits[0] & ~bits[1];
     if (!pass_runs(varying, p)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0u;
+    uint32_t *row = hist + (size_t) blockIdx.x * cols;
+    const int i = 4 * tid;
+    uint32_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = i + q < cols ? row[i + q] : 0u;
+    const uint32_t own = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = own;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    for (int base = 0; base < total; base += 4096) {
-        const int i = base + 4 * tid;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (i < total) v = *reinterpret_cast<const uint4 *>(hist + i);
-        const uint32_t own = v.x + v.y + v.z + v.w;
-        uint32_t inc = own;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t before = s_carry;
-        for (int w = 0; w < wave; ++w) before += s_wave[w];
-        before += inc - own;                                    // everything in front of this thread's four entries
-        if (i < total) *reinterpret_cast<uint4 *>(hist + i) = make_uint4(before, before + v.x, before + v.x + v.y, before + v.x + v.y + v.z);
-        __syncthreads();
-        if (tid == 1023) s_carry = before + own;
-        __syncthreads();
-    }
+    uint32_t before = inc - own;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    uint32_t run = before;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (i + q < cols) row[i + q] = run; run += v[q]; }
+    if (tid == 255) totals[blockIdx.x] = before + own;
 }
 
 template <typename K>
 __global__ __launch_bounds__(256) void k_sort_scatter(K *k0, K *k1, uint32_t *v0, uint32_t *v1, size_t n, int p, int tile, int cols,
-                                                      const unsigned long long *bits, const uint32_t *hist, int iota_first) {
+                                                      const unsigned long long *bits, const uint32_t *hist, int iota_first, const uint32_t *totals) {
     __shared__ uint32_t s_cnt[4][256];
+    __shared__ uint32_t s_base[256], s_wsum[4];
     const unsigned long long varying = bits[0] & ~bits[1];
     if (!pass_runs(varying, p)) return;
+    {   // where digit d's run starts: exclusive scan of the 256 row totals (thread t = digit t)
+        const int t = threadIdx.x, l = t & 63, w = t >> 6;
+        const uint32_t tot = totals[t];
+        uint32_t inc = tot;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (l >= d) inc += o; }
+        if (l == 63) s_wsum[w] = inc;
+        __syncthreads();
+        uint32_t base = inc - tot;
+        for (int q = 0; q < w; ++q) base += s_wsum[q];
+        s_base[t] = base;
+        __syncthreads();
+    }
     const int cur = buffer_before(varying, p);
     const bool first = iota_first && (varying & ((1ull << (8 * p)) - 1ull)) == 0ull;      // no earlier pass ran: values are still 0 .. n-1
     const K *src_k = cur ? k1 : k0;
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(K *k0, K *k1, uint32_t *v0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = blockIdx.x * 4 + wave, shift = 8 * p;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     if (col >= cols) return;
-    for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = hist[(size_t) i * cols + col];
+    for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = hist[(size_t) i * cols + col] + s_base[i];
     const size_t e0 = (size_t) col * tile, e1 = std::min(n, e0 + (size_t) tile);
     for (size_t e = e0 + lane; e - lane < e1; e += 64) {
         const bool valid = e < e1;
@@ -281,14 +297,15 @@ inline hipError_t sort_pairs(SortScratch &S, K *keys, K *keys_alt, uint32_t *val
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(S.bits + 1, 0xFF, sizeof(unsigned long long), stream);               // AND accumulator
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sort_bits<K>, dim3((unsigned) std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, stream, (const K *) keys, n, S.bits);
+    hipLaunchKernelGGL(k_sort_bits<K>, dim3((unsigned) std::min<size_t>((n + 255) / 256, 256)), dim3(256), 0, stream, (const K *) keys, n, S.bits);
+    uint32_t *totals = reinterpret_cast<uint32_t *>(S.bits + 2);
     const unsigned grid = (unsigned) ((cols + 3) / 4);
     for (int p = 0; p < passes; ++p) {
         hipLaunchKernelGGL(k_sort_hist<K>, dim3(grid), dim3(256), 0, stream, (const K *) keys, (const K *) keys_alt, n, p, tile, cols,
                            (const unsigned long long *) S.bits, S.hist);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, stream, S.hist, 256 * cols, p, (const unsigned long long *) S.bits);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, S.hist, cols, p, (const unsigned long long *) S.bits, totals);
         hipLaunchKernelGGL(k_sort_scatter<K>, dim3(grid), dim3(256), 0, stream, keys, keys_alt, vals, vals_alt, n, p, tile, cols,
-                           (const unsigned long long *) S.bits, (const uint32_t *) S.hist, iota_vals ? 1 : 0);
+                           (const unsigned long long *) S.bits, (const uint32_t *) S.hist, iota_vals ? 1 : 0, (const uint32_t *) totals);
     }
     hipLaunchKernelGGL(k_sort_finish<K>, dim3((unsigned) std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, (const K *) keys, keys_alt,
                        (const uint32_t *) vals, vals_alt, n, passes, (const unsigned long long *) S.bits, iota_vals ? 1 : 0);
