@@ -221,6 +221,10 @@ constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
 // Stream loop of the generic path: keep the next chunk's loads IN FRONT of the current chunk's test in the instruction stream. Left to
 // itself the scheduler starts the test (whose first instructions wait for the current chunk) before it has issued the next chunk's
 // loads, so only one chunk is ever in flight; with the fence the next chunk's loads are out before the wait.
+// The probe-batch loop of the generic path (VIT = 2 batches of 16 sweep voxels on the 27-voxel sweep, 8 on the 125-voxel one).
+#ifndef CTGN_BATCH_UNROLL
+#define CTGN_BATCH_UNROLL _Pragma("unroll")
+#endif
 #ifndef CTGN_STREAM_DEPTH
 #define CTGN_STREAM_DEPTH 2          // register sets of the stream loop. 3 (two chunks in flight) fits the registers without spills and
                                      // was measured: B2 0.1250 -> 0.1273 ms per iteration (the bounded searches stream 2-4 chunks per
@@ -1341,7 +1345,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             //   loads of chunk c+1 in flight while chunk c is tested against the radius / current k-th best and
             //   compacted into the row's LDS candidate list. A candidate's visit index is (sweep index v << 6) | slot:
             //   the reference's x-major sweep + insertion order (map.h:470-480), whatever the probing order.
-#pragma unroll
+CTGN_BATCH_UNROLL
             for (int it = 0; it < VIT; ++it) {
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
                 // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
