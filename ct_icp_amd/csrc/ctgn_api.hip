@@ -596,7 +596,10 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
         hipLaunchKernelGGL(k_residual_reduce<512>, dim3(grid), dim3(512), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
     }
-    const int grid = std::max(1, std::min(tiles256, h->res_grid_cap));
+    static const int env_cap = [] { const char *e = std::getenv("CTGN_RES_GRID_CAP"); return e ? std::atoi(e) : 0; }();           // measurement hook
+    // no more blocks than are resident at once (3 per CU): a larger scan's blocks take several tiles each, and the solve kernel has 768
+    // records to sum instead of 2 048 (config D: 0.6931 -> 0.6858 ms per iteration; 1 024: 0.6872, 1 536: 0.6885)
+    const int grid = std::max(1, std::min(tiles256, env_cap > 0 ? env_cap : std::min(h->res_grid_cap, 3 * h->num_cus)));
     hipLaunchKernelGGL(k_residual_reduce<RES_BLOCK>, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
                        h->ablate);
     return grid;
