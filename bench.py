@@ -916,6 +916,8 @@ def compact_line(result) -> str:
         line["robust_route"] = _pick(result["robust_route"], "value", "ms_per_frame")
     if isinstance(result.get("frame_pipeline"), dict):
         line["frame_pipeline"] = _pick(result["frame_pipeline"], "frame_ms", "register_ms", "update_map_ms", "frames_per_sec")
+        if isinstance(result["frame_pipeline"].get("page_locked_arrays"), dict):
+            line["frame_pipeline"]["page_locked_frame_ms"] = _round(result["frame_pipeline"]["page_locked_arrays"].get("frame_ms"))
     if isinstance(result.get("config_e"), dict):
         line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures", "scale")
     for k in ("strong_scaling_single_gpu_reference", "weak_scaling_line"):
@@ -1015,7 +1017,7 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
     every repetition gets a fresh one: one warm-up map, then the median over five timed maps."""
     raw, t = inp["raw"], inp["t"]
     maps = []
-    for _ in range(7):                                   # 0-3: stage by stage, 4-6: the frame pipeline
+    for _ in range(10):                                  # 0-3: stage by stage, 4-6: the frame pipeline, 7-9: the same from page-locked arrays
         m = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75,
                                                     device=device, device_updates=True))
         # frame-sized batches: the hash table is sized for the worst case of a batch (every point a new voxel), and the eviction scan
@@ -1030,7 +1032,7 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
     o5 = cia.CTICPOptions(solver=cia.GN, num_iters_icp=5, debug_print=False)
     ptimes, pcounts = [], {}
     world_all = np.zeros_like(raw)                       # the caller's own array for the undistorted scan, as the reference's in-place loop has
-    for rep, m in enumerate(maps[4:]):
+    for rep, m in enumerate(maps[4:7]):
         fp = cia.FramePipeline(m, frame_voxel_size=0.5, sample_voxel_size=1.5)
         regs = []
         for _ in range(4):                               # the registration does not change the map: repeat on the same one
@@ -1066,6 +1068,30 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
                             "and handed over, beside far-voxel eviction + insertion of the device-resident sampled frame (update_map_ms = what "
                             "the call costs beyond a register call)"}
     pipeline.update(pcounts)
+    # the same call with the scan, its timestamps and the output array in page-locked memory (what a driver that fills a pinned buffer
+    # from its sensor packets hands over): no staging copy on the way in, no hand-over copy on the way out
+    raw_p, t_p, world_p = cia.pinned_array(raw.shape), cia.pinned_array(t.shape), cia.pinned_array(raw.shape)
+    raw_p[:] = raw
+    t_p[:] = t
+    locked = []
+    for rep, m in enumerate(maps[7:10]):
+        fp = cia.FramePipeline(m, frame_voxel_size=0.5, sample_voxel_size=1.5)
+        regs = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            r = fp.register(raw_p, t_p, pose0, inp["tbe"], o5, want_all=True, want_sampled=False, all_world_out=world_p)
+            regs.append((time.perf_counter() - t0) * 1e3)
+        fp.update_map(r["pose"][11:14], 100.0, False)
+        t0 = time.perf_counter()
+        rp = fp.frame(raw_p, t_p, pose0, inp["tbe"], o5, 100.0, want_all=True, want_sampled=False, all_world_out=world_p)
+        whole = (time.perf_counter() - t0) * 1e3
+        assert np.array_equal(rp["pose"], rf["pose"]) and np.array_equal(world_p, world_all)
+        if rep > 0:
+            locked.append([min(regs[1:]), whole])
+    lm = np.median(np.array(locked), axis=0)
+    pipeline["page_locked_arrays"] = {"register_ms": float(lm[0]), "frame_ms": float(lm[1]), "frames_per_sec": 1e3 / float(lm[1]),
+                                      "what": "scan rows, timestamps and the output array in page-locked host memory (ct_icp_amd.pinned_array): "
+                                              "DMA from / to the caller's arrays, no staging; same results bit for bit"}
     world_buf = np.zeros_like(raw)
     for rep, m in enumerate(maps[:4]):
         cia.grid_sampling(m, raw, 0.5)                   # a fresh handle sizes its scratch on the first scan-sized call: not a per-frame cost

@@ -297,6 +297,18 @@ bool on_device(const void *p) {
     return a.type == hipMemoryTypeDevice;
 }
 
+// host memory the runtime can DMA from / to as it lies (hipHostMalloc, hipHostRegister, a framework's pinned allocator): both ends of
+// the range belong to a page-locked allocation
+bool host_pinned(const void *p, size_t bytes) {
+    if (!p || !bytes) return false;
+    auto pinned = [](const void *q) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void) hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    return pinned(p) && pinned(static_cast<const char *>(p) + bytes - 1);
+}
+
 inline int grid_for(size_t n) { return (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096)); }
 
 // device view -> SoA doubles on the handle's stream
@@ -2103,6 +2115,13 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
     const size_t nchunks = std::max<size_t>(1, (n + CHUNK - 1) / CHUNK);
     struct ChunkStat { double mn, mx; bool has_nan, bad_order; };
     std::vector<ChunkStat> stat(nchunks, ChunkStat{INFINITY, -INFINITY, false, false});
+    // Page-locked caller arrays in the plain layout (x y z rows of doubles, timestamps as doubles, scan order) are not staged: the DMA
+    // engine reads them where they lie and a kernel writes the x y z t records (a driver that fills such a buffer from its sensor
+    // packets saves the 4 MB staging copy of a 132 k-point scan). CTGN_FRAME_NO_DIRECT=1: always stage (measurement hook).
+    static const bool no_direct = std::getenv("CTGN_FRAME_NO_DIRECT") != nullptr;
+    const bool direct_in = n && !no_direct && !order && f64 && raw.stride_bytes == 3 * sizeof(double) &&
+                           (fo->override_timestamps || (tf64 && ts.stride_bytes == sizeof(double))) && host_pinned(raw.base, n * 3 * sizeof(double)) &&
+                           (fo->override_timestamps || host_pinned(ts.base, n * sizeof(double)));
     const std::function<void(size_t)> stage_chunk = [&](size_t k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
         // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
@@ -2136,6 +2155,41 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
     h->pool.ensure(helpers);
     const size_t group = (size_t) helpers + 1;
     bool has_nan = false;
+    if (direct_in) {
+        if (fo->override_timestamps) {
+            tmin = tmax = fo->override_timestamp;
+            has_nan = tmin != tmin;
+        } else {
+            const double *tp = reinterpret_cast<const double *>(tb_);
+            h->pool.run(nchunks, [&](size_t k) {
+                const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+                double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                bool nan = false;
+                size_t j = j0;
+                for (; j + 4 <= j1; j += 4)
+                    for (int u = 0; u < 4; ++u) {
+                        const double t = tp[j + u];
+                        mn[u] = t < mn[u] ? t : mn[u];
+                        mx[u] = t > mx[u] ? t : mx[u];
+                        nan = nan || t != t;
+                    }
+                for (; j < j1; ++j) { const double t = tp[j]; mn[0] = t < mn[0] ? t : mn[0]; mx[0] = t > mx[0] ? t : mx[0]; nan = nan || t != t; }
+                stat[k] = ChunkStat{std::min(std::min(mn[0], mn[1]), std::min(mn[2], mn[3])), std::max(std::max(mx[0], mx[1]), std::max(mx[2], mx[3])), nan, false};
+            });
+            for (size_t k = 0; k < nchunks; ++k) {
+                has_nan = has_nan || stat[k].has_nan;
+                tmin = std::min(tmin, stat[k].mn);
+                tmax = std::max(tmax, stat[k].mx);
+            }
+        }
+        // the output planes are free until the undistortion: the rows and the timestamps land there, the records are written from them
+        HIPCHK(h, hipMemcpyAsync(F.d_scan, F.h_scan, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(F.d_world, raw.base, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (!fo->override_timestamps) HIPCHK(h, hipMemcpyAsync(F.d_corr, ts.base, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_frame_records, dim3(grid_for(n)), dim3(256), 0, h->stream, F.d_world, fo->override_timestamps ? (const double *) nullptr : F.d_corr,
+                           fo->override_timestamp, (int) n, F.d_scan + 16);
+        HIPCHK(h, hipGetLastError());
+    } else
     for (size_t g0 = 0; g0 < nchunks; g0 += group) {
         const size_t g1 = std::min(nchunks, g0 + group);
         h->pool.run(g1 - g0, [&](size_t i) { stage_chunk(g0 + i); });
@@ -2194,8 +2248,11 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
         size_t pairs = 0, near = 0;
         for (size_t i = 0; i + gap < n; i += step, ++pairs) {
             bool ok = true;
-            for (int a = 0; a < 3 && ok; ++a)
-                ok = std::abs(voxel_coord(hs[4 * i + a], res) - voxel_coord(hs[4 * (i + gap) + a], res)) <= 1;
+            for (int a = 0; a < 3 && ok; ++a) {
+                const double p0 = direct_in ? reinterpret_cast<const double *>(rb)[3 * i + a] : hs[4 * i + a];
+                const double p1 = direct_in ? reinterpret_cast<const double *>(rb)[3 * (i + gap) + a] : hs[4 * (i + gap) + a];
+                ok = std::abs(voxel_coord(p0, res) - voxel_coord(p1, res)) <= 1;
+            }
             near += ok ? 1 : 0;
         }
         h->kp_coherent = pairs > 0 && 2 * near >= pairs;
@@ -2253,7 +2310,11 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
         HIPCHK(h, hipStreamWaitEvent(h->stream_down, h->ev_frame, 0));
         s_out = h->stream_down;
     }
-    if (want_all) HIPCHK(h, hipMemcpyAsync(F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double), hipMemcpyDeviceToHost, s_out));
+    // ... and straight into the caller's array when that is page-locked
+    const bool direct_out = all_rows && !no_direct && host_pinned(out->all_world_base, n * 3 * sizeof(double));
+    if (want_all)
+        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double),
+                                 hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_world_base && n1)
         HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_indices && n1)
@@ -2305,7 +2366,7 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
     if (out) {
         out->num_sampled = n1;
         out->num_keypoints = n2;
-        if (want_all) {
+        if (want_all && !direct_out) {
             const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
             char *ob = static_cast<char *>(out->all_world_base);
             const size_t os = out->all_world_stride_bytes;
@@ -2345,8 +2406,9 @@ static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view t
         mark(6);
         std::fprintf(stderr, "[ctgn] frame_register us: stage+upload enqueue %.0f | enqueue samplers %.0f | wait counts %.0f | keypoints+registration "
                              "enqueue %.0f | undistort enqueue %.0f | wait %.0f | scatter outputs %.0f | total %.0f (n %zu, sampled %zu, "
-                             "keypoints %zu)\n", marks[0], marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3],
-                     marks[5] - marks[4], marks[6] - marks[5], marks[6], n, n1, n2);
+                             "keypoints %zu%s%s)\n", marks[0], marks[1] - marks[0], marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3],
+                     marks[5] - marks[4], marks[6] - marks[5], marks[6], n, n1, n2, direct_in ? ", page-locked scan read in place" : "",
+                     direct_out ? ", page-locked output written in place" : "");
     }
     return CTGN_OK;
 }

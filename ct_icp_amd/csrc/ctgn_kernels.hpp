@@ -2498,6 +2498,16 @@ __global__ __launch_bounds__(256) void k_transform_points(const double *in, doub
 
 // Frame pipeline: keypoint i = scan point sel[i] (x y z t records): raw point and timestamp into the solver's keypoint arrays
 // (planes c apart).
+// x y z rows + timestamps (or one timestamp for all: t == nullptr) -> the frame's x y z t records
+__global__ __launch_bounds__(256) void k_frame_records(const double *xyz, const double *t, double t_all, int n, double *rec) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = xyz[3 * (size_t) i], y = xyz[3 * (size_t) i + 1], z = xyz[3 * (size_t) i + 2];
+        const double ti = t ? t[i] : t_all;
+        double *q = rec + 4 * (size_t) i;
+        q[0] = x; q[1] = y; q[2] = z; q[3] = ti;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_frame_keypoints(const double *scan, const uint32_t *sel, int n, double *kp, size_t c) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double *q = scan + (size_t) sel[i] * 4;

@@ -118,6 +118,15 @@ class CT_ICP_Registration:
         return _summary(s)
 
 
+def pinned_array(shape, dtype=np.float64) -> np.ndarray:
+    """A page-locked host array (the runtime's pinned allocator behind a NumPy view). FramePipeline calls whose scan (N x 3 float64
+    rows), timestamps (float64) and `all_world_out` live in such arrays are not staged: the DMA engine reads and writes them where
+    they lie (ctgn_frame_register). Needs a GPU runtime."""
+    import torch
+    buf = torch.empty(tuple(np.atleast_1d(shape)), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
+    return buf.numpy()          # the view keeps the tensor (and its allocation) alive
+
+
 def transform_points(voxel_map: GpuVoxelMap, raw, t, pose14, t_begin_end, out=None):
     """Full-scan continuous-time undistortion on the GPU (reference src/ct_icp/odometry.cpp:461-486): world[i] =
     begin.InterpolatePose(end, t[i]) * raw[i]. numpy in -> numpy out; torch CUDA tensors in -> torch CUDA tensor out (no host hop).

@@ -432,7 +432,9 @@ typedef struct {                         /* any pointer may be NULL = not wanted
 /* Sampling -> keypoints -> registration -> undistortion of one scan. `robust` NULL: the GN route with `opts` (+ `prior`, may be
  * NULL); `robust` non-NULL: the robust-loss route (`opts` / `prior` ignored, `robust_prior` may be NULL). pose_io in: the initial
  * begin|end estimate (trajectory_[kIndexFrame]); out: the optimised poses. The views are host memory. Errors leave the map and
- * the previous resident frame untouched. */
+ * the previous resident frame untouched. Page-locked arrays in the plain layout are used in place, without a staging copy: raw_xyz as
+ * rows of three doubles + timestamps as doubles (or override_timestamps) with order == NULL on the way in, all_world as rows of three
+ * doubles on the way out; every other layout is staged through the handle's own pinned buffers. Same results. */
 ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const uint32_t *order,
                                 const ctgn_frame_options *fopts, double pose_io[14], const double t_begin_end[2],
                                 const ctgn_options *opts, const ctgn_motion_prior *prior, const ctgn_robust_options *robust,

@@ -982,6 +982,58 @@ def test_frame_call_with_a_failed_registration_leaves_the_map_to_the_eviction(st
     assert np.array_equal(pa[np.lexsort(pa.T[::-1])], pb[np.lexsort(pb.T[::-1])])
 
 
+def test_page_locked_scan_arrays_are_read_and_written_in_place(street_case):
+    """Round 4: a frame call whose scan rows, timestamps and output array are page-locked host memory (ct_icp_amd.pinned_array) skips
+    the staging copy on the way in and the hand-over copy on the way out (ctgn_frame_register: DMA from / to the caller's arrays, the
+    x y z t records written by a kernel). Same poses, indices, world points and map as the staged path, bit for bit — also with the
+    first frames' overridden timestamp, with only some of the arrays page-locked, and with a timestamp outside the frame's interval."""
+    case = street_case
+    mk = lambda: cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(0.8, 0.1, 30)], default_radius=0.75, device_updates=True))
+    ga, gb = mk(), mk()
+    for j in range(4):
+        ga.InsertPointCloud(case["scans"][j].world_gt)
+        gb.InsertPointCloud(case["scans"][j].world_gt)
+    sc = case["scans"][4]
+    n = len(sc.t)
+    raw_p, t_p, out_p = cia.pinned_array((n, 3)), cia.pinned_array(n), cia.pinned_array((n, 3))
+    raw_p[:] = sc.raw
+    t_p[:] = sc.t
+    out_p[:] = -1.0
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=5)
+    o = _opts(num_iters_icp=4)
+    fa, fb = cia.FramePipeline(ga, 0.5, 1.5), cia.FramePipeline(gb, 0.5, 1.5)
+    ra = fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, o, want_all=True, want_sampled=True)
+    rb = fb.register(raw_p, t_p, pose0, sc.t_begin_end, o, want_all=True, want_sampled=True, all_world_out=out_p)
+    assert rb["all_world"] is out_p
+    for key in ("pose", "sampled_indices", "keypoint_indices", "all_world", "sampled_world"):
+        assert np.array_equal(ra[key], rb[key]), key
+    # mixed: page-locked input, pageable output and the other way round
+    rc = fb.register(raw_p, t_p, pose0, sc.t_begin_end, o, want_all=True, want_sampled=False)
+    out_p[:] = -1.0
+    rd = fb.register(sc.raw, sc.t, pose0, sc.t_begin_end, o, want_all=True, want_sampled=False, all_world_out=out_p)
+    assert np.array_equal(rc["all_world"], ra["all_world"]) and np.array_equal(rd["all_world"], ra["all_world"])
+    # one timestamp for every point (the first two registered frames, odometry.cpp:357-361)
+    o0 = _opts(num_iters_icp=0)
+    ea = fa.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o0, override_timestamp=sc.t_begin_end[1], want_sampled=False)
+    eb = fb.register(raw_p, t_p, sc.pose_gt, sc.t_begin_end, o0, override_timestamp=sc.t_begin_end[1], want_sampled=False, all_world_out=out_p)
+    assert np.array_equal(ea["all_world"], eb["all_world"])
+    # the whole frame, map update included
+    fa_ = fa.frame(sc.raw, sc.t, pose0, sc.t_begin_end, o, 60.0, want_all=True, want_sampled=False)
+    fb_ = fb.frame(raw_p, t_p, pose0, sc.t_begin_end, o, 60.0, want_all=True, want_sampled=False, all_world_out=out_p)
+    assert np.array_equal(fa_["pose"], fb_["pose"]) and np.array_equal(fa_["all_world"], fb_["all_world"])
+    assert ga.NumPoints() == gb.NumPoints() > 0
+    pa, pb = ga.MapAsPointCloud(), gb.MapAsPointCloud()
+    assert np.array_equal(pa[np.lexsort(pa.T[::-1])], pb[np.lexsort(pb.T[::-1])])
+    # a timestamp outside [t_begin, t_end] (or NaN) is refused as on the staged path, and the handle goes on working
+    for bad in (sc.t_begin_end[1] + 1.0, np.nan):
+        t_p[n // 2] = bad
+        with pytest.raises(cia.CtgnError):
+            fb.register(raw_p, t_p, pose0, sc.t_begin_end, o, want_all=False, want_sampled=False)
+    t_p[:] = sc.t
+    rz = fb.register(raw_p, t_p, pose0, sc.t_begin_end, o, want_all=False, want_sampled=False)
+    assert rz["summary"].success
+
+
 def test_map_or_keypoints_changed_inside_a_stepwise_solve_drop_the_carried_bound(street_case):
     """Every search after the first of a solve is bounded by the previous search's k-th neighbour distance —
     valid only while map and keypoints stay what they were. The stepwise API lets a caller change either between two accumulate
