@@ -2073,7 +2073,25 @@ static ctgn_status frame_finish_map_update(ctgn_handle h) {
     return CTGN_OK;
 }
 
+static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance);
+// An error return must not leave transfers in flight: with page-locked caller arrays the DMA engine reads and writes the CALLER's
+// memory, which the caller may free as soon as the call is back.
 static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
+    const ctgn_status st = frame_register_body(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, fused_max_distance);
+    if (st != CTGN_OK && h && h->device >= 0) {
+        (void) hipStreamSynchronize(h->stream);
+        if (h->stream_down) (void) hipStreamSynchronize(h->stream_down);
+        (void) hipGetLastError();
+    }
+    return st;
+}
+static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
                                        const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
                                        const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
                                        ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
