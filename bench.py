@@ -336,6 +336,33 @@ class Runner:
         else:
             self.solver.set_keypoints(W["raw"], W["world0"], W["t"])
 
+    def settle_clocks(self, body, limit_s=2.0):
+        """Untimed chunks of `body` (four solves' worth each) until two consecutive chunks take the same time to 3 %, at most `limit_s`:
+        the GPU leaves its idle clocks only under sustained load, and how long that takes depends on what the process — and the box — did
+        before (a run that started right behind another process's teardown measured 0.46 ms per step over K = 5 after the fixed 150
+        warm-up iterations). Single-process runs only (every rank would have to agree on the chunk count). Returns the iterations run."""
+        if self.dist is not None:
+            return 0
+        chunk = 4 * self.W["ipf"]
+        self.solver.set_profiling(False)
+        prev, good, done = None, 0, 0
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < limit_s:
+            self.sync_all()
+            t0 = time.perf_counter()
+            body(chunk)
+            self.sync_all()
+            dt = time.perf_counter() - t0
+            done += chunk
+            if prev is not None and abs(dt - prev) <= 0.03 * prev:
+                good += 1
+                if good >= 2:
+                    break
+            else:
+                good = 0
+            prev = dt
+        return done
+
     def timed(self, body, steps, warmup, clock_warm, profile=True):
         """clock_warm + warmup untimed iterations of `body`, then exactly `steps` timed ones bracketed by barrier + synchronize.
         Returns (seconds, summary, HIP-event kernel times: all, first-of-solve, bounded). profile=False: no event pairs (and a small
@@ -457,6 +484,7 @@ def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_wa
     # two passes of the same loop: the VALUE from a pass without event pairs (what a caller runs; a small frame goes through the
     # one-launch persistent kernel there), the search-kernel times of the roofline from a pass with a HIP-event pair around every
     # search launch (always the three-launch loop)
+    settled = R.settle_clocks(R.fresh)
     plain = R.timed(R.fresh, steps, warmup, clock_warm, profile=False)
     timing = R.timed(R.fresh, steps, warmup, 0, profile=True)
     prof_dt = timing[0]
@@ -476,6 +504,7 @@ def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_wa
     timing = (dt,) + tuple(timing[1:])
     out = {"value": total_kp * steps / dt, "unit": "keypoints/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "keypoints": n_kp,
            "keypoints_total": total_kp, "iterations_per_solve": W["ipf"], "solves_timed": (steps + W["ipf"] - 1) // W["ipf"],
+           "clock_settle_iterations": settled,
            "n_used_last_iter": int(summ.num_residuals_used), "first_iteration_ms": None, "later_iteration_ms": None,
            "map_points": int(W["gm"].NumPoints()), "map_voxels": int(W["gm"].NumVoxels(W["level"])), "searched_level_mb": W["level_mb"],
            "frames_per_sec_equiv": 1.0 / (dt / steps * W["ipf"]) if dt > 0 else None}
@@ -738,6 +767,7 @@ def main():
                                "of every solve has no carried-over bound, exactly as a frame pays it",
             "first_iteration_ms": res["first_iteration_ms"], "later_iteration_ms": res["later_iteration_ms"], "iteration_split_note": res["iteration_split_note"],
             "clock_warmup_iterations": args.clock_warm,
+            "clock_settle_iterations": res.get("clock_settle_iterations"),
             "clock_warmup_note": "untimed iterations of the same fresh-solve loop immediately before the W warm-up and K timed steps (no upload in "
                                  "between): the GPU leaves its idle clocks only under sustained load",
             "frames_per_sec_equiv": res["frames_per_sec_equiv"],
@@ -751,24 +781,31 @@ def main():
             gm, mm = W["gm"], W["mm"]
             result["frames_per_sec"] = measure_frames_per_sec(cia, gm, inp, syn, se3, mm)
             result["robust_route"] = measure_robust_frames_per_sec(cia, gm, inp, syn, se3, mm)
-            result["frame_stages"] = fs = measure_frame_stages(cia, inp, syn, se3, local_rank)
-            # the whole per-frame loop of Odometry::DoRegister on this frame, every data-parallel step through the library with host
-            # buffers in and out: the steps either side + one Register call on the sampled keypoints
-            for route, reg_ms in (("gn", result["frames_per_sec"]["ms_per_frame"]), ("robust", result["robust_route"]["ms_per_frame"])):
-                ms = fs["grid_sampling_ms"] + fs["keypoint_sampling_ms"] + reg_ms + fs["undistortion_ms"] + fs["map_update_ms"]
-                result.setdefault("frame_by_stage_calls", {})[route] = {"ms_per_frame": ms, "frames_per_sec": 1e3 / ms}
-            # the same frame as ONE ctgn_frame_register + ctgn_frame_update_map (scan resident on the device)
-            result["frame_pipeline"] = fs.pop("frame_pipeline")
-            result["frame_pipeline"]["frames_per_sec"] = 1e3 / result["frame_pipeline"]["frame_ms"]
+            # (the measurements around the path must not cost the run its headline line: a failure is recorded, not raised)
+            try:
+                result["frame_stages"] = fs = measure_frame_stages(cia, inp, syn, se3, local_rank)
+                # the whole per-frame loop of Odometry::DoRegister on this frame, every data-parallel step through the library with host
+                # buffers in and out: the steps either side + one Register call on the sampled keypoints
+                for route, reg_ms in (("gn", result["frames_per_sec"]["ms_per_frame"]), ("robust", result["robust_route"]["ms_per_frame"])):
+                    ms = fs["grid_sampling_ms"] + fs["keypoint_sampling_ms"] + reg_ms + fs["undistortion_ms"] + fs["map_update_ms"]
+                    result.setdefault("frame_by_stage_calls", {})[route] = {"ms_per_frame": ms, "frames_per_sec": 1e3 / ms}
+                # the same frame as ONE ctgn_frame_register + ctgn_frame_update_map (scan resident on the device)
+                result["frame_pipeline"] = fs.pop("frame_pipeline")
+                result["frame_pipeline"]["frames_per_sec"] = 1e3 / result["frame_pipeline"]["frame_ms"]
+            except Exception as e:
+                result["frame_stages_error"] = f"{type(e).__name__}: {e}"[:300]
             if default_line and args.config_e_scale > 0:
                 # config E on one GPU (no 8-GPU number is asked of this run): the 11 sequences back to back, one ctgn_frame call per frame
                 import importlib.util
                 spec = importlib.util.spec_from_file_location("ctgn_sequence_run", os.path.join(ROOT, "scripts", "sequence_run.py"))
                 seq_mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(seq_mod)
-                ce = seq_mod.run_config_e(scale=args.config_e_scale, device=local_rank)
-                ce.pop("per_sequence_detail", None)
-                result["config_e"] = ce
+                try:
+                    ce = seq_mod.run_config_e(scale=args.config_e_scale, device=local_rank)
+                    ce.pop("per_sequence_detail", None)
+                    result["config_e"] = ce
+                except Exception as e:
+                    result["config_e_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline and args.workload in ("B2", "B2-small") and world == 1:      # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(inp, W["pose0"], W["world0"], args, om)
             if result["cpu_baseline"]["value"]:
@@ -794,16 +831,20 @@ def main():
         result["workloads"] = {}
         for name in subs:
             t_sub = time.perf_counter()
-            Ws = build_workload(name, rank, world, args, cia, syn, se3)
-            small = name in ("B1", "C")
-            sub_steps = {"B1": 200, "C": 200, "D": 20}.get(name, 50)
-            sres, som = measure_workload(Ws, args, cia, torch, None, False, sub_steps, 10 if small else 5, 100 if small else 10, want_steady=True,
-                                         cpu_seconds=8.0, register_extras=small, pmc_live=(name in args.sub_pmc.split(",") and not args.no_pmc))
-            sres["config"] = NAMES[name]
-            if name == "D":
-                sres["config_detail"] = {"rays": int(Ws["inp"]["rays"]), "returns": int(Ws["inp"]["returns"])}
-            sres["wall_seconds"] = time.perf_counter() - t_sub
-            result["workloads"][name] = sres
+            Ws = som = None
+            try:                                          # a sub-workload that fails costs its own object, not the line
+                Ws = build_workload(name, rank, world, args, cia, syn, se3)
+                small = name in ("B1", "C")
+                sub_steps = {"B1": 200, "C": 200, "D": 20}.get(name, 50)
+                sres, som = measure_workload(Ws, args, cia, torch, None, False, sub_steps, 10 if small else 5, 100 if small else 10, want_steady=True,
+                                             cpu_seconds=8.0, register_extras=small, pmc_live=(name in args.sub_pmc.split(",") and not args.no_pmc))
+                sres["config"] = NAMES[name]
+                if name == "D":
+                    sres["config_detail"] = {"rays": int(Ws["inp"]["rays"]), "returns": int(Ws["inp"]["returns"])}
+                sres["wall_seconds"] = time.perf_counter() - t_sub
+                result["workloads"][name] = sres
+            except Exception as e:
+                result["workloads"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             del Ws, som
             gc.collect()
 
@@ -812,33 +853,47 @@ def main():
         from ct_icp_amd.distributed import ShardedGnSolver, allreduce_system
         gm, mm, pose0, inp = W["gm"], W["mm"], W["pose0"], W["inp"]
         # (a) the same scan on ONE GPU (rank 0, the others wait): the denominator of the strong-scaling efficiency
+        # (neither may cost the run its line: rank 0's own measurement is wrapped; the collective one starts only if every rank got
+        # its inputs, so no rank waits in an exchange its peers never reach)
         single = None
         if rank == 0:
-            W1 = dict(W, raw=W["all_raw"], t=W["all_t"], world0=W["all_world0"])
-            W1.pop("shard", None)
-            R1 = Runner(W1, args, cia, torch, None, False)
-            R1.upload()
-            d1 = R1.timed(R1.fresh, args.steps, args.warmup, args.clock_warm)[0]
-            R1.close()
-            single = {"value": len(W1["t"]) * args.steps / d1, "ms_per_step": d1 / args.steps * 1e3, "keypoints": int(len(W1["t"])),
-                      "note": "the same scan, unsharded, on rank 0's GPU; same fresh-solve loop"}
+            try:
+                W1 = dict(W, raw=W["all_raw"], t=W["all_t"], world0=W["all_world0"])
+                W1.pop("shard", None)
+                R1 = Runner(W1, args, cia, torch, None, False)
+                R1.upload()
+                d1 = R1.timed(R1.fresh, args.steps, args.warmup, args.clock_warm)[0]
+                R1.close()
+                single = {"value": len(W1["t"]) * args.steps / d1, "ms_per_step": d1 / args.steps * 1e3, "keypoints": int(len(W1["t"])),
+                          "note": "the same scan, unsharded, on rank 0's GPU; same fresh-solve loop"}
+            except Exception as e:
+                result["strong_scaling_single_gpu_reference_error"] = f"{type(e).__name__}: {e}"[:300]
         dist.barrier()
         # (b) weak-scaling line: one B2-small sweep per rank (its own noise realisation), same sharded loop
-        Ww = build_workload("B2-small", rank, world, args, cia, syn, se3)
-        Rw = Runner(Ww, args, cia, torch, dist, True)
-        Rw.upload()
-        dw = Rw.timed(Rw.fresh, args.steps, args.warmup, args.clock_warm)[0]
-        Rw.close()
-        tw = torch.tensor([dw], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        nw = torch.tensor([len(Ww["t"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(nw, op=dist.ReduceOp.SUM)
+        Ww = None
+        try:
+            Ww = build_workload("B2-small", rank, world, args, cia, syn, se3)
+        except Exception as e:
+            if rank == 0:
+                result["weak_scaling_line_error"] = f"{type(e).__name__}: {e}"[:300]
+        ready = torch.tensor([1.0 if Ww is not None else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
         if rank == 0:
             result["strong_scaling_single_gpu_reference"] = single
             if single:
                 result["strong_scaling_efficiency"] = result["value"] / (world * single["value"])
-            result["weak_scaling_line"] = {"value": float(nw.item()) * args.steps / float(tw.item()), "ms_per_step": float(tw.item()) / args.steps * 1e3,
-                                           "keypoints_per_gpu": int(len(Ww["t"])), "workload": "B2-small sweep per rank, sharded loop", "scaling": "weak"}
+        if ready.item() > 0.5:
+            Rw = Runner(Ww, args, cia, torch, dist, True)
+            Rw.upload()
+            dw = Rw.timed(Rw.fresh, args.steps, args.warmup, args.clock_warm)[0]
+            Rw.close()
+            tw = torch.tensor([dw], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            nw = torch.tensor([len(Ww["t"])], dtype=torch.float64, device="cuda")
+            dist.all_reduce(nw, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                result["weak_scaling_line"] = {"value": float(nw.item()) * args.steps / float(tw.item()), "ms_per_step": float(tw.item()) / args.steps * 1e3,
+                                               "keypoints_per_gpu": int(len(Ww["t"])), "workload": "B2-small sweep per rank, sharded loop", "scaling": "weak"}
     if rank == 0:
         emit(result, args)
     if dist is not None:
@@ -1070,11 +1125,16 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
     pipeline.update(pcounts)
     # the same call with the scan, its timestamps and the output array in page-locked memory (what a driver that fills a pinned buffer
     # from its sensor packets hands over): no staging copy on the way in, no hand-over copy on the way out
-    raw_p, t_p, world_p = cia.pinned_array(raw.shape), cia.pinned_array(t.shape), cia.pinned_array(raw.shape)
-    raw_p[:] = raw
-    t_p[:] = t
+    try:
+        raw_p, t_p, world_p = cia.pinned_array(raw.shape), cia.pinned_array(t.shape), cia.pinned_array(raw.shape)
+    except Exception as e:                                # no page-locked memory to be had: the staged numbers stand alone
+        raw_p = None
+        pipeline["page_locked_arrays"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     locked = []
-    for rep, m in enumerate(maps[7:10]):
+    for rep, m in enumerate(maps[7:10] if raw_p is not None else []):
+        if rep == 0:
+            raw_p[:] = raw
+            t_p[:] = t
         fp = cia.FramePipeline(m, frame_voxel_size=0.5, sample_voxel_size=1.5)
         regs = []
         for _ in range(4):
@@ -1088,10 +1148,11 @@ def measure_frame_stages(cia, inp, syn, se3, device: int):
         assert np.array_equal(rp["pose"], rf["pose"]) and np.array_equal(world_p, world_all)
         if rep > 0:
             locked.append([min(regs[1:]), whole])
-    lm = np.median(np.array(locked), axis=0)
-    pipeline["page_locked_arrays"] = {"register_ms": float(lm[0]), "frame_ms": float(lm[1]), "frames_per_sec": 1e3 / float(lm[1]),
-                                      "what": "scan rows, timestamps and the output array in page-locked host memory (ct_icp_amd.pinned_array): "
-                                              "DMA from / to the caller's arrays, no staging; same results bit for bit"}
+    if locked:
+        lm = np.median(np.array(locked), axis=0)
+        pipeline["page_locked_arrays"] = {"register_ms": float(lm[0]), "frame_ms": float(lm[1]), "frames_per_sec": 1e3 / float(lm[1]),
+                                          "what": "scan rows, timestamps and the output array in page-locked host memory (ct_icp_amd.pinned_array): "
+                                                  "DMA from / to the caller's arrays, no staging; same results bit for bit"}
     world_buf = np.zeros_like(raw)
     for rep, m in enumerate(maps[:4]):
         cia.grid_sampling(m, raw, 0.5)                   # a fresh handle sizes its scratch on the first scan-sized call: not a per-frame cost
