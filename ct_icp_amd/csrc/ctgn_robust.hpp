@@ -166,7 +166,12 @@ __device__ __forceinline__ double ct_residual(const PoseCtx &c, double alpha, Ve
             wb = ax + s * (cb * perp - sb * uxc);        // W_b^T c
             we = ax + s * (ce * perp - se * uxc);        // W_e^T c
         }
-        const Vec3 jb = cross(a, m) + quat_rotate(qb, wb), je = quat_rotate(qe, we);
+        // alpha == 1: slerp(q_b, q_e, 1) is q_e whatever q_b, and the reference's Jets say so exactly (Eigen's slerp gives scale0 = sin(0 * theta) /
+        // sin(theta) and scale1 = sin(theta) / sin(theta), whose derivatives are 0 and (da - 1 * db) / b with da == db). The closed form
+        // cancels a x m against R_b W_b^T c only to rounding, and a column of 1e-16s is not harmless: Levenberg-Marquardt damps a (near)
+        // zero column with min_diagonal / radius = 1e-10, so gradient noise of 1e-14 becomes a step of 1e-4. Frames 0 and 1 of a sequence
+        // carry the end timestamp on every point (odometry.cpp:354-359): there the begin orientation must stay where it was, bit for bit.
+        const Vec3 jb = oma == 0.0 ? Vec3{0.0, 0.0, 0.0} : cross(a, m) + quat_rotate(qb, wb), je = quat_rotate(qe, we);
         J[0] = -2.0 * jb.x; J[1] = -2.0 * jb.y; J[2] = -2.0 * jb.z;
         J[3] = 2.0 * je.x; J[4] = 2.0 * je.y; J[5] = 2.0 * je.z;
         J[6] = -oma * m.x; J[7] = -oma * m.y; J[8] = -oma * m.z;

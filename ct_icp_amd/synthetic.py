@@ -340,9 +340,11 @@ def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps:
 # Trajectory: frame k spans [k*dt, (k+1)*dt]; end pose of frame k == begin pose of frame k+1
 # --------------------------------------------------------------------------------------------------
 def driving_trajectory(num_frames: int, dt: float = 0.1, speed: float = 10.0, yaw_rate: float = 0.1,
-                       height: float = 1.73, jitter: float = 0.0, seed: int = 0, start_x: float = 0.0):
+                       height: float = 1.73, jitter: float = 0.0, seed: int = 0, start_x: float = 0.0, ramp_frames: int = 0):
     """Knot poses (num_frames+1, 7) of a constant-speed, constant-yaw-rate vehicle; optional roll/pitch jitter
-    (config C). Yaw oscillates so the vehicle stays inside the street."""
+    (config C). Yaw oscillates so the vehicle stays inside the street. `ramp_frames` > 0: the vehicle pulls away from rest, its speed
+    rising linearly to `speed` over that many frames (a recording that starts with the car standing, as the KITTI drives do: an
+    odometry that starts from the identity — Odometry::InitializeMotion, odometry.cpp:276-300 — has no velocity to extrapolate yet)."""
     rng = np.random.default_rng(seed)
     poses = np.zeros((num_frames + 1, 7))
     x, y, yaw = start_x, 0.0, 0.0
@@ -352,8 +354,9 @@ def driving_trajectory(num_frames: int, dt: float = 0.1, speed: float = 10.0, ya
                          se3.quat_mul(se3.quat_from_rotvec([0, pitch, 0]), se3.quat_from_rotvec([roll, 0, 0])))
         poses[k, 0:4] = se3.quat_normalize(q)
         poses[k, 4:7] = [x, y, height]
-        x += speed * dt * np.cos(yaw)
-        y += speed * dt * np.sin(yaw)
+        v = speed * min(1.0, (k + 0.5) / ramp_frames) if ramp_frames > 0 else speed
+        x += v * dt * np.cos(yaw)
+        y += v * dt * np.sin(yaw)
         yaw += yaw_rate * dt * np.cos(2 * np.pi * k / 40.0)
     return poses
 

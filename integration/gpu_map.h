@@ -32,13 +32,21 @@ namespace ct_icp {
 
     class GpuVoxelMap : public ISlamMap {
     public:
-        struct Options : public MultipleResolutionVoxelMap::Options {       // same YAML keys (src/ct_icp/map.cpp:32-65) + `device`
+        // Same fields and YAML keys as MultipleResolutionVoxelMap::Options (map.h:109-134, src/ct_icp/map.cpp:32-65) + `device`. Derived from
+        // IMapOptions itself: MultipleResolutionVoxelMap::Options::MakeMapFromOptions is `final` (map.h:130), and the factory call is how
+        // Odometry::Odometry / Odometry::Reset come by their map (src/ct_icp/odometry.cpp:700,973).
+        struct Options : public IMapOptions {
+            std::vector<MultipleResolutionVoxelMap::ResolutionParam> resolutions = MultipleResolutionVoxelMap::Options().resolutions;
+            size_t max_frames_to_keep = 100;                                // kept for the YAML loader; the device map keeps no frame ids
+            double default_radius = 0.8;
             int device = 0;
             bool device_updates = true;                                     // insert / evict rules run on the GPU (ctgn_map_set_update_mode)
 
             static std::string Type() { return "GPU_VOXEL_HASHMAP"; }
 
             std::string GetType() const override { return Type(); }
+
+            inline std::shared_ptr<ISlamMap> MakeMapFromOptions() const final { return std::make_shared<GpuVoxelMap>(*this); }
         };
 
         explicit GpuVoxelMap(const Options &options) : options_(options) {
