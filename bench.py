@@ -332,6 +332,7 @@ class Runner:
         W = self.W
         if "shard" in W:
             idx = self.solver.set_keypoints_sharded(W["all_raw"], W["all_world0"], W["all_t"], *W["shard"])
+            W["upload_h2d_bytes"] = self.solver.last_upload_bytes()         # 24 B x scan + 56 B x chunk per rank (56 B x scan before round 5)
             W["raw"], W["t"], W["world0"] = W["all_raw"][idx], W["all_t"][idx], W["all_world0"][idx]
         else:
             self.solver.set_keypoints(W["raw"], W["world0"], W["t"])
@@ -508,6 +509,9 @@ def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_wa
            "n_used_last_iter": int(summ.num_residuals_used), "first_iteration_ms": None, "later_iteration_ms": None,
            "map_points": int(W["gm"].NumPoints()), "map_voxels": int(W["gm"].NumVoxels(W["level"])), "searched_level_mb": W["level_mb"],
            "frames_per_sec_equiv": 1.0 / (dt / steps * W["ipf"]) if dt > 0 else None}
+    if "upload_h2d_bytes" in W:
+        out["sharded_upload"] = {"h2d_bytes_this_rank": int(W["upload_h2d_bytes"]), "h2d_bytes_whole_scan_7_arrays": 56 * int(total_kp),
+                                 "note": "per rank: 24 B x scan (world points: the home-voxel order every rank must agree on) + 56 B x chunk"}
     # ---- steady state: ONE running loop (round 2's headline): every search after the first is bounded, the pose has converged
     steady = None
     if want_steady and not args.inner:
@@ -662,6 +666,25 @@ def register_calls(W, cia, om):
     return res
 
 
+def self_launch(n_gpus: int, backend: str, devices_visible: int) -> int:
+    """Re-run this command line under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free port) and return its exit
+    code. Fewer visible devices than ranks is an error (one JSON line, exit code 2) unless the gloo rehearsal backend was asked for, whose
+    ranks share devices on purpose."""
+    import socket
+    import subprocess
+    if backend == "nccl" and devices_visible < n_gpus:
+        print(json.dumps({"error": f"--gpus {n_gpus} needs {n_gpus} visible devices, this box has {devices_visible}",
+                          "n_gpus_requested": n_gpus, "devices_visible": devices_visible}))
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -707,14 +730,27 @@ def main():
         args.sub = "none"
 
     import torch
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it starts its own ranks (one process per GPU over RCCL, exactly the
+    # command the driver uses for N > 1); it never prints a line whose n_gpus differs from --gpus with exit code 0.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, args.dist_backend, torch.cuda.device_count()))
+
     import ct_icp_amd as cia
     from ct_icp_amd import se3, synthetic as syn
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", "n_gpus_requested": args.gpus}))
+        raise SystemExit(2)
+    if args.dist_backend == "nccl" and torch.cuda.device_count() < (world if world > 1 else 1):
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} needs {world} visible devices, this box has {torch.cuda.device_count()}",
+                              "n_gpus_requested": args.gpus, "devices_visible": torch.cuda.device_count()}))
+        raise SystemExit(2)
     default_line = args.workload is None and world == 1
     if args.workload is None:
         args.workload = "B2" if world == 1 else "D"
@@ -773,7 +809,7 @@ def main():
             "frames_per_sec_equiv": res["frames_per_sec_equiv"],
             "roofline": res["roofline"],
         }
-        for k in ("parity_m_rad", "parity"):
+        for k in ("parity_m_rad", "parity", "sharded_upload"):
             if k in res:
                 result[k] = res[k]
         inp = W["inp"]

@@ -179,6 +179,7 @@ SYMBOLS = {
     "ctgn_phase_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "ctgn_test_sort_pairs": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
     "ctgn_test_compact": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "ctgn_last_upload_bytes": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 

@@ -141,6 +141,11 @@ struct ctgn_context {
     double guess_factor = -1.0;         // ctgn_set_search_guess: < 0 automatic, 0 off, > 0 forced factor on r_k (launch_accumulate)
     int normals_mode = 0;               // ctgn_set_normals: 0 library default (hybrid), 1 exact, 2 hybrid, 3 fast
     int fail_slot = 0;                  // which of the two fail-list counters the next split launch counts in (the other one is zeroed by it)
+    uint64_t last_upload_bytes = 0;     // host-to-device bytes of the last ctgn_set_keypoints_sharded call on this rank (bench detail)
+    int rb_split_search[2] = {0, 0};    // resident blocks of the split path's search launch (27- / 125-voxel instantiation)
+    bool fail_reset_pending = true;     // a new solve began: its first split launch zeroes both counters and starts from slot 0 (a solve that
+                                        // stops early leaves the slot its last EXECUTED launch counted in non-zero: the launches behind the stop
+                                        // test return before they zero anything, while the host keeps toggling the slot)
     bool gn_active = false;
     std::chrono::steady_clock::time_point gn_t0;
     double init_ms = 0.0;               // host time from the call to the first launch (ICPSummary::duration_init)
@@ -738,6 +743,11 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const int rounds_c = pick_rounds(h->n_kp, rb_check * ROW_WAVES);
             const int ntiles_c = (h->n_kp + 4 * rounds_c - 1) / (4 * rounds_c);
             int *counters = reinterpret_cast<int *>(h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 4));
+            if (h->fail_reset_pending) {
+                HIPCHK(h, hipMemsetAsync(counters, 0, 8 * sizeof(int), h->stream));
+                h->fail_slot = 0;
+                h->fail_reset_pending = false;
+            }
             kv.fail_count = counters + 4 * h->fail_slot;
             kv.fail_count_next = counters + 4 * (h->fail_slot ^ 1);
             h->fail_slot ^= 1;
@@ -749,7 +759,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             ks.resume = 1;
             ks.clk_iter_start = nullptr;
             auto search = [&](auto kernel, size_t smem) {
-                const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
+                int &rb = h->rb_split_search[mv.nb == 1 ? 0 : 1];                 // one occupancy query per handle and instantiation
+                if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
                 hipLaunchKernelGGL(kernel, dim3(rb), dim3(ROW_BLOCK), smem, h->stream, mv, ks, h->d_state, h->prm, h->d_partials, dv, 0, 1,
                                    (unsigned long long *) nullptr, h->ablate);
             };
@@ -1457,6 +1468,7 @@ ctgn_status ctgn_gn_begin(ctgn_handle h, const double pose[14], const double tbe
     h->world_final_done = false;
     h->launched_iters = 0;
     h->searches_in_solve = 0;
+    h->fail_reset_pending = true;
     h->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->gn_t0).count();
     h->planned_iters = opts->num_iters_icp;
     // a solve begun while the previous one was never ended (repeated solves enqueued back to back): its launches all did work and
@@ -1697,14 +1709,82 @@ ctgn_status ctgn_dist_shutdown(ctgn_handle h) {
     return CTGN_OK;
 }
 
+// Host views, more than one rank (round 5): every rank needs the ORDER of the whole scan (the partition must be the same everywhere and the
+// sort is the library's deterministic one), but only its own chunk of the seven keypoint arrays. So only the world points go up for the key
+// pass (24 B per keypoint of the scan), the rank's chunk of the order comes back (4 B per keypoint of the chunk), and the chunk's rows are
+// gathered from the caller's views straight into kernel order and uploaded (56 B per keypoint of the chunk): 24 N + 56 N / G bytes per rank
+// instead of 56 N. Timestamps are range-checked over the whole scan on the host, so that every rank accepts or refuses the same scan.
+static ctgn_status set_keypoints_sharded_lean(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n, int32_t rank,
+                                              int32_t world_size, uint32_t *shard_indices, size_t *shard_n) {
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many keypoints");
+    ctgn_status st = reserve_keypoints(h, n);
+    if (st != CTGN_OK) return st;
+    HIPCHK(h, hipStreamSynchronize(h->stream));                // staging reuse
+    const size_t c = (size_t) h->kp_stride;
+    double tmin = INFINITY, tmax = -INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) h->h_kp[(4 + a) * c + i] = read_elem(world.base, world.stride_bytes, world.dtype, i, a);
+        const double t = read_elem(ts.base, ts.stride_bytes, ts.dtype, i, 0);
+        tmin = t < tmin ? t : tmin;
+        tmax = t > tmax ? t : tmax;
+        if (t != t) tmax = NAN;
+    }
+    h->t_min = tmin; h->t_max = tmax;
+    HIPCHK(h, hipMemcpyAsync(h->d_kp + 4 * c, h->h_kp + 4 * c, 3 * c * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int map_id, nb;
+    double res;
+    search_params(h->levels, h->opts.default_radius, &map_id, &res, &nb);
+    st = order_reserve(h);
+    if (st != CTGN_OK) return st;
+    DMCHK(h, order_by_home_voxel(h->ord, h->d_kp + 4 * c, h->d_kp + 5 * c, h->d_kp + 6 * c, n, res, h->stream));
+    const size_t base = n / (size_t) world_size, rem = n % (size_t) world_size;        // contiguous, balanced chunks
+    const size_t lo = (size_t) rank * base + std::min<size_t>((size_t) rank, rem), m = base + ((size_t) rank < rem ? 1 : 0);
+    const size_t c2 = std::min((m + 63) & ~(size_t) 63, c);
+    std::vector<uint32_t> own;
+    uint32_t *idx = shard_indices;
+    if (!idx) { own.resize(m); idx = own.data(); }
+    HIPCHK(h, hipMemcpyAsync(idx, h->ord.order + lo, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));                // the order is here; the staging buffer is free again
+    for (size_t j = 0; j < m; ++j) {
+        const size_t i = idx[j];
+        for (int a = 0; a < 3; ++a) {
+            h->h_kp[a * c2 + j] = read_elem(raw.base, raw.stride_bytes, raw.dtype, i, a);
+            h->h_kp[(4 + a) * c2 + j] = read_elem(world.base, world.stride_bytes, world.dtype, i, a);
+        }
+        h->h_kp[3 * c2 + j] = read_elem(ts.base, ts.stride_bytes, ts.dtype, i, 0);
+    }
+    for (int a = 0; a < 7; ++a)
+        for (size_t j = m; j < c2; ++j) h->h_kp[a * c2 + j] = 0.0;
+    HIPCHK(h, hipMemcpyAsync(h->d_kp, h->h_kp, 7 * c2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->last_upload_bytes = (3 * (uint64_t) c + 7 * (uint64_t) c2) * sizeof(double);
+    h->n_kp = (int) m;
+    h->kp_stride = (int) c2;
+    h->pose_on_device = false;
+    h->kp_coherent = false;
+    h->kp_presorted = true;
+    h->order_stale = false;
+    h->order_valid = false;
+    h->kth_fresh = false;
+    if (shard_n) *shard_n = m;
+    st = save_world0(h);
+    if (st != CTGN_OK) return st;
+    return ensure_debug(h);
+}
+
 ctgn_status ctgn_set_keypoints_sharded(ctgn_handle h, ctgn_view raw, ctgn_view world, ctgn_view ts, size_t n, int32_t rank, int32_t world_size,
                                        uint32_t *shard_indices, size_t *shard_n) {
     NEED_DEVICE(h);
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "bad rank / world size");
     if (shard_n) *shard_n = 0;
+    h->last_upload_bytes = 0;
+    if (world_size > 1 && n >= (size_t) 64 * (size_t) world_size && raw.base && world.base && ts.base && !on_device(raw.base) &&
+        !on_device(world.base) && !on_device(ts.base))
+        return set_keypoints_sharded_lean(h, raw, world, ts, n, rank, world_size, shard_indices, shard_n);
     const bool keep = h->keep_world0;
     h->keep_world0 = false;                                    // the copy for ctgn_rewind_keypoints is taken of the shard, below
     ctgn_status st = ctgn_set_keypoints(h, raw, world, ts, n); // the whole scan, resident for a moment; t_min / t_max are the scan's
+    if (st == CTGN_OK && n > 0 && !on_device(raw.base)) h->last_upload_bytes = 7 * (uint64_t) h->kp_stride * sizeof(double);
     h->keep_world0 = keep;
     if (st != CTGN_OK || n == 0) return st;
     int map_id, nb;
@@ -2599,6 +2679,7 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     const bool saved_prof = h->profiling;
     h->profiling = false;
     h->searches_in_solve = 0;
+    h->fail_reset_pending = true;
     for (int it = 0; st == CTGN_OK && it < o->num_iters_icp; ++it) {                     // :535
         st = launch_accumulate(h, mv, false, true);                                      // transform_keypoints + neighbourhoods
         if (st != CTGN_OK) break;
@@ -2838,6 +2919,12 @@ ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, 
         return CTGN_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_test_sort(keys, n, key_bits, key_bytes, order_out, h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_last_upload_bytes(ctgn_handle h, uint64_t *bytes) {
+    if (!h || !bytes) return CTGN_ERR_INVALID_ARGUMENT;
+    *bytes = h->last_upload_bytes;
     return CTGN_OK;
 }
 

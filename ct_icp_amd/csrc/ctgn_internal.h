@@ -47,6 +47,26 @@ ctgn_status ctgn_traffic_counters(ctgn_handle h, uint64_t out[2], int32_t reset)
  * rounds); slots of waves that did not run keep their previous content (zero initially). */
 ctgn_status ctgn_wave_timeline(ctgn_handle h, uint64_t *out, size_t max_waves, size_t *n_waves);
 
+/* Moved here from include/ctgn.h in round 5 (measurement / A-B hooks, not part of the drop-in contract): */
+/* Counting pass for the roofline: V = voxels probed per keypoint, total map points inside them, summed
+ * over the resident keypoints at their current world positions. */
+ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *voxels_probed, uint64_t *voxels_hit,
+                               uint64_t *points_scanned);
+/* The same, split by what bounded the search: [0] = the first search of a solve (radius only: nothing carried over), [1] = every later
+ * one (bounded by the previous search's k-th neighbour distance + the keypoint's displacement). */
+ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t launches[2], int32_t reset);
+/* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
+ * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection,
+ * 3 = variant 0 instrumented with per-phase shader clocks (read through ct_icp_amd/csrc/ctgn_internal.h), 4 = variant 0 compiled for
+ * 4 waves per SIMD instead of 3 (A/B hook), 5 = variant 0 with the shared-home-voxel path of the 27-voxel sweep compiled in
+ * (the four keypoints of a round probe and stream one flattened neighbourhood; the default until round 2, now slower than the
+ * bounded generic path — A/B hook). Same results for every variant. Test / measurement hook. */
+ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
+
+/* Host-to-device bytes the last ctgn_set_keypoints_sharded call moved on this rank (host views): 56 B per keypoint of the scan with one rank,
+ * 24 B per keypoint of the scan (world points, for the order every rank must agree on) + 56 B per keypoint of the rank's chunk otherwise. */
+ctgn_status ctgn_last_upload_bytes(ctgn_handle h, uint64_t *bytes);
+
 /* Test hooks for the library's own sort / compaction kernels (ctgn_sort.hpp; they replace a vendor sort library on the frame path: the
  * map-update batch, the adaptive sampler, the home-voxel ordering): order_out[j] = index of the j-th smallest key under a STABLE sort on
  * the low key_bits bits (key_bytes 4: the keys are narrowed to 32 bits first); out_indices = ascending indices whose flag is non-zero.

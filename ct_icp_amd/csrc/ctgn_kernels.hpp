@@ -1512,7 +1512,10 @@ CTGN_BATCH_UNROLL
             // searched again on the radius (pass 1) and hands nothing over now
             bool retry = false;
             if (guessed && searching) {
-                retry = admitted < k || !(R.d2[k - 1] * (1.0 + 0x1p-48) < (double) W.kb[src]);
+                // R.d2[k - 1] is the k-th smallest only behind a selection: a row that was not selected (min_number_neighbors above k, or the
+                // selection ablated) is searched again rather than trusted
+                const bool selected = row_needed && !(ablate & 2);
+                retry = admitted < k || !selected || !(R.d2[k - 1] * (1.0 + 0x1p-48) < (double) W.kb[src]);
                 if (retry && sub == 0) W.todo[src] = 2;
             }
             CTGN_TICK(4)

@@ -340,6 +340,12 @@ class GnSolver:
         self._n = int(m.value)
         return idx[:self._n].copy()
 
+    def last_upload_bytes(self) -> int:
+        """Host-to-device bytes of the last set_keypoints_sharded on this rank (ctgn_internal.h: measurement hook)."""
+        out = C.c_uint64()
+        L.check(self._h, L.lib().ctgn_last_upload_bytes(self._h, C.byref(out)))
+        return int(out.value)
+
     def set_rewind(self, on=True):
         """ctgn_set_rewind: later uploads keep a device copy of their world points for rewind()."""
         L.check(self._h, L.lib().ctgn_set_rewind(self._h, int(on)))

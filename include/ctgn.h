@@ -461,24 +461,10 @@ ctgn_status ctgn_get_debug(ctgn_handle h, int32_t *n_neighbors, double *normal, 
                            uint8_t *used, size_t n);
 /* Host copy of the packed system of the last accumulate/solve. */
 ctgn_status ctgn_get_system(ctgn_handle h, double out[CTGN_SYSTEM_DOUBLES]);
-/* Counting pass for the roofline: V = voxels probed per keypoint, total map points inside them, summed
- * over the resident keypoints at their current world positions. */
-ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *voxels_probed, uint64_t *voxels_hit,
-                               uint64_t *points_scanned);
 /* Bracket every accumulate launch with HIP events on the handle's stream (off by default). */
 ctgn_status ctgn_set_profiling(ctgn_handle h, int32_t enable);
 /* Average HIP-event time (ms) of the accumulate kernel over the launches that did work since the last reset. */
 ctgn_status ctgn_kernel_timing(ctgn_handle h, double *avg_accumulate_ms, int32_t *launches, int32_t reset);
-/* The same, split by what bounded the search: [0] = the first search of a solve (radius only: nothing carried over), [1] = every later
- * one (bounded by the previous search's k-th neighbour distance + the keypoint's displacement). */
-ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t launches[2], int32_t reset);
-/* Select the accumulate kernel: 0 = 16-lanes-per-keypoint + histogram-assisted selection (default),
- * 1 = lane-per-keypoint cross-check kernel, 2 = 16-lanes-per-keypoint with plain rank selection,
- * 3 = variant 0 instrumented with per-phase shader clocks (read through ct_icp_amd/csrc/ctgn_internal.h), 4 = variant 0 compiled for
- * 4 waves per SIMD instead of 3 (A/B hook), 5 = variant 0 with the shared-home-voxel path of the 27-voxel sweep compiled in
- * (the four keypoints of a round probe and stream one flattened neighbourhood; the default until round 2, now slower than the
- * bounded generic path — A/B hook). Same results for every variant. Test / measurement hook. */
-ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 /* Keypoint ordering of the GN kernels: -1 = automatic (default), 0 = never, 1 = always. When ordered, the kernels work through
  * the upload in home-voxel order (positions sorted once per upload on the device, the kernels iterate on a position-ordered
  * working copy): same per-keypoint results, the packed sums then run in position order (a different, still fixed, rounding).

@@ -1,0 +1,143 @@
+"""One config-E sequence through three loops, frame by frame, with where each departs from ground truth and from the others:
+
+  ref-cpu   the REFERENCE'S OWN ct_icp::Odometry::RegisterFrame (oracle/_ref/libctgn_ref_odometry.so: src/ct_icp/odometry.cpp compiled where it
+            lies) on its own MULTI_RESOLUTION_VOXEL_HASHMAP — AssessRegistration, insertion policy, the init regime, everything
+  ref-gpu   the same Odometry object code on GPU_VOXEL_HASHMAP (integration/gpu_map.h + the solver arms, libctgn.so underneath)
+  ctgn      ct_icp_amd.sequence_runner: one ctgn_frame call per frame (the product's own loop, what bench.py's config_e times)
+
+The sequences are SURVEY.md 8d's config E (config-B generator, seeds 10-20, KITTI lengths / scale). All three loops start from the identity
+(Odometry::InitializeMotion, odometry.cpp:276-300), so the vehicle pulls away from rest (`--ramp` frames) as a KITTI drive does.
+
+  python scripts/odometry_vs_reference.py --sequence 0 --frames 300 --solver GN --impl ref-cpu,ref-gpu,ctgn --out profiles/r05_config_e_seq0_vs_reference.json
+
+Test infrastructure (imports oracle/); nothing here is on the product path."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ct_icp_amd import se3, synthetic as syn  # noqa: E402
+from ct_icp_amd.sequence_runner import KITTI_LENGTHS  # noqa: E402
+
+
+def make_scans(sid: int, frames: int, ramp: int, azimuth_steps=None, scene_kind: str = "street", log=None):
+    seed = 10 + sid
+    scene = syn.config_e_scene(frames, seed) if hasattr(syn, "config_e_scene") and scene_kind == "config_e" else \
+        syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
+    dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps)
+    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=ramp)
+    scans = []
+    t0 = time.perf_counter()
+    for j in range(frames):
+        sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=1000 * seed + j, use_torch=True)
+        scans.append((sc.raw, sc.t, (0.1 * j, 0.1 * (j + 1))))
+        if log and j % 50 == 49:
+            log(f"  generated {j + 1}/{frames} scans ({time.perf_counter() - t0:.0f} s)")
+    return scans, knots
+
+
+def relative_truth(knots, j):
+    """Ground-truth begin|end pose of frame j expressed in the frame of the sensor at the start of frame 0 (the world of a loop that starts
+    from the identity)."""
+    g0 = syn.frame_pose14(knots, 0)
+    q0c = se3.quat_conj(g0[0:4])
+    g = syn.frame_pose14(knots, j)
+    out = np.zeros(14)
+    for o in (0, 7):
+        out[o:o + 4] = se3.quat_normalize(se3.quat_mul(q0c, g[o:o + 4]))
+        out[o + 4:o + 7] = se3.quat_rotate(q0c, g[o + 4:o + 7] - g0[4:7])
+    return out
+
+
+def run_reference(scans, map_kind, solver, extra):
+    from oracle import ref_odometry as ro
+    od = ro.RefOdometry(ro.GPU_MAP if map_kind == "gpu" else ro.CPU_MAP, solver=ro.GN if solver == "GN" else ro.CERES, **extra)
+    poses, rec = [], dict(success=[], residuals=[], keypoints=[], points_added=[], ms=[])
+    for raw, t, _ in scans:
+        r = od.register_frame(raw, t)
+        poses.append(r["pose"])
+        rec["success"].append(bool(r["success"]))
+        rec["residuals"].append(int(r["number_of_residuals"]))
+        rec["keypoints"].append(int(r["sample_size"]))
+        rec["points_added"].append(bool(r["points_added"]))
+        rec["ms"].append(float(r["milliseconds"]))
+    return np.array(poses), rec
+
+
+def run_ctgn(scans, solver, reference_regime: bool):
+    import ct_icp_amd as cia
+    from ct_icp_amd import sequence_runner as sr
+    kw = dict(solver=cia.GN if solver == "GN" else cia.CERES, voxel_size=0.5, sample_voxel_size=1.5, max_distance=100.0, init_poses=None, init_frames=1)
+    if reference_regime and "reference_regime" in sr.run_sequence.__code__.co_varnames:
+        kw["reference_regime"] = True
+    r = sr.run_sequence(scans, **kw)
+    return r["poses"], dict(success=[bool(v) for v in r["success"]], keypoints=[int(v) for v in r["keypoints"]],
+                            ms=[1e3 * r["seconds"] / max(1, r["frames"])] * r["frames"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sequence", type=int, default=0)
+    ap.add_argument("--scale", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=300, help="0 = the whole sequence")
+    ap.add_argument("--ramp", type=int, default=20)
+    ap.add_argument("--azimuth-steps", type=int, default=0, help="0 = the full HDL-64E pattern (133 k rays)")
+    ap.add_argument("--solver", default="GN")
+    ap.add_argument("--impl", default="ref-cpu")
+    ap.add_argument("--scene", default="config_e")
+    ap.add_argument("--set", action="append", default=[], help="key=value handed to the reference's OdometryOptions (repeatable)")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    log = lambda m: print(m, file=sys.stderr, flush=True)
+    length = max(3, int(round(KITTI_LENGTHS[args.sequence] / args.scale)))
+    frames = length if args.frames <= 0 else min(args.frames, length)
+    extra = {k: float(v) for k, v in (kv.split("=") for kv in args.set)}
+    log(f"sequence {args.sequence} (seed {10 + args.sequence}): {frames} of {length} frames")
+    scans, knots = make_scans(args.sequence, frames, args.ramp, args.azimuth_steps or None, args.scene, log)
+    truth = np.array([relative_truth(knots, j) for j in range(frames)])
+    result = dict(sequence=args.sequence, seed=10 + args.sequence, frames=frames, length=length, ramp_frames=args.ramp, scene=args.scene,
+                  points_per_frame=float(np.mean([len(s[1]) for s in scans])), options=extra, runs={})
+    poses = {}
+    for solver in args.solver.split(","):
+        for impl in args.impl.split(","):
+            t0 = time.perf_counter()
+            if impl in ("ref-cpu", "ref-gpu"):
+                p, rec = run_reference(scans, impl[4:], solver, extra)
+            else:
+                p, rec = run_ctgn(scans, solver, impl == "ctgn-ref-regime")
+            seconds = time.perf_counter() - t0
+            err = np.array([se3.pose_error(p[j], truth[j]) for j in range(frames)])
+            fails = [j for j, ok in enumerate(rec["success"]) if not ok]
+            key = f"{impl}:{solver}"
+            poses[key] = p
+            lost = next((j for j in range(frames) if err[j, 0] > 2.0), None)
+            result["runs"][key] = dict(seconds=seconds, failures=len(fails), first_failure=fails[0] if fails else None, failed_frames=fails[:50],
+                                       err_tr_max=float(err[:, 0].max()), err_tr_final=float(err[-1, 0]), err_rot_max=float(err[:, 1].max()),
+                                       first_frame_beyond_2m=lost, err_tr_every_10=[round(float(e), 4) for e in err[::10, 0]],
+                                       keypoints_mean=float(np.mean(rec["keypoints"][2:])) if frames > 2 else 0.0,
+                                       ms_per_frame_mean=float(np.mean(rec["ms"])))
+            log(f"{key}: {seconds:.1f} s, failures {len(fails)} (first {fails[0] if fails else None}), max |dt| {err[:, 0].max():.3f} m, "
+                f"final {err[-1, 0]:.3f} m, beyond 2 m at frame {lost}")
+    keys = list(poses)
+    result["between_runs"] = {}
+    for i in range(len(keys)):
+        for k in range(i + 1, len(keys)):
+            d = np.abs(poses[keys[i]] - poses[keys[k]]).max(axis=1)
+            first = next((j for j in range(frames) if d[j] > 1e-6), None)
+            result["between_runs"][f"{keys[i]} vs {keys[k]}"] = dict(max_abs_pose_difference=float(d.max()), first_frame_above_1e_6=first,
+                                                                      every_10=[float(f"{v:.2e}") for v in d[::10]])
+    line = json.dumps(result)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(line + "\n")
+    print(line)
+
+
+if __name__ == "__main__":
+    main()

@@ -61,3 +61,22 @@ def test_compact_line_survives_a_hostile_result():
     assert len(line) < 4096
     c = json.loads(line, parse_constant=_reject)
     assert c["value"] == d["value"] and c["roofline"].get("frac") is None and c["roofline"]["traffic"] is None
+
+
+def test_gpus_n_never_reports_another_n_with_exit_code_zero():
+    """Round 5: `python bench.py --gpus N` (N > 1) without a launcher starts its own N ranks; with fewer than N visible devices — here: none — it
+    prints ONE JSON error line and exits non-zero instead of quietly running the one-GPU workload as before. A launcher that started another number
+    of ranks than --gpus is refused the same way."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert r.returncode == 2, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+        d = json.loads(r.stdout.strip().splitlines()[-1], parse_constant=_reject)
+        assert "error" in d and d["n_gpus_requested"] == 8 and d["devices_visible"] == torch.cuda.device_count() and "value" not in d
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode == 2
+    d = json.loads(r.stdout.strip().splitlines()[-1], parse_constant=_reject)
+    assert "error" in d and "value" not in d

@@ -386,6 +386,40 @@ def test_pools_give_the_same_neighbours_as_searching_every_iteration(box_case, n
             assert np.array_equal(np.asarray(outs[0][2][key])[kept], np.asarray(outs[1][2][key])[kept]), key
 
 
+def test_split_pool_check_counters_survive_solves_that_stop_early(box_case):
+    """Round 5 (advisor): the split pool-check launches count failing positions in two alternating counters; a launch behind the stop test
+    returns before it zeroes the next one while the host keeps toggling the slot, so after a solve that converged early a stale count could
+    sit in the slot the next solve starts in. Each solve now starts from zeroed counters and slot 0. Here: on ONE handle, fused solves that stop
+    after a varying number of their enqueued launches (both parities of skipped split launches), each followed by a solve on FEWER keypoints;
+    every result must be the one a fresh handle without pools gives."""
+    om, gm = build_maps(box_case, 5, with_gpu=True)
+    sc, raw, t, pose0, world0 = _keypoints(box_case, 5, 0.3, perturb=(0.005, 0.03))
+    prior = _prior(box_case, 5)[0]
+
+    def fresh(n, o):
+        s = cia.GnSolver(gm)
+        s.set_pools(0)
+        s.set_keypoints(raw[:n], world0[:n], t[:n])
+        pose, summ, _ = s.solve(pose0, sc.t_begin_end, o, prior)
+        return pose, summ, s.world_points()
+
+    shared = cia.GnSolver(gm)
+    shared.set_pools(1)
+    shared.set_ablation(1 << 25)
+    stops = set()
+    for num_iters, thr in ((9, 1e-5), (10, 1e-5), (8, 3e-6), (9, 3e-6), (7, 1e-3), (12, 1e-7)):
+        o = _opts(num_iters_icp=num_iters, threshold_orientation_norm=thr)
+        for n in (len(t), len(t) // 3):
+            shared.set_keypoints(raw[:n], world0[:n], t[:n])
+            pose_s, summ_s, _ = shared.solve(pose0, sc.t_begin_end, o, prior)
+            pose_f, summ_f, w_f = fresh(n, o)
+            assert summ_s.success == summ_f.success and summ_s.num_iters == summ_f.num_iters and summ_s.num_residuals_used == summ_f.num_residuals_used
+            assert np.array_equal(pose_s, pose_f) and np.array_equal(shared.world_points(), w_f), (num_iters, thr, n)
+            if summ_s.num_iters >= 3:
+                stops.add((num_iters - summ_s.num_iters) % 2)
+    assert stops == {0, 1}, stops           # both parities of launches skipped behind the stop test were exercised
+
+
 # ------------------------------------------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def config_b_full():
@@ -1787,6 +1821,9 @@ def test_library_side_sharding_on_one_gpu(street_case):
     for rank in (0, 1):
         idx = s.set_keypoints_sharded(raw, world0, t, rank, 2)
         seen.append(idx)
+        # round 5: a rank uploads the scan's world points (the order every rank must agree on) + its own chunk of the seven arrays, not the scan
+        pad = lambda v: (v + 63) // 64 * 64
+        assert s.last_upload_bytes() == 8 * (3 * pad(len(t)) + 7 * pad(len(idx))) < 8 * 7 * len(t) * 0.95
         vox = np.trunc(world0[idx] / res).astype(np.int64)
         key = ((vox[:, 0] & 4095) << 20) | ((vox[:, 1] & 4095) << 8) | (vox[:, 2] & 255)
         assert np.all(np.diff(key) >= 0)                    # resident order = home-voxel order
@@ -1816,9 +1853,9 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     import json, os, subprocess, sys
     root = ROOT_DIR
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29563",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "0", "--clock-warm", "0", "--workload", "D",
-           "--d-sweeps", "1", "--d-radius", "45", "--no-pmc"]
+    # plain `python bench.py --gpus 2`: the script starts its own two ranks (round 5; the driver's N > 1 command line goes through the same code)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "0", "--clock-warm", "0",
+           "--workload", "D", "--d-sweeps", "1", "--d-radius", "45", "--no-pmc"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = r.stdout.strip().splitlines()           # (torch's gloo backend announces its ranks on stdout; the line the driver parses is the LAST one)
