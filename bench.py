@@ -679,7 +679,8 @@ def self_launch(n_gpus: int, backend: str, devices_visible: int) -> int:
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -733,7 +734,8 @@ def main():
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it starts its own ranks (one process per GPU over RCCL, exactly the
     # command the driver uses for N > 1); it never prints a line whose n_gpus differs from --gpus with exit code 0.
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # (a stray WORLD_SIZE=1 — e.g. left in the environment by a single-rank rendezvous earlier in the same process tree — is not a launcher)
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         raise SystemExit(self_launch(args.gpus, args.dist_backend, torch.cuda.device_count()))
 
     import ct_icp_amd as cia

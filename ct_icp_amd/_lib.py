@@ -180,6 +180,7 @@ SYMBOLS = {
     "ctgn_test_sort_pairs": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
     "ctgn_test_compact": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_last_upload_bytes": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "ctgn_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 

@@ -55,11 +55,60 @@ constexpr size_t PROF_WORDS = 16 + 4 * (size_t) MAX_PARTIAL_BLOCKS * ROW_WAVES;
 constexpr size_t KP_TAIL = 16 + (sizeof(GnState) + 7) / 8;
 static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState is mirrored by one thread block as doubles");
 
-// how many helpers: CTGN_HOST_THREADS (0 = none), else 3; never more than the CPUs this process may run on minus the caller's
+// ---------------------------------------------------------------------------------------- tuning table
+// The A/B switches of the measurement sessions in ONE place (round 5: they used to be 18 getenv calls scattered over this file). Process-wide,
+// like the function-local statics they replace; set through ctgn_set_tuning (ctgn_internal.h) or, for a session script that cannot call into
+// the library, ONE environment variable read once: CTGN_TUNING="key=value,key=value". Defaults = what the A/B sessions adopted. None of them
+// changes a result; the switches whose A/B is closed (hipGraph capture of the loop, 512-thread residual blocks, the 4-wave solve block, the
+// unfused frame call) are gone together with their code paths.
+struct Tuning {
+    double host_threads = 3;        // helper threads of the host-side staging loops (0 = none)
+    double order = -1;              // home-voxel ordering when ctgn_set_ordering left it automatic: -1 = cost model, 0 / 1 = never / always
+    double pool_min = 8192;         // neighbour pools from this many keypoints on (automatic mode)
+    double res_small = -1;          // 64-thread residual blocks: -1 = up to 8 192 keypoints, 0 / 1 = never / always
+    double res_grid_cap = 0;        // cap of the residual kernel's grid (0 = 3 blocks per CU)
+    double guess_factor = 1.25;     // guessed first-search bound: factor on r_k ...
+    double guess_maxfrac = 0.8;     // ... used when (factor r_k)^2 is below this fraction of the squared radius
+    double split = -1;              // pool check as its own kernel: -1 = from 400 k keypoints, 0 / 1 = never / always
+    double xcd_split = -1;          // one eighth of the tiles per XCD: -1 = incoherent ordered uploads only, 0 / 1
+    double fuse_small = -1;         // k_search_residual for small frames: 1 = on (its sums run in another fixed order)
+    double persistent = -1;         // overrides ctgn_set_persistent when >= 0
+    double persist_times = 0;       // per-block timeline of the persistent kernel -> ctgn_wave_timeline
+    double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
+    double frame_no_direct = 0;     // always stage page-locked scan arrays
+};
+static double *tuning_slot(Tuning &t, const std::string &key) {
+#define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
+    CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
+    CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
+    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct)
+#undef CTGN_TUNING_KEY
+    return nullptr;
+}
+static Tuning &tuning() {
+    static Tuning t = [] {
+        Tuning v;
+        if (const char *e = std::getenv("CTGN_TUNING")) {
+            std::string all(e);
+            size_t at = 0;
+            while (at < all.size()) {
+                const size_t end = std::min(all.find(',', at), all.size());
+                const std::string item = all.substr(at, end - at);
+                const size_t eq = item.find('=');
+                if (eq != std::string::npos)
+                    if (double *slot = tuning_slot(v, item.substr(0, eq))) *slot = std::atof(item.c_str() + eq + 1);
+                at = end + 1;
+            }
+        }
+        return v;
+    }();
+    return t;
+}
+
+// how many helpers: tuning().host_threads (0 = none, default 3); never more than the CPUs this process may run on minus the caller's
 static int host_helpers_wanted() {
     static const int n = [] {
-        const char *e = std::getenv("CTGN_HOST_THREADS");
-        int want = e ? std::atoi(e) : 3;
+        int want = (int) tuning().host_threads;
         cpu_set_t set;
         int cpus = 1;
         if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
@@ -475,7 +524,7 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
 // Never below 32 k keypoints. ctgn_set_ordering (or CTGN_ORDER=0 / 1 in the environment, for whole test-suite runs) forces it
 // off / on.
 bool want_order(ctgn_handle h, uint64_t level_points) {
-    static const int env_forced = [] { const char *e = std::getenv("CTGN_ORDER"); return e ? std::atoi(e) : -1; }();
+    const int env_forced = (int) tuning().order;
     const int forced = h->ordering_mode >= 0 ? h->ordering_mode : env_forced;
     if (forced >= 0) return forced != 0 && h->n_kp > 0;
     if (h->n_kp < 32768) return false;
@@ -535,7 +584,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.kth_valid = 0;
     // Pools pay where the search is throughput-bound: a pool check is an extra dependent phase in front of the searches that remain, and a
     // frame of a few thousand keypoints (a handful of waves per CU) is bound by exactly that chain (B1 / C: +3 % with pools, B2 -7 %, D -29 %).
-    static const int env_pool_min = [] { const char *e = std::getenv("CTGN_POOL_MIN"); return e ? std::atoi(e) : 8192; }();      // measurement hook
+    const int env_pool_min = (int) tuning().pool_min;
     v.pools = h->pool_mode >= 0 ? h->pool_mode : (h->n_kp >= env_pool_min ? 1 : 0);
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
@@ -596,24 +645,17 @@ int resident_blocks(ctgn_handle h, K kernel, int block, size_t smem) {
 // k_residual_reduce: 256-thread blocks for throughput, 64-thread blocks for small frames (the scattered gathers are bound by the
 // per-CU texture path, so a small frame wants MORE CUs, not fuller ones). Returns the grid = number of per-block partials.
 int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const DebugView &dv) {
-    static const int env_small = [] { const char *e = std::getenv("CTGN_RES_SMALL"); return e ? std::atoi(e) : -1; }();      // measurement hook
+    const int env_small = (int) tuning().res_small;
     const bool small = env_small >= 0 ? env_small != 0 : h->n_kp <= 8192;
     if (small) {
         const int grid = std::max(1, std::min((h->n_kp + 63) / 64, h->res_grid_cap));
         hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
         return grid;
     }
-    // 512-thread blocks halve the per-block records the solve kernel has to sum (a 132 k-keypoint sweep: 259 instead of 518).
-    static const int env_blk = [] { const char *e = std::getenv("CTGN_RES_BLOCK"); return e ? std::atoi(e) : 0; }();              // measurement hook
+    // (512-thread blocks would halve the per-block records the solve kernel sums — 259 instead of 518 on a 132 k-keypoint sweep — but 259
+    // blocks of 8 waves need a second round on 3 CUs at 3 waves per SIMD: the kernel lost 5 us where the solve kernel gained 3; removed)
     const int tiles256 = (h->n_kp + RES_BLOCK - 1) / RES_BLOCK;
-    // (measured, B2: 259 blocks of 512 need a second round on 3 CUs — one 8-wave block per CU at 3 waves per SIMD — and the kernel loses
-    // 5 us where the solve kernel gains 3: off unless asked for)
-    if (env_blk == 512) {
-        const int grid = std::max(1, std::min((h->n_kp + 511) / 512, h->res_grid_cap));
-        hipLaunchKernelGGL(k_residual_reduce<512>, dim3(grid), dim3(512), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
-        return grid;
-    }
-    static const int env_cap = [] { const char *e = std::getenv("CTGN_RES_GRID_CAP"); return e ? std::atoi(e) : 0; }();           // measurement hook
+    const int env_cap = (int) tuning().res_grid_cap;
     // no more blocks than are resident at once (3 per CU): a larger scan's blocks take several tiles each, and the solve kernel has 768
     // records to sum instead of 2 048 (config D: 0.6931 -> 0.6858 ms per iteration; 1 024: 0.6872, 1 536: 0.6885)
     const int grid = std::max(1, std::min(tiles256, env_cap > 0 ? env_cap : std::min(h->res_grid_cap, 3 * h->num_cus)));
@@ -662,7 +704,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     // (config D, step ms by factor: off 0.844 | 0.9: 0.936 | 1.05: 0.806 | 1.15: 0.766 | 1.3: 0.777 | 1.6: 0.796 | 2.0: 0.828;
     //  B2, first search ms: off 0.133 | 1.1: 0.127 | 1.2: 0.116 | 1.25: 0.112 | 1.4: 0.113)
     if (rows_ok && !kv.kth_valid && !(h->ablate & (1 << 24)) && h->variant != 1) {
-        static const double env_factor = [] { const char *e = std::getenv("CTGN_GUESS_FACTOR"); return e ? std::atof(e) : 1.25; }(); // measurement hook
+        const double env_factor = tuning().guess_factor;
         const bool forced = h->guess_factor > 0.0;            // ctgn_set_search_guess: a test forces guesses that mostly fail
         const double factor = h->guess_factor >= 0.0 ? h->guess_factor : env_factor;
         int map_id, nb_;
@@ -673,7 +715,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (factor > 0.0 && nvox > 0.0 && npts > 0.0) {
             const double ppv = npts / nvox;
             const double g = factor * mv.resolution * std::sqrt((double) h->prm.max_nb / (3.14159265358979323846 * ppv));
-            static const double env_frac = [] { const char *e = std::getenv("CTGN_GUESS_MAXFRAC"); return e ? std::atof(e) : 0.8; }();      // measurement hook
+            const double env_frac = tuning().guess_maxfrac;
             if (g * g < (forced ? 1.0 : env_frac) * mv.r2thr) kv.guess2 = (float) (g * g * (1.0 + 1e-6));
         }
     }
@@ -685,7 +727,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     // anyway, gains 2.6 % per step)
     constexpr int SPLIT_MIN_KEYPOINTS = 400000;
     constexpr int FUSE_SMALL_MAX = 4096;
-    static const int env_split = [] { const char *e = std::getenv("CTGN_SPLIT"); return e ? std::atoi(e) : -1; }();               // measurement hook
+    const int env_split = (int) tuning().split;
     const bool split = rows_ok && h->variant == 0 && kv.kth_valid && kv.pools && h->searches_in_solve >= 3 && kv.order == nullptr &&
                        h->prm.max_nb + 1 <= KMAX && (h->ablate & 0xffff) == 0 && (env_split >= 0 ? env_split != 0 : ((h->n_kp >= SPLIT_MIN_KEYPOINTS || (h->ablate & (1 << 25))) && !(h->ablate & (1 << 19))));
     if (search_only && (h->variant == 1 || !rows_ok))
@@ -702,7 +744,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
-            static const int env_xcd = [] { const char *e = std::getenv("CTGN_XCD_SPLIT"); return e ? std::atoi(e) : -1; }();     // measurement hook
+            const int env_xcd = (int) tuning().xcd_split;
             // one contiguous eighth of the tiles per XCD: +4 % on config D (uniformly spread keypoints), -50 % on a sweep whose density
             // varies along the sort key (the eighths then differ in work: B2 over the 270 MB map 0.145 -> 0.215 ms) -> incoherent uploads only
             kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : ((h->order_valid && !h->kp_coherent) || h->kp_presorted)) && g1 >= 64 ? 1 : 0;
@@ -719,7 +761,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         // B1 (1 024 keypoints, 27-voxel sweep) 0.0327 -> 0.0343 ms per iteration, C (1 500 keypoints, 125-voxel sweep) 0.0385 -> 0.0366 ms;
         // its packed sums run per wave and search block, a different (fixed) order than the residual kernel's, so switching it by size
         // would make poses depend on the path in the last bit. Not under per-launch profiling: the event pair brackets the SEARCH kernel.
-        static const int env_fuse = [] { const char *e = std::getenv("CTGN_FUSE_SMALL"); return e ? std::atoi(e) : -1; }();
+        const int env_fuse = (int) tuning().fuse_small;
         const bool fuse_small = !search_only && h->variant == 0 && h->n_kp <= FUSE_SMALL_MAX && !kv.pools && kv.order == nullptr && !h->profiling &&
                                 (h->ablate & 0xffff) == 0 && env_fuse == 1;
         if (fuse_small) {
@@ -806,7 +848,7 @@ ctgn_status flush_state_init(ctgn_handle h) {
 // Is this solve one for the persistent kernel? Small frames on the default row kernel, nothing that needs per-launch events, per-position
 // ordering or kernel variants; never after a barrier of it has timed out on this handle.
 bool persistent_ok(ctgn_handle h, const MapView &mv) {
-    static const int env = [] { const char *e = std::getenv("CTGN_PERSISTENT"); return e ? std::atoi(e) : -1; }();      // measurement hook: forces it on / off
+    const int env = (int) tuning().persistent;      // measurement hook: forces it on / off
     const int mode = env >= 0 ? env : h->persist_mode;
     if (mode != 1 || h->persist_disabled || h->n_kp < 1 || h->n_kp > 4096) return false;
     if (h->variant != 0 || h->profiling || h->ablate || h->ordering_mode == 1 || h->order_valid || h->kp_presorted) return false;
@@ -823,7 +865,7 @@ ctgn_status launch_persistent(ctgn_handle h, const MapView &mv, int iters, bool 
         ctgn_status os = order_keypoints(h, mv);
         if (os != CTGN_OK) return os;
     }
-    static const bool env_times = std::getenv("CTGN_PERSIST_TIMES") != nullptr;      // measurement hook: per-block timeline -> ctgn_wave_timeline
+    const bool env_times = tuning().persist_times != 0;      // measurement hook: per-block timeline -> ctgn_wave_timeline
     auto launch = [&](auto kernel, size_t smem) -> ctgn_status {
         static int per_cu_cached[2] = {0, 0};
         int &per_cu = per_cu_cached[mv.nb == 1 ? 0 : 1];
@@ -854,19 +896,14 @@ ctgn_status launch_persistent(ctgn_handle h, const MapView &mv, int iters, bool 
 }
 
 ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
-    // measurement hook (CTGN_SOLVE_SMALL=1): a 4-wave block for <= 128 partial columns. Slower on the B1 frame (0.0425 vs 0.0404 ms per
-    // iteration: the reduce is one trip to 96 freshly written lines, and four waves have a quarter of the loads in flight), so off.
-    static const int env_small = [] { const char *e = std::getenv("CTGN_SOLVE_SMALL"); return e ? std::atoi(e) : 0; }();
+    // (a 4-wave block for <= 128 partial columns was measured slower on the B1 frame — 0.0425 vs 0.0404 ms per iteration: the reduce is one
+    // trip to 96 freshly written lines, and four waves have a quarter of the loads in flight — and removed)
     {
         ctgn_status fs = flush_state_init(h);
         if (fs != CTGN_OK) return fs;
     }
-    if (env_small == 1 && h->last_grid <= 128)
-        hipLaunchKernelGGL(k_reduce_solve<256>, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state, h->prm, mode,
-                           CTGN_MIN_KEYPOINTS_USED);
-    else
-        hipLaunchKernelGGL(k_reduce_solve<SOLVE_BLOCK>, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
-                           h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
+    hipLaunchKernelGGL(k_reduce_solve<SOLVE_BLOCK>, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
+                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
     HIPCHK(h, hipGetLastError());
     return CTGN_OK;
 }
@@ -1633,14 +1670,9 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
     }
     MapView mv;
     st = make_map_view(h, -1.0, &mv);
-    // Measurement hook (CTGN_GRAPH=1): run the iteration loop as one hipGraph captured from the stream. Kept out of the default
-    // path: the loop is bound by the GPU-side latency of its dependent launches, not by host launch cost.
-    static const bool use_graph = std::getenv("CTGN_GRAPH") != nullptr;
-    const bool capture = use_graph && st == CTGN_OK && !h->profiling && h->variant != 3;
-    hipGraph_t graph = nullptr;
-    if (capture && hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
-        return fail(h, CTGN_ERR_HIP, "[HIP] hipStreamBeginCapture");
-    if (st == CTGN_OK && !capture && opts->num_iters_icp > 0 && persistent_ok(h, mv)) {
+    // (a hipGraph captured from this loop was measured in round 1 and dropped: the loop is bound by the GPU-side latency of its dependent
+    // launches, not by host launch cost — docs/history.md section 7)
+    if (st == CTGN_OK && opts->num_iters_icp > 0 && persistent_ok(h, mv)) {
         // a small frame (the reference's own keypoint count): state init, all iterations and the final re-transform in ONE launch
         const bool merged = h->prefetch_world && h->n_kp > 0;
         st = launch_persistent(h, mv, opts->num_iters_icp, true, merged ? h->d_kp + 7 * (size_t) h->kp_stride + 16 : nullptr);
@@ -1648,21 +1680,6 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
     for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {       // ct_icp.cpp:745
         st = launch_accumulate(h, mv, it == 0);
         if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
-    }
-    if (capture) {
-        hipGraphExec_t exec = nullptr;
-        const auto tg0 = std::chrono::steady_clock::now();
-        bool ok = hipStreamEndCapture(h->stream, &graph) == hipSuccess && graph &&
-                  hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        const auto tg1 = std::chrono::steady_clock::now();
-        ok = ok && hipGraphLaunch(exec, h->stream) == hipSuccess;
-        if (opts->debug_print > 1)
-            std::fprintf(stderr, "[ctgn] hipGraph: end-capture + instantiate %.1f us\n",
-                         std::chrono::duration<double, std::micro>(tg1 - tg0).count());
-        if (ok) hipStreamSynchronize(h->stream);
-        if (exec) hipGraphExecDestroy(exec);
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) st = fail(h, CTGN_ERR_HIP, "[HIP] graph capture / launch failed");
     }
     if (st != CTGN_OK) {
         h->gn_active = false;
@@ -1996,7 +2013,7 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     for (int i = 0; i < 14; ++i) h_in[i] = pose[i];
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
     const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
-    static const bool tp_timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;      // measurement hook: host-clock marks on stderr
+    const bool tp_timing = tuning().frame_timing != 0;      // measurement hook: host-clock marks on stderr
     const auto tp_t0 = std::chrono::steady_clock::now();
     auto tp_now = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp_t0).count(); };
     double tp_gather = 0;
@@ -2185,7 +2202,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_register takes host views (the stage entry points accept device memory)");
     const auto t_call = std::chrono::steady_clock::now();
     // CTGN_FRAME_TIMING=1: host-clock marks of the call's phases on stderr (measurement hook; no extra synchronisation)
-    static const bool timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;
+    const bool timing = tuning().frame_timing != 0;
     double marks[8] = {0};
     auto mark = [&](int k) { if (timing) marks[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
     auto &F = h->fr;
@@ -2215,8 +2232,8 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     std::vector<ChunkStat> stat(nchunks, ChunkStat{INFINITY, -INFINITY, false, false});
     // Page-locked caller arrays in the plain layout (x y z rows of doubles, timestamps as doubles, scan order) are not staged: the DMA
     // engine reads them where they lie and a kernel writes the x y z t records (a driver that fills such a buffer from its sensor
-    // packets saves the 4 MB staging copy of a 132 k-point scan). CTGN_FRAME_NO_DIRECT=1: always stage (measurement hook).
-    static const bool no_direct = std::getenv("CTGN_FRAME_NO_DIRECT") != nullptr;
+    // packets saves the 4 MB staging copy of a 132 k-point scan). tuning frame_no_direct = 1: always stage (measurement hook).
+    const bool no_direct = tuning().frame_no_direct != 0;
     const bool direct_in = n && !no_direct && !order && f64 && raw.stride_bytes == 3 * sizeof(double) &&
                            (fo->override_timestamps || (tf64 && ts.stride_bytes == sizeof(double))) && host_pinned(raw.base, n * 3 * sizeof(double)) &&
                            (fo->override_timestamps || host_pinned(ts.base, n * sizeof(double)));
@@ -2519,7 +2536,7 @@ ctgn_status ctgn_frame_update_map(ctgn_handle h, const double location[3], doubl
     auto &F = h->fr;
     h->kth_fresh = false;
     if (add_points && !F.valid) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no registered frame is resident (ctgn_frame_register)");
-    static const bool timing = std::getenv("CTGN_FRAME_TIMING") != nullptr;
+    const bool timing = tuning().frame_timing != 0;
     const auto t0 = std::chrono::steady_clock::now();
     for (auto &DL : h->devlevels) DMCHK(h, devmap_level_remove_far(DL, location, max_distance, h->stream));   // odometry.cpp:938-940
     const auto t1 = std::chrono::steady_clock::now();
@@ -2547,8 +2564,7 @@ ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, con
     if (!summary) summary = &local;
     if (h && h->update_mode != 1)
         return fail(h, CTGN_ERR_UNSUPPORTED, "the frame pipeline updates the device-resident map (ctgn_map_set_update_mode(h, 1))");
-    static const bool unfused = std::getenv("CTGN_FRAME_UNFUSED") != nullptr;        // measurement hook: the two calls one after the other, as until round 3
-    if (!robust && !unfused)       // GN route: the map update is enqueued inside, behind the undistortion (frame_register_impl)
+    if (!robust)                   // GN route: the map update is enqueued inside, behind the undistortion (frame_register_impl)
         return frame_register_impl(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, &max_distance);
     ctgn_status st = ctgn_frame_register(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary);
     if (st != CTGN_OK) return st;
@@ -2919,6 +2935,14 @@ ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, 
         return CTGN_ERR_INVALID_ARGUMENT;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DMCHK(h, devmap_test_sort(keys, n, key_bits, key_bytes, order_out, h->stream));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_set_tuning(const char *key, double value) {
+    if (!key) return CTGN_ERR_INVALID_ARGUMENT;
+    double *slot = tuning_slot(tuning(), key);
+    if (!slot) return CTGN_ERR_INVALID_ARGUMENT;
+    *slot = value;
     return CTGN_OK;
 }
 

@@ -63,6 +63,11 @@ ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t la
  * bounded generic path — A/B hook). Same results for every variant. Test / measurement hook. */
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 
+/* The A/B switches of the measurement sessions, one table (ctgn_api.hip, struct Tuning: host_threads, order, pool_min, res_small, res_grid_cap,
+ * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct). Process-wide; none of
+ * them changes a result. A session script that cannot call into the library sets CTGN_TUNING="key=value,key=value" instead (read once). */
+ctgn_status ctgn_set_tuning(const char *key, double value);
+
 /* Host-to-device bytes the last ctgn_set_keypoints_sharded call moved on this rank (host views): 56 B per keypoint of the scan with one rank,
  * 24 B per keypoint of the scan (world points, for the order every rank must agree on) + 56 B per keypoint of the rank's chunk otherwise. */
 ctgn_status ctgn_last_upload_bytes(ctgn_handle h, uint64_t *bytes);

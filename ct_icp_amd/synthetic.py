@@ -340,11 +340,16 @@ def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps:
 # Trajectory: frame k spans [k*dt, (k+1)*dt]; end pose of frame k == begin pose of frame k+1
 # --------------------------------------------------------------------------------------------------
 def driving_trajectory(num_frames: int, dt: float = 0.1, speed: float = 10.0, yaw_rate: float = 0.1,
-                       height: float = 1.73, jitter: float = 0.0, seed: int = 0, start_x: float = 0.0, ramp_frames: int = 0):
+                       height: float = 1.73, jitter: float = 0.0, seed: int = 0, start_x: float = 0.0, ramp_frames: int = 0,
+                       centered: bool = False):
     """Knot poses (num_frames+1, 7) of a constant-speed, constant-yaw-rate vehicle; optional roll/pitch jitter
     (config C). Yaw oscillates so the vehicle stays inside the street. `ramp_frames` > 0: the vehicle pulls away from rest, its speed
     rising linearly to `speed` over that many frames (a recording that starts with the car standing, as the KITTI drives do: an
-    odometry that starts from the identity — Odometry::InitializeMotion, odometry.cpp:276-300 — has no velocity to extrapolate yet)."""
+    odometry that starts from the identity — Odometry::InitializeMotion, odometry.cpp:276-300 — has no velocity to extrapolate yet).
+    `centered`: the yaw is A sin(2 pi k / 40) in closed form, zero mean, so the vehicle weaves +-0.4 m about the centre line however long the
+    drive. The default accumulates yaw_rate dt cos(2 pi k / 40), whose running sum oscillates about +0.5 terms: a mean heading of 0.005 rad,
+    0.5 m of lateral drift per 100 m — short workloads never notice, but a 450-frame drive ends up in the row of parked cars at y = 2-4 m
+    (found in round 5: this, not the street's geometry, is what lost config E's three longest sequences between frames 260 and 350)."""
     rng = np.random.default_rng(seed)
     poses = np.zeros((num_frames + 1, 7))
     x, y, yaw = start_x, 0.0, 0.0
@@ -357,7 +362,10 @@ def driving_trajectory(num_frames: int, dt: float = 0.1, speed: float = 10.0, ya
         v = speed * min(1.0, (k + 0.5) / ramp_frames) if ramp_frames > 0 else speed
         x += v * dt * np.cos(yaw)
         y += v * dt * np.sin(yaw)
-        yaw += yaw_rate * dt * np.cos(2 * np.pi * k / 40.0)
+        if centered:
+            yaw = yaw_rate * dt * (40.0 / (2 * np.pi)) * np.sin(2 * np.pi * (k + 1) / 40.0)
+        else:
+            yaw += yaw_rate * dt * np.cos(2 * np.pi * k / 40.0)
     return poses
 
 

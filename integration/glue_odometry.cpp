@@ -7,7 +7,7 @@
 //   map_kind 1: GpuVoxelMap::Options                 (`map_type: GPU_VOXEL_HASHMAP`, integration/gpu_map.h; Register reaches libctgn.so through
 //                                                     the one-line arms of integration/gn_gpu_arm.h, every map call through ISlamMap)
 // Nothing of Odometry is restated here: the functions below fill an OdometryOptions, construct ct_icp::Odometry and call RegisterFrame.
-// extern "C" so that the tests can feed both instances the same scans from Python (tests/test_odometry_glue.py, scripts/odometry_vs_reference.py);
+// extern "C" so that the tests can feed both instances the same scans from Python (tests/test_odometry_glue.py, tests/odometry_vs_reference.py);
 // linked into oracle/_ref/libctgn_ref_odometry.so by oracle/Makefile (target `odometry`) with the reference's sources + libctgn.so.
 // TEST INFRASTRUCTURE: third-party arithmetic underneath the reference is oracle/shims/ (see oracle/shims/mini_eigen.h).
 #include <chrono>

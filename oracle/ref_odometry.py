@@ -5,7 +5,7 @@ the reference's own factory call (odometry.cpp:700):
     RefOdometry(map_kind=CPU_MAP)   MULTI_RESOLUTION_VOXEL_HASHMAP: the reference's map and its CPU solver loops
     RefOdometry(map_kind=GPU_MAP)   GPU_VOXEL_HASHMAP: integration/gpu_map.h over libctgn.so, Register through the arms of integration/gn_gpu_arm.h
 
-TEST INFRASTRUCTURE ONLY (tests/, scripts/odometry_vs_reference.py, bench.py's cpu_baseline leg); nothing under ct_icp_amd/ imports it.
+TEST INFRASTRUCTURE ONLY (tests/, tests/odometry_vs_reference.py, bench.py's cpu_baseline leg); nothing under ct_icp_amd/ imports it.
 The library is built in the CPU container and travels to the GPU box as a built file. Third-party arithmetic underneath the reference
 (Eigen, Ceres, tsl::robin_map, glog) is oracle/shims/ — on BOTH map kinds, so the comparison isolates exactly the drop-in.
 """

@@ -8,9 +8,9 @@
 The sequences are SURVEY.md 8d's config E (config-B generator, seeds 10-20, KITTI lengths / scale). All three loops start from the identity
 (Odometry::InitializeMotion, odometry.cpp:276-300), so the vehicle pulls away from rest (`--ramp` frames) as a KITTI drive does.
 
-  python scripts/odometry_vs_reference.py --sequence 0 --frames 300 --solver GN --impl ref-cpu,ref-gpu,ctgn --out profiles/r05_config_e_seq0_vs_reference.json
+  python tests/odometry_vs_reference.py --sequence 0 --frames 300 --solver GN --impl ref-cpu,ref-gpu,ctgn --out profiles/r05_config_e_seq0_vs_reference.json
 
-Test infrastructure (imports oracle/); nothing here is on the product path."""
+Test infrastructure: lives under tests/ because it drives oracle/_ref (only tests/, smoke() and bench.py's cpu_baseline leg may); not collected by pytest."""
 import argparse
 import json
 import os
@@ -26,12 +26,12 @@ from ct_icp_amd import se3, synthetic as syn  # noqa: E402
 from ct_icp_amd.sequence_runner import KITTI_LENGTHS  # noqa: E402
 
 
-def make_scans(sid: int, frames: int, ramp: int, azimuth_steps=None, scene_kind: str = "street", log=None):
+def make_scans(sid: int, frames: int, ramp: int, azimuth_steps=None, scene_kind: str = "street", log=None, centered: bool = True):
     seed = 10 + sid
     scene = syn.config_e_scene(frames, seed) if hasattr(syn, "config_e_scene") and scene_kind == "config_e" else \
         syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
     dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps)
-    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=ramp)
+    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=ramp, centered=centered)
     scans = []
     t0 = time.perf_counter()
     for j in range(frames):
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--impl", default="ref-cpu")
     ap.add_argument("--scene", default="config_e")
     ap.add_argument("--set", action="append", default=[], help="key=value handed to the reference's OdometryOptions (repeatable)")
+    ap.add_argument("--uncentered", action="store_true", help="the trajectory of rounds 1-4 (mean heading 0.005 rad: drifts into the parked cars)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     log = lambda m: print(m, file=sys.stderr, flush=True)
@@ -99,9 +100,9 @@ def main():
     frames = length if args.frames <= 0 else min(args.frames, length)
     extra = {k: float(v) for k, v in (kv.split("=") for kv in args.set)}
     log(f"sequence {args.sequence} (seed {10 + args.sequence}): {frames} of {length} frames")
-    scans, knots = make_scans(args.sequence, frames, args.ramp, args.azimuth_steps or None, args.scene, log)
+    scans, knots = make_scans(args.sequence, frames, args.ramp, args.azimuth_steps or None, args.scene, log, centered=not args.uncentered)
     truth = np.array([relative_truth(knots, j) for j in range(frames)])
-    result = dict(sequence=args.sequence, seed=10 + args.sequence, frames=frames, length=length, ramp_frames=args.ramp, scene=args.scene,
+    result = dict(sequence=args.sequence, seed=10 + args.sequence, frames=frames, length=length, ramp_frames=args.ramp, scene=args.scene, centered=not args.uncentered,
                   points_per_frame=float(np.mean([len(s[1]) for s in scans])), options=extra, runs={})
     poses = {}
     for solver in args.solver.split(","):

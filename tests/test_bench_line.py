@@ -76,7 +76,7 @@ def test_gpus_n_never_reports_another_n_with_exit_code_zero():
         d = json.loads(r.stdout.strip().splitlines()[-1], parse_constant=_reject)
         assert "error" in d and d["n_gpus_requested"] == 8 and d["devices_visible"] == torch.cuda.device_count() and "value" not in d
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
-                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)          # a launcher with another rank count
     assert r.returncode == 2
     d = json.loads(r.stdout.strip().splitlines()[-1], parse_constant=_reject)
     assert "error" in d and "value" not in d

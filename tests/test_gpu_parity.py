@@ -407,7 +407,12 @@ def test_split_pool_check_counters_survive_solves_that_stop_early(box_case):
     shared.set_pools(1)
     shared.set_ablation(1 << 25)
     stops = set()
-    for num_iters, thr in ((9, 1e-5), (10, 1e-5), (8, 3e-6), (9, 3e-6), (7, 1e-3), (12, 1e-7)):
+    for thr in (3e-5, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2):                                                     # a threshold the solve meets after 3 .. 10 iterations
+        stop_at = fresh(len(t), _opts(num_iters_icp=14, threshold_orientation_norm=thr))[1].num_iters  # where this solve's stop test fires
+        if 3 <= stop_at <= 10:
+            break
+    assert 3 <= stop_at <= 10, stop_at                                                                   # late enough for split launches to have run
+    for num_iters in (stop_at + 1, stop_at + 2, stop_at + 3, stop_at + 4):                               # 1 .. 4 launches skipped behind the stop
         o = _opts(num_iters_icp=num_iters, threshold_orientation_norm=thr)
         for n in (len(t), len(t) // 3):
             shared.set_keypoints(raw[:n], world0[:n], t[:n])
@@ -415,7 +420,7 @@ def test_split_pool_check_counters_survive_solves_that_stop_early(box_case):
             pose_f, summ_f, w_f = fresh(n, o)
             assert summ_s.success == summ_f.success and summ_s.num_iters == summ_f.num_iters and summ_s.num_residuals_used == summ_f.num_residuals_used
             assert np.array_equal(pose_s, pose_f) and np.array_equal(shared.world_points(), w_f), (num_iters, thr, n)
-            if summ_s.num_iters >= 3:
+            if summ_s.num_iters >= 3 and summ_s.num_iters < num_iters:
                 stops.add((num_iters - summ_s.num_iters) % 2)
     assert stops == {0, 1}, stops           # both parities of launches skipped behind the stop test were exercised
 
