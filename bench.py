@@ -715,10 +715,10 @@ def main():
                                                     "rocprofv3 passes each; default D — the configuration whose map exceeds the caches; 'C,D' for both)")
     ap.add_argument("--no-extras", action="store_true", help="skip frames/s, robust route, frame stages")
     ap.add_argument("--detail-stdout", action="store_true", help="also print the full detail object as an EARLIER stdout line (default: files only)")
-    ap.add_argument("--config-e-scale", type=int, default=100,
+    ap.add_argument("--config-e-scale", type=int, default=10,
                     help="config E (BASELINE.json configs[4]) on this one GPU inside the default line: 11 sequences, seeds 10-20, KITTI lengths / "
-                         "this (100 = 233 frames, ~20 s with scan generation; 10 = the size SURVEY.md 8d defines: scripts/sequence_run.py "
-                         "--config-e, profiles/r04_config_e_n1.json); 0 = skip")
+                         "this (10 = the size SURVEY.md 8d defines: 2 319 frames, ~1.7 s of loop + ~30 s of scan generation on the GPU, "
+                         "profiles/r05_config_e_n1.json; 100 = 233 frames for a quick look); 0 = skip")
     ap.add_argument("--clock-warm", type=int, default=CLOCK_WARM)
     ap.add_argument("--inner", action="store_true", help="the run the PMC passes profile: timed loop only, no extras")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],

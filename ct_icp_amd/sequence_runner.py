@@ -55,10 +55,13 @@ def constant_velocity_guess(prev_pose14: np.ndarray, prev_prev_pose14: np.ndarra
 def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sample_voxel_size: float = 1.5,
                  max_distance: float = 100.0, init_poses=None, init_frames: int = 1, options: CTICPOptions = None,
                  use_motion_model: bool = None, resolutions=((0.8, 0.1, 30),), default_radius: float = 0.75, frame_period: float = 0.1,
-                 orders=None):
+                 orders=None, init_num_frames: int = 20, init_voxel_size: float = 0.2, init_sample_voxel_size: float = 1.0, init_num_iters: int = 15):
     """scans: iterable of (raw (N, 3), t (N,), (t_begin, t_end)). The first `init_frames` frames enter the map with `init_poses[j]`
     (ground truth / identity) and no registration; every later frame is registered from the constant-velocity guess and inserted if
-    the registration succeeded. Returns dict(poses (F, 14), success (F,), seconds, frames, keypoints, sampled, map_points)."""
+    the registration succeeded. Without `init_poses` the sequence starts from the identity like the reference's Odometry, and the first
+    `init_num_frames` frames run its start-up regime (odometry.cpp:340-342, 533-534, 552-556: a 0.2 m frame grid and a 1.0 m keypoint grid
+    instead of 0.5 / 1.5 m, at least 15 ICP iterations) — one frame sampled at 0.5 m leaves 2-4 points per 0.8 m map voxel, too few for any
+    20-point neighbourhood. Returns dict(poses (F, 14), success (F,), seconds, frames, keypoints, sampled, map_points)."""
     gm = GpuVoxelMap(GpuVoxelMapOptions(resolutions=[ResolutionParam(*r) for r in resolutions], default_radius=default_radius,
                                         device=device, device_updates=True))
     fp = FramePipeline(gm, frame_voxel_size=voxel_size, sample_voxel_size=sample_voxel_size)
@@ -75,8 +78,14 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
     poses, success, n_kp, n_sampled = [], [], [], []
     prev, prev2 = None, None
     t_start = time.perf_counter()
+    import copy
+    startup_options = copy.copy(options)
+    startup_options.num_iters_icp = max(options.num_iters_icp, init_num_iters)
     for j, (raw, t, tbe) in enumerate(scans):
         order = None if orders is None else orders[j]
+        startup = init_poses is None and j < init_num_frames
+        fp.frame_voxel_size = init_voxel_size if startup else voxel_size
+        fp.sample_voxel_size = init_sample_voxel_size if startup else sample_voxel_size
         # the first two registered frames carry the frame's end timestamp on every point: "no elastic ICP for first frame because no
         # initialization of ego-motion" (odometry.cpp:354-359) — unless the caller supplies their begin / end poses (a bootstrap from
         # ground truth, which the reference does not have): those frames are then inserted undistorted with the poses given
@@ -90,7 +99,7 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
             use_prev2 = j >= 2 and (init_poses is None or j >= init_frames + 1)
             guess = constant_velocity_guess(prev, prev2 if use_prev2 else None, third_frame=(j == 2))
             mm.previous_frame = TrajectoryFrame.from_pose14(prev, tbe[0] - frame_period, tbe[0])
-            r = fp.frame(raw, t, guess, tbe, options, max_distance, motion_model=mm if use_motion_model else None, order=order,
+            r = fp.frame(raw, t, guess, tbe, startup_options if startup else options, max_distance, motion_model=mm if use_motion_model else None, order=order,
                          override_timestamp=override, want_all=False)
         poses.append(r["pose"])
         success.append(bool(r["summary"].success))

@@ -315,7 +315,9 @@ def box_scene(half: float = 10.0, n_spheres: int = 4, seed: int = 20240901) -> S
 # --------------------------------------------------------------------------------------------------
 # Sensors: unit directions in the sensor frame + relative firing time in [0, 1)
 # --------------------------------------------------------------------------------------------------
-def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps: int = 1):
+def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps: int = 1, azimuth_offset: float = 0.0):
+    """Beam directions (sensor frame, x forward) and relative firing time of one sweep. `azimuth_offset`: azimuth of the sweep's first column;
+    0 = the sweep starts and ends looking straight ahead (rounds 1-4), pi = it starts and ends at the REAR, as a KITTI Velodyne scan does."""
     if kind == "hdl64":          # HDL-64E: +2 .. -24.8 deg, ~0.17 deg azimuth -> ~133 k returns
         elev = np.radians(np.linspace(2.0, -24.8, 64))
         az_steps = azimuth_steps or 2083
@@ -329,7 +331,7 @@ def lidar_pattern(kind: str = "hdl64", azimuth_steps: int | None = None, sweeps:
         raise ValueError(kind)
     cols = az_steps * sweeps
     # sub-sweeps are offset by a fraction of a column so accumulated scans are denser, not duplicated
-    az = (np.arange(cols) % az_steps + (np.arange(cols) // az_steps) / max(sweeps, 1)) * (2 * np.pi / az_steps)
+    az = (np.arange(cols) % az_steps + (np.arange(cols) // az_steps) / max(sweeps, 1)) * (2 * np.pi / az_steps) + azimuth_offset
     rel_t = np.arange(cols) / cols
     ce, se_ = np.cos(elev), np.sin(elev)
     dirs = np.stack([np.outer(np.cos(az), ce), np.outer(np.sin(az), ce), np.outer(np.ones_like(az), se_)], axis=-1)

@@ -226,9 +226,13 @@ def config_e_sequences(scale: int = 10, azimuth_steps: int = None):
 
     def maker(sid):
         frames, seed = lengths[sid], 10 + sid
+        # Round 5: the sweep starts and ends at the REAR of the vehicle, as a KITTI Velodyne scan does, and the weave about the centre line has
+        # zero mean. Rounds 1-4 cut the sweep straight ahead and let the heading average 0.005 rad: the first feeds a roll twist between a
+        # frame's begin and end pose back through the map (the reference's own Odometry loses such a sequence after ~250 frames,
+        # profiles/r05_config_e_seq0_vs_reference.json), the second drove the 400-frame sequences into the row of parked cars.
         scene = syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
-        dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps)
-        knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0)
+        dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps, azimuth_offset=np.pi)
+        knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, centered=True)
         scans = []
         for j in range(frames):
             sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=1000 * seed + j,

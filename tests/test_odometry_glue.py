@@ -24,8 +24,8 @@ def street_sequence(frames: int, azimuth_steps: int, seed: int = 10, ramp_frames
     """Config-B generator: HDL-64E pattern over the procedural street; the vehicle pulls away from rest, because the
     reference's odometry starts from the identity with nothing to extrapolate (odometry.cpp:276-300)."""
     scene = syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
-    dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps)
-    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=ramp_frames)
+    dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_steps=azimuth_steps, azimuth_offset=np.pi)     # the sweep starts / ends at the rear, as KITTI's does
+    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=ramp_frames, centered=True)
     scans = []
     for j in range(frames):
         sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=1000 * seed + j,
