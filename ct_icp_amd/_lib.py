@@ -181,6 +181,8 @@ SYMBOLS = {
     "ctgn_test_compact": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
     "ctgn_last_upload_bytes": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "ctgn_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
+    "ctgn_path_counters": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "ctgn_measure_hbm": (C.c_int, [_H, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
@@ -205,6 +207,8 @@ def lib() -> C.CDLL:
                 pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("CTGN_LIB_PATH") and not hasattr(L, name):
+                continue               # an older build under A/B (the override only): hooks it predates stay unbound
             fn = getattr(L, name)      # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

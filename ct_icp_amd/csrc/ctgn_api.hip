@@ -76,12 +76,15 @@ struct Tuning {
     double persist_times = 0;       // per-block timeline of the persistent kernel -> ctgn_wave_timeline
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
+    double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = automatic (launch_accumulate), else that many
+    double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 64 blocks on), 0 / 1 = never / always
 };
 static double *tuning_slot(Tuning &t, const std::string &key) {
 #define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
     CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct)
+    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce)
 #undef CTGN_TUNING_KEY
     return nullptr;
 }
@@ -187,11 +190,16 @@ struct ctgn_context {
     bool kth_fresh = false;             // the k-th distances on the device were written by the previous search of this solve
     int searches_in_solve = 0;          // neighbour searches launched since the solve began (the first one has no carried-over bound)
     int last_grid = 0;
+    uint64_t path_counts[2] = {0, 0};   // ctgn_path_counters: residual launches with per-XCD pre-sums | the last solve launch summed group records (0 / 1)
+    XcdReduce xr_last{nullptr, nullptr, 0u};   // what the last residual launch was given (ctl == nullptr: per-block records only): the solve launch behind it gets the same
+    unsigned int xr_epoch = 0;          // launch number of the per-XCD pre-sums (never 0 on the device)
     double guess_factor = -1.0;         // ctgn_set_search_guess: < 0 automatic, 0 off, > 0 forced factor on r_k (launch_accumulate)
     int normals_mode = 0;               // ctgn_set_normals: 0 library default (hybrid), 1 exact, 2 hybrid, 3 fast
     int fail_slot = 0;                  // which of the two fail-list counters the next split launch counts in (the other one is zeroed by it)
     uint64_t last_upload_bytes = 0;     // host-to-device bytes of the last ctgn_set_keypoints_sharded call on this rank (bench detail)
     int rb_split_search[2] = {0, 0};    // resident blocks of the split path's search launch (27- / 125-voxel instantiation)
+    int rb_rows[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of k_accumulate_rows by (sweep, variant)
+    int rb_check = 0, rb_fused[2] = {0, 0}, per_cu_persist[2] = {0, 0};   // the other occupancy queries, cached per handle (= per device) too
     bool fail_reset_pending = true;     // a new solve began: its first split launch zeroes both counters and starts from slot 0 (a solve that
                                         // stops early leaves the slot its last EXECUTED launch counted in non-zero: the launches behind the stop
                                         // test return before they zero anything, while the host keeps toggling the slot)
@@ -360,7 +368,16 @@ bool host_pinned(const void *p, size_t bytes) {
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void) hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     };
-    return pinned(p) && pinned(static_cast<const char *>(p) + bytes - 1);
+    const void *last = static_cast<const char *>(p) + bytes - 1;
+    if (!(pinned(p) && pinned(last))) return false;
+    // both ends page-locked is not yet "the whole range": two separate page-locked allocations with pageable memory between them would
+    // pass. Where the runtime can name the allocation an address belongs to, both ends must name the same one.
+    hipDeviceptr_t b0 = nullptr, b1 = nullptr;
+    size_t s0 = 0, s1 = 0;
+    const bool k0 = hipMemGetAddressRange(&b0, &s0, const_cast<void *>(p)) == hipSuccess;
+    const bool k1 = hipMemGetAddressRange(&b1, &s1, const_cast<void *>(last)) == hipSuccess;
+    if (!(k0 && k1)) { (void) hipGetLastError(); return k0 == k1; }      // not answerable for this kind of memory (both ends alike): the two-ends test stands
+    return b0 == b1 && s0 == s1;
 }
 
 inline int grid_for(size_t n) { return (int) std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 4096)); }
@@ -588,7 +605,7 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.pools = h->pool_mode >= 0 ? h->pool_mode : (h->n_kp >= env_pool_min ? 1 : 0);
     v.n = h->n_kp;
     v.order = (h->order_valid && !sorted) ? h->ord.order : nullptr;
-    v.chunk = 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
+    v.chunk = tuning().tile_chunk > 0 ? std::min((int) tuning().tile_chunk, 16) : 1;     // consecutive rounds per chunk, ordered B2 at sustained clocks: 1 / 2 / 3 -> 0.965 / 0.952 / 0.923 of the accounting    // measured on B2 (ordered): chunk 1 / 2 / 4 -> 0.81 / 0.83 / 0.76 of the accounting
     v.xcd_split = 0;                    // set per launch (needs the grid size)
     v.clk_iter_start = nullptr;         // set by launch_accumulate for the launch that opens an iteration
     v.fail_list = h->d_res + (size_t) h->cap_kp * (SEL_STRIDE + 3);
@@ -649,7 +666,8 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
     const bool small = env_small >= 0 ? env_small != 0 : h->n_kp <= 8192;
     if (small) {
         const int grid = std::max(1, std::min((h->n_kp + 63) / 64, h->res_grid_cap));
-        hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate);
+        h->xr_last = XcdReduce{nullptr, nullptr, 0u};
+        hipLaunchKernelGGL(k_residual_reduce<64>, dim3(grid), dim3(64), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv, h->ablate, h->xr_last);
         return grid;
     }
     // (512-thread blocks would halve the per-block records the solve kernel sums — 259 instead of 518 on a 132 k-keypoint sweep — but 259
@@ -659,8 +677,20 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
     // no more blocks than are resident at once (3 per CU): a larger scan's blocks take several tiles each, and the solve kernel has 768
     // records to sum instead of 2 048 (config D: 0.6931 -> 0.6858 ms per iteration; 1 024: 0.6872, 1 536: 0.6885)
     const int grid = std::max(1, std::min(tiles256, env_cap > 0 ? env_cap : std::min(h->res_grid_cap, 3 * h->num_cus)));
+    // per-XCD pre-sums of the block records (XcdReduce, ctgn_kernels.hpp) once there are enough records for the solve kernel's own
+    // reduction to show: B2 (518 records) solve kernel 13.5 -> ?? us
+    const int env_xr = (int) tuning().xcd_reduce;
+    const bool xr_on = env_xr >= 0 ? (env_xr != 0 && grid >= XCD_GROUPS) : grid >= 4 * XCD_GROUPS;
+    if (xr_on) {
+        if (++h->xr_epoch == 0u) h->xr_epoch = 1u;
+        h->path_counts[0]++;
+        double *rec = h->d_partials + (size_t) MAX_PARTIAL_BLOCKS * SYS_N;
+        h->xr_last = XcdReduce{reinterpret_cast<unsigned int *>(rec + XCD_GROUPS * SYS_N), rec, h->xr_epoch};
+    } else {
+        h->xr_last = XcdReduce{nullptr, nullptr, 0u};
+    }
     hipLaunchKernelGGL(k_residual_reduce<RES_BLOCK>, dim3(grid), dim3(RES_BLOCK), 0, h->stream, mv, kv, h->d_state, h->prm, h->d_partials, dv,
-                       h->ablate);
+                       h->ablate, h->xr_last);
     return grid;
 }
 
@@ -676,6 +706,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (os != CTGN_OK) return os;
     }
     KpView kv = kp_view(h, !search_only);
+    h->xr_last = XcdReduce{nullptr, nullptr, 0u};      // set again by launch_residual when the block records get per-XCD pre-sums
     if (!search_only) kv.clk_iter_start = &h->d_state->clk_iter_start;
     // the previous search's k-th distances bound this one — only inside one solve (same keypoints, same map, world points untouched)
     kv.kth_valid = (!first_iter && h->searches_in_solve > 0 && h->kth_fresh) ? 1 : 0;
@@ -740,7 +771,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
     } else {
         // one instantiation per (sweep half-width, selection flavour, instrumentation, waves per SIMD)
         auto launch = [&](auto kernel, size_t smem, unsigned long long *prof) {
-            const int rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
+            int &rb = h->rb_rows[(mv.nb == 1 ? 0 : 8) + (h->variant & 7)];        // one occupancy query per handle and instantiation (it used to run on every launch)
+            if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
             const int g1 = std::max(1, std::min((ntiles + ROW_WAVES - 1) / ROW_WAVES, rb));
@@ -766,8 +798,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                                 (h->ablate & 0xffff) == 0 && env_fuse == 1;
         if (fuse_small) {
             auto go = [&](auto kernel, size_t smem) {
-                static int rb_cached[2] = {0, 0};
-                int &rb = rb_cached[mv.nb == 1 ? 0 : 1];
+                int &rb = h->rb_fused[mv.nb == 1 ? 0 : 1];
                 if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
                 const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
                 const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
@@ -780,7 +811,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             if (ev) (void) hipEventRecord(ev->stop, h->stream);
             ev = nullptr;
         } else if (split) {
-            static int rb_check = 0;
+            int &rb_check = h->rb_check;
             if (rb_check == 0) rb_check = std::min(resident_blocks(h, k_pool_check<true, CHECK_WPS>, ROW_BLOCK, sizeof(CheckScratch) * ROW_WAVES), 4 * MAX_PARTIAL_BLOCKS);
             const int rounds_c = pick_rounds(h->n_kp, rb_check * ROW_WAVES);
             const int ntiles_c = (h->n_kp + 4 * rounds_c - 1) / (4 * rounds_c);
@@ -867,8 +898,7 @@ ctgn_status launch_persistent(ctgn_handle h, const MapView &mv, int iters, bool 
     }
     const bool env_times = tuning().persist_times != 0;      // measurement hook: per-block timeline -> ctgn_wave_timeline
     auto launch = [&](auto kernel, size_t smem) -> ctgn_status {
-        static int per_cu_cached[2] = {0, 0};
-        int &per_cu = per_cu_cached[mv.nb == 1 ? 0 : 1];
+        int &per_cu = h->per_cu_persist[mv.nb == 1 ? 0 : 1];
         if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, ROW_BLOCK, smem) != hipSuccess || per_cu < 1)) per_cu = 1;
         const int mmax = std::min(per_cu * std::max(1, h->num_cus / 8), MAX_PARTIAL_BLOCKS);       // co-resident blocks on one XCD
         int rounds = 1;
@@ -903,7 +933,7 @@ ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
         if (fs != CTGN_OK) return fs;
     }
     hipLaunchKernelGGL(k_reduce_solve<SOLVE_BLOCK>, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
-                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED);
+                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED, h->xr_last);
     HIPCHK(h, hipGetLastError());
     return CTGN_OK;
 }
@@ -1009,7 +1039,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
         ok = ok && hipMalloc(reinterpret_cast<void **>(&h->d_state), sizeof(GnState)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(GnState), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_sys_own), SYS_N * sizeof(double)) == hipSuccess &&
-             hipMalloc(reinterpret_cast<void **>(&h->d_partials), (size_t) MAX_PARTIAL_BLOCKS * SYS_N * sizeof(double)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&h->d_partials), ((size_t) (MAX_PARTIAL_BLOCKS + XCD_GROUPS) * SYS_N) * sizeof(double) + XCD_CTL_WORDS * sizeof(unsigned int)) == hipSuccess &&    // + the XCD group records + control words (XcdReduce)
+             hipMemsetAsync(h->d_partials + (size_t) (MAX_PARTIAL_BLOCKS + XCD_GROUPS) * SYS_N, 0, XCD_CTL_WORDS * sizeof(unsigned int), h->stream) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_pose_in), 16 * sizeof(double)) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&h->h_pose_in), 16 * sizeof(double), hipHostMallocDefault) == hipSuccess &&
              hipMalloc(reinterpret_cast<void **>(&h->d_counters), sizeof(Counters)) == hipSuccess &&
@@ -1603,6 +1634,10 @@ ctgn_status ctgn_gn_end(ctgn_handle h, double pose_out[14], ctgn_summary *summar
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev_loop_stop, h->stream));
+    // (round 5, measured and removed: a zero-copy ending for small frames — k_transform writing the world points and the final state
+    // straight into the page-locked staging block and publishing a completion word the host polled, no copy command, no stream
+    // synchronisation. Register of 1 679 keypoints: 0.1530 / 0.1541 ms with the copy + synchronise below, 0.1531 / 0.1529 ms without
+    // them (profiles/r05_ab_s2_register_zero_copy_end.txt): the end of the call waits for the device, not for the runtime.)
     if (merged) {
         HIPCHK(h, hipMemcpyAsync(h->h_kp + 4 * c, h->d_kp + 4 * c, (3 * c + KP_TAIL) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
@@ -2445,7 +2480,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         update_pending = true;
         hipError_t e = hipSuccess;
         for (auto &DL : h->devlevels)
-            if (e == hipSuccess) e = devmap_level_remove_far_enqueue(DL, d_pose + 11, *fused_max_distance, h->stream);
+            if (e == hipSuccess) e = devmap_level_remove_far_enqueue(DL, d_pose + 11, *fused_max_distance, h->stream, d_failed);
         if (e == hipSuccess && n1) {
             DevMapScratch &S = h->dm;
             double *own_pts = S.pts;
@@ -2857,6 +2892,47 @@ ctgn_status ctgn_get_system(ctgn_handle h, double out[CTGN_SYSTEM_DOUBLES]) {
     return CTGN_OK;
 }
 
+// What the box's HBM actually delivers to plain streaming kernels ("verify on the box with a device-to-device copy /
+// triad ... record both"): a float4 grid-stride copy (bytes read + bytes written) and the triad a = b + s c, `reps` launches each over
+// `bytes`-sized arrays, HIP events on the handle's stream. out_gbs[0] = copy, [1] = triad, GB/s of read + written bytes.
+namespace {
+__global__ __launch_bounds__(256) void k_hbm_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_hbm_triad(const float4 *__restrict__ b, const float4 *__restrict__ c, float4 *__restrict__ a, float s, size_t n4) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    }
+}
+}  // namespace
+ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[2]) {
+    NEED_DEVICE(h);
+    if (!out_gbs || bytes < (1u << 20) || reps < 1) return CTGN_ERR_INVALID_ARGUMENT;
+    const size_t n4 = (size_t) bytes / sizeof(float4);
+    float4 *buf[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&] { for (auto *b : buf) if (b) hipFree(b); if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); };
+    for (auto &b : buf)
+        if (hipMalloc(reinterpret_cast<void **>(&b), n4 * sizeof(float4)) != hipSuccess) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] ctgn_measure_hbm: out of device memory"); }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] hipEventCreate"); }
+    for (auto *b : buf) (void) hipMemsetAsync(b, 0, n4 * sizeof(float4), h->stream);
+    const int grid = h->num_cus * 8;                   // grid-stride: 8 blocks of 4 waves per CU
+    float ms = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int r = -2; r < reps; ++r) {              // two untimed launches first
+            if (r == 0) (void) hipEventRecord(e0, h->stream);
+            if (pass == 0) hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], n4);
+            else hipLaunchKernelGGL(k_hbm_triad, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], buf[2], 0.5f, n4);
+        }
+        (void) hipEventRecord(e1, h->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] ctgn_measure_hbm: timing failed"); }
+        out_gbs[pass] = (double) (pass == 0 ? 2 : 3) * (double) (n4 * sizeof(float4)) * reps / ((double) ms * 1e-3) / 1e9;
+    }
+    cleanup();
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_count_traffic(ctgn_handle h, uint64_t *probed, uint64_t *hit, uint64_t *points) {
     NEED_DEVICE(h);
     MapView mv;
@@ -2943,6 +3019,19 @@ ctgn_status ctgn_set_tuning(const char *key, double value) {
     double *slot = tuning_slot(tuning(), key);
     if (!slot) return CTGN_ERR_INVALID_ARGUMENT;
     *slot = value;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_path_counters(ctgn_handle h, uint64_t out[2]) {
+    if (!h || !out) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->device >= 0 && h->d_partials) {           // did the last solve launch sum the per-XCD group records? (drains the stream)
+        unsigned int w = 0;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(&w, reinterpret_cast<unsigned int *>(h->d_partials + (size_t) (MAX_PARTIAL_BLOCKS + XCD_GROUPS) * SYS_N) + 32 * XCD_GROUPS + 1, sizeof(w), hipMemcpyDeviceToHost));
+        h->path_counts[1] = w;
+    }
+    out[0] = h->path_counts[0];
+    out[1] = h->path_counts[1];
     return CTGN_OK;
 }
 

@@ -112,7 +112,12 @@ __global__ void k_dm_insert(Slot *slots, uint32_t mask, double *blocks, int blk,
 
 // RemoveElementsFarFromLocation (map.h:305-322): voxel removed iff ||first point - location|| > distance.
 __global__ void k_dm_remove_far(Slot *slots, uint64_t nslots, const double *blocks, int blk, uint32_t *free_list, DevCounters *cnt,
-                                double lx, double ly, double lz, double distance, double resolution, const double *loc_dev) {
+                                double lx, double ly, double lz, double distance, double resolution, const double *loc_dev,
+                                const int *failed_dev = nullptr) {
+    // the fused frame call enqueues this behind a registration whose outcome the host has not seen: a HARD error of that solve (GnState::failed
+    // >= 3: in-kernel barrier timed out, a peer rank failed — the call returns an error) must leave the map untouched, as include/ctgn.h promises;
+    // a soft failure (1: too few keypoints) evicts round the unchanged pose, as the reference's loop does
+    if (failed_dev && *failed_dev >= 3) return;
     if (loc_dev) { lx = loc_dev[0]; ly = loc_dev[1]; lz = loc_dev[2]; }      // the location lives on the device (a pose the host has not seen yet)
     for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         const Slot s = slots[i];
@@ -615,15 +620,16 @@ hipError_t devmap_test_compact(const uint8_t *flags_host, size_t n, uint32_t *ou
 
 hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {
     hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
-                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution, (const double *) nullptr);
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution, (const double *) nullptr,
+                       (const int *) nullptr);
     DM_CHK(hipGetLastError());
     return read_counters(L, stream);
 }
 
 // the same with the location read from device memory (3 doubles) and no counter read-back
-hipError_t devmap_level_remove_far_enqueue(DevLevel &L, const double *loc_dev, double distance, hipStream_t stream) {
+hipError_t devmap_level_remove_far_enqueue(DevLevel &L, const double *loc_dev, double distance, hipStream_t stream, const int *failed_dev) {
     hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
-                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, 0.0, 0.0, 0.0, distance, L.resolution, loc_dev);
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, 0.0, 0.0, 0.0, distance, L.resolution, loc_dev, failed_dev);
     return hipGetLastError();
 }
 

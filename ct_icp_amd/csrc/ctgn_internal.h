@@ -63,10 +63,21 @@ ctgn_status ctgn_kernel_timing_split(ctgn_handle h, double avg_ms[2], int32_t la
  * bounded generic path — A/B hook). Same results for every variant. Test / measurement hook. */
 ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 
+/* Measured streaming bandwidth of the device's HBM (the roofline's peak verified on the box): float4 copy and triad over
+ * `bytes`-sized arrays (>= 1 MiB; three of them are allocated for the call), `reps` timed launches each. out_gbs[0] = copy, [1] = triad,
+ * GB/s of bytes read + written. Measurement hook (bench.py: roofline.peak_measured). */
+ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[2]);
+
 /* The A/B switches of the measurement sessions, one table (ctgn_api.hip, struct Tuning: host_threads, order, pool_min, res_small, res_grid_cap,
- * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct). Process-wide; none of
+ * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct, tile_chunk,
+ * xcd_reduce). Process-wide; none of
  * them changes a result. A session script that cannot call into the library sets CTGN_TUNING="key=value,key=value" instead (read once). */
 ctgn_status ctgn_set_tuning(const char *key, double value);
+
+/* Has the size-dependent reduction path run (tests assert that the path they mean to cover did)? out[0] = residual launches of this handle
+ * whose block records got per-XCD pre-sums (XcdReduce, ctgn_kernels.hpp), out[1] = 1 if the last solve launch summed the group records
+ * rather than the block records (the placement check held). Drains the stream. */
+ctgn_status ctgn_path_counters(ctgn_handle h, uint64_t out[2]);
 
 /* Host-to-device bytes the last ctgn_set_keypoints_sharded call moved on this rank (host views): 56 B per keypoint of the scan with one rank,
  * 24 B per keypoint of the scan (world points, for the order every rank must agree on) + 56 B per keypoint of the rank's chunk otherwise. */

@@ -925,6 +925,10 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     }
     const int kp_per_wave = 4 * rounds;
     const int ntiles = (kp.n + kp_per_wave - 1) / kp_per_wave;
+    // 125-voxel sweep, wave-shared probes (shared2): the home voxel whose sweep sits in W.socc and the per-axis offset sets (slab-mask
+    // form) it was probed for; a later round with the same home voxel that needs no more than that takes the table as it is (round 5)
+    int s2_hx = INT_MIN, s2_hy = 0, s2_hz = 0;
+    uint32_t s2_mask = 0u;
     for (int tile = tile_first; tile < tile_end; tile += tile_step) {
         // ---------------- phase A: lane (row, sub < rounds) owns keypoint (sub * ntiles + tile) * 4 + row: round r of a
         // tile works on four CONSECUTIVE keypoints (neighbours in the scan usually share their home voxel), while the
@@ -1318,24 +1322,31 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 }
                 shared2 = same && hx != INT_MIN;
                 if (shared2) {
-                    // which sweep voxels some row can reach (slab masks only: a superset of the rows' exact tests)
+                    // which sweep voxels some row can reach (slab masks only: a superset of the rows' exact tests). The wave probes the
+                    // PRODUCT of the per-axis unions of the four rows' offset sets — a superset of the union of their products that one
+                    // 15-bit mask describes, so that a later round of the same home voxel can tell whether the table already holds
+                    // what it needs (consecutive rounds of a chunked tile, KpView::chunk > 1, share their home voxel as a rule).
                     const uint32_t m0 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 0);
                     const uint32_t m1 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 16);
                     const uint32_t m2 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 32);
                     const uint32_t m3 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 48);
-                    auto wanted = [&](int v) {
-                        const int ox = v / (S * S), oy = (v / S) % S, oz = v % S;            // offsets + NB: bit positions 0 .. 4
-                        auto t = [&](uint32_t mr) { return ((mr >> ox) & (mr >> (5 + oy)) & (mr >> (10 + oz)) & 1u) != 0u; };
-                        return v < V && (t(m0) || t(m1) || t(m2) || t(m3));
-                    };
-                    const int v0 = lane, v1 = lane + 64;
-                    const bool w0 = wanted(v0) && !(ablate & 16), w1 = wanted(v1) && !(ablate & 16);
-                    Probe p0 = probe_issue(map, w0, hx + v0 / (S * S) - NB, hy + (v0 / S) % S - NB, hz + v0 % S - NB);
-                    Probe p1 = probe_issue(map, w1, hx + (v1 % V) / (S * S) - NB, hy + ((v1 % V) / S) % S - NB, hz + (v1 % V) % S - NB);
-                    if (PROF) pc[10] += (unsigned long long) (__popcll(ballot64(w0)) + __popcll(ballot64(w1)));
-                    const uint32_t b0 = probe_resolve(map, p0), b1 = probe_resolve(map, p1);
-                    W.socc[v0] = b0;
-                    W.socc[v1] = b1;
+                    const uint32_t mu = m0 | m1 | m2 | m3;
+                    const bool staged = !(ablate & (1 << 27)) && hx == s2_hx && hy == s2_hy && hz == s2_hz && (mu & ~s2_mask) == 0u;
+                    if (!staged) {
+                        auto wanted = [&](int v) {
+                            const int ox = v / (S * S), oy = (v / S) % S, oz = v % S;            // offsets + NB: bit positions 0 .. 4
+                            return v < V && ((mu >> ox) & (mu >> (5 + oy)) & (mu >> (10 + oz)) & 1u) != 0u;
+                        };
+                        const int v0 = lane, v1 = lane + 64;
+                        const bool w0 = wanted(v0) && !(ablate & 16), w1 = wanted(v1) && !(ablate & 16);
+                        Probe p0 = probe_issue(map, w0, hx + v0 / (S * S) - NB, hy + (v0 / S) % S - NB, hz + v0 % S - NB);
+                        Probe p1 = probe_issue(map, w1, hx + (v1 % V) / (S * S) - NB, hy + ((v1 % V) / S) % S - NB, hz + (v1 % V) % S - NB);
+                        if (PROF) pc[10] += (unsigned long long) (__popcll(ballot64(w0)) + __popcll(ballot64(w1)));
+                        const uint32_t b0 = probe_resolve(map, p0), b1 = probe_resolve(map, p1);
+                        W.socc[v0] = b0;
+                        W.socc[v1] = b1;
+                        s2_hx = hx; s2_hy = hy; s2_hz = hz; s2_mask = mu;
+                    }
                 }
             }
             if (!shared2 && nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
@@ -1345,8 +1356,17 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             //   loads of chunk c+1 in flight while chunk c is tested against the radius / current k-th best and
             //   compacted into the row's LDS candidate list. A candidate's visit index is (sweep index v << 6) | slot:
             //   the reference's x-major sweep + insertion order (map.h:470-480), whatever the probing order.
+            // 125-voxel sweep: the voxels next to the home voxel (every offset within +-1) are the first 27 entries of the nearest-first order,
+            // i.e. probe batches 0 and 1; when no searching row of the round reaches farther on any axis (its slab mask has no +-2 bit: every
+            // bounded or guessed search on a level whose voxels are wider than the bound), batches 2 .. 7 hold nothing any row would accept
+            // and are not run at all (they used to cost a reach test per lane and batch). Bit 26 of the ablation mask: off (A/B).
+            int vit_run = VIT;
+            if constexpr (NB == 2) {
+                if (!(ablate & (1 << 26)) && !any64(searching && (mreach & 0x4631u) != 0u)) vit_run = 2;
+            }
 CTGN_BATCH_UNROLL
             for (int it = 0; it < VIT; ++it) {
+                if (NB == 2 && it >= vit_run) continue;      // (not `break`: the loop stays unrolled)
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
                 // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
                 Probe cur = nxt;
@@ -1359,7 +1379,7 @@ CTGN_BATCH_UNROLL
                     cur.active = batch_reach<NB>(map, it, sub, searching, kx, ky, kz, qx, qy, qz, cur_v, vx_, vy_, vz_, ablate, fmin(r2bound, kth_d2), mreach);
                     bc_shared = cur.active ? W.socc[cur_v == 255 ? 0 : cur_v] : 0u;
                 } else
-                if (it + 1 < VIT) {
+                if (it + 1 < vit_run) {
                     // (against the row's CURRENT bound: on the 125-voxel sweep a first search knows its k-th best after the first batch or
                     // two, and the remaining batches then probe only the voxels that bound can still reach instead of every voxel
                     // within the radius — hash probes into a map larger than the caches are what that sweep waits for)
@@ -1474,7 +1494,7 @@ CTGN_BATCH_UNROLL
                 // a row that has k candidates but no bound yet: find its k-th best now, so that the remaining (farther) voxels
                 // of the sweep can be culled against it (refreshing the bound after every batch that added candidates was
                 // measured too: D 2.31 -> 2.40-2.43 ms, the selections cost more than the tighter bound saves)
-                if ((NB == 2 || cull1) && it + 1 < VIT && any64(Ln >= kpool && !(kth_d2 < map.r2thr))) {
+                if ((NB == 2 || cull1) && it + 1 < vit_run && any64(Ln >= kpool && !(kth_d2 < map.r2thr))) {
                     Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
                     if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
                     CTGN_TICK(3)
@@ -1920,11 +1940,40 @@ __device__ __forceinline__ void unpack_wave_sums(int lane, const d4_t &accm, int
     if (lane == 0) comb[90] = (double) n_used_wave;
 }
 
+// loads / stores that bypass this CU's L1 (sc1: served by the XCD's L2, the point of coherence of its 32 CUs)
+__device__ __forceinline__ void sc1_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sc1_load(const double *p) {
+    return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Per-XCD pre-sums of the per-block records (round 5). The solve kernel's reduction pulls every block record — 518 x 768 B on a
+// 132 k-keypoint sweep — through ONE compute unit: ~4.5 us of its 13.7. The workgroups of a launch are dealt round-robin to the eight
+// XCDs (workgroup b runs on XCD b % 8), and the blocks of one XCD share its L2. The blocks form XCD_GROUPS = 32 groups (b % 32: four per
+// XCD): each block stores its record plainly (write-through L1, the line stays in that L2), drains its stores and takes a ticket on its
+// group's counter; the group's LAST block sums the group's records in block order (sc1 loads: its own L1 bypassed, L2 hits; one trip,
+// every load in flight) into the group's record — 32 blocks doing that side by side behind the last of their group, each out of its own
+// L2, instead of one block behind the launch boundary. The solve kernel then adds 32 records. The idiom is k_gn_persistent's, and so is
+// the placement check: every block leaves the XCC it ran on (HW_REG_XCC_ID) in a pad entry of its record, and a last block that finds a
+// member on another XCC stamps the launch's epoch into the control block; the solve kernel takes the group records only when every group
+// stamped this launch's epoch and none flagged its placement — otherwise the per-block records (always written, as before). Whatever the
+// dispatcher does, the result is one of the two fixed-order sums, never a partial one.
+constexpr int XCD_GROUPS = 32;
+struct XcdReduce {
+    unsigned int *ctl;       // group g owns the 128-byte line ctl[32 g ..]: [0] arrivals, [1] epoch its record was last written in;
+                             // ctl[32 XCD_GROUPS] = epoch of the last launch whose placement check failed, [+1] = 1 iff the last solve launch summed the group records
+    double *rec;             // [XCD_GROUPS][SYS_N] group records
+    unsigned int epoch;      // this launch's number (never 0)
+};
+constexpr int XCD_CTL_WORDS = 32 * XCD_GROUPS + 4;
+constexpr int XCD_PAD_ENTRY = SYS_N - 1;     // entry 95 of a block record: the XCC the block ran on (as a double), never summed into the system
+
 // BLK = 256 (throughput: 4 waves share a CU's texture path) or 64 (small frames: the 60 scattered gathers per keypoint are bound by the
 // per-CU texture path — ~1 line per clock — so a 1 k-keypoint frame is spread over 16 CUs instead of 4)
 template <int BLK>
 __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView kp, const GnState *st, GnParams prm,
-                                                            double *partials, DebugView dbg, int ablate) {
+                                                            double *partials, DebugView dbg, int ablate, XcdReduce xr) {
     __shared__ double s_rec[BLK / 64][64 * 13];
     __shared__ double s_comb[BLK / 64][SYS_N];
     __shared__ TieScratch s_tie[BLK / 64];
@@ -1948,10 +1997,56 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
         residual_tile(map, kp, st, prm, dbg, ablate, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave, s_tie[wave]);
     unpack_wave_sums(lane, accm, n_used_wave, s_comb[wave]);
     __syncthreads();
+    const unsigned int my_xcc = (unsigned int) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
     for (int e = tid; e < SYS_N; e += BLK) {
         double s = 0.0;
         for (int w = 0; w < BLK / 64; ++w) s += s_comb[w][e];
+        if (xr.ctl && e == XCD_PAD_ENTRY) s = (double) my_xcc;  // pad entry: where this block ran (XcdReduce's placement check; never part of the system)
         partials[(size_t) blockIdx.x * SYS_N + e] = s;          // block-major: one contiguous 768-byte record per block (see reduce_partials)
+    }
+    if constexpr (BLK >= 2 * SYS_N) {
+        if (xr.ctl) {            // per-XCD pre-sum (XcdReduce)
+            __shared__ int s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's part of the record has reached L2
+            __syncthreads();
+            const int g = (int) (blockIdx.x % XCD_GROUPS);
+            const int members = ((int) gridDim.x - g + XCD_GROUPS - 1) / XCD_GROUPS;
+            if (tid == 0) {
+                const unsigned int t = __hip_atomic_fetch_add(xr.ctl + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = t == (unsigned int) members - 1u;
+                if (last) __hip_atomic_store(xr.ctl + 32 * g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // for the next launch (stream order)
+                s_last = last;
+            }
+            __syncthreads();
+            if (s_last) {
+                // thread (h, e), h = 0 / 1: entry e of the group's members h, h + 2, ... in that order, every load in flight at once (a group
+                // of a resident grid has at most 24 members: 12 per thread); then half 0 + half 1. The pad entry is not summed but compared.
+                constexpr int MAXM = (3 * 256 + XCD_GROUPS - 1) / XCD_GROUPS;      // members of a group at the residual kernel's largest grid (3 blocks per CU)
+                bool same_xcc = true;
+                if (tid < 2 * SYS_N) {
+                    const int hh = tid / SYS_N, e2 = tid - hh * SYS_N;
+                    const double *col = partials + (size_t) g * SYS_N + e2;          // member m = block g + XCD_GROUPS m
+                    double sum = 0.0;
+                    for (int m0 = hh; m0 < members; m0 += MAXM) {
+                        double v[(MAXM + 1) / 2];
+#pragma unroll
+                        for (int q = 0; q < (MAXM + 1) / 2; ++q) v[q] = (m0 + 2 * q < members) ? sc1_load(col + (size_t) (m0 + 2 * q) * XCD_GROUPS * SYS_N) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < (MAXM + 1) / 2; ++q) {
+                            if (e2 == XCD_PAD_ENTRY) same_xcc = same_xcc && (m0 + 2 * q >= members || v[q] == (double) my_xcc);
+                            else sum += v[q];
+                        }
+                    }
+                    s_comb[hh][e2] = sum;
+                }
+                const bool placed = __syncthreads_and(same_xcc ? 1 : 0) != 0;
+                if (tid < SYS_N) xr.rec[(size_t) g * SYS_N + tid] = tid == XCD_PAD_ENTRY ? 0.0 : s_comb[0][tid] + s_comb[1][tid];
+                if (tid == 0) {
+                    if (placed) __hip_atomic_store(xr.ctl + 32 * g + 1, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // this group's record is this launch's
+                    else __hip_atomic_store(xr.ctl + 32 * XCD_GROUPS, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // a member ran behind another L2: void
+                }
+            }
+        }
     }
 }
 
@@ -2050,6 +2145,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
         double sum = 0.0;
 #pragma unroll
         for (int g = 0; g < G; ++g) sum += s_tmp[g * SYS_N + tid];
+        if (tid >= SYS_USED) sum = 0.0;            // pad entries (a block record's last one may carry its XCC id, XcdReduce)
         sys_global[tid] = sum;
         s_sys[tid] = sum;
     }
@@ -2254,7 +2350,7 @@ __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const 
 // at the barrier before the solve can start.
 template <int BLKS>
 __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
-                                                       GnParams prm, int mode, int min_used) {
+                                                       GnParams prm, int mode, int min_used, XcdReduce xr) {
     __shared__ SolveScratch S;
     __shared__ double s_tmp[(BLKS / SYS_N) * SYS_N];
     if (st->done) return;
@@ -2262,7 +2358,29 @@ __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, i
     const unsigned long long tc0 = __builtin_readcyclecounter();
     const unsigned long long wall0 = wall_clock64();
     if (mode != 2) {
-        reduce_partials<BLKS>(partials, nblocks, tid, sys, S.sys, s_tmp);
+        // the residual kernel left eight per-XCD group records (XcdReduce) unless its placement check failed in this very launch
+        // (every wave looks at all the stamps at once, lane l at group l % 32's: one round trip — a chain of `&&` over 32 loads cost the
+        // kernel 8 us, more than the reduction it replaces)
+        bool groups = false;
+        if (xr.ctl != nullptr && nblocks >= XCD_GROUPS) {
+            const unsigned int stamp = xr.ctl[32 * (lane & (XCD_GROUPS - 1)) + 1], bad = xr.ctl[32 * XCD_GROUPS];
+            groups = ballot64(stamp == xr.epoch && bad != xr.epoch) == ~0ull;
+        }
+        if (xr.ctl != nullptr && tid == 0) xr.ctl[32 * XCD_GROUPS + 1] = groups ? 1u : 0u;       // which sum this launch took (ctgn_path_counters)
+        if (groups) {
+            if (tid < SYS_N) {
+                double v[XCD_GROUPS];
+#pragma unroll
+                for (int g = 0; g < XCD_GROUPS; ++g) v[g] = xr.rec[(size_t) g * SYS_N + tid];
+                double sum = 0.0;
+#pragma unroll
+                for (int g = 0; g < XCD_GROUPS; ++g) sum += v[g];
+                sys[tid] = sum;
+                S.sys[tid] = sum;
+            }
+        } else {
+            reduce_partials<BLKS>(partials, nblocks, tid, sys, S.sys, s_tmp);
+        }
     } else {
         if (tid < SYS_N) S.sys[tid] = sys[tid];
     }
@@ -2308,12 +2426,6 @@ constexpr int GN_FAILED_BARRIER = 3;     // GnState::failed: the in-kernel barri
 template <int NB>
 inline size_t persistent_kernel_smem() { return rows_kernel_smem<NB>() + sizeof(PersistShared); }
 
-__device__ __forceinline__ void sc1_store(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double sc1_load(const double *p) {
-    return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 
 template <int NB>
 __global__ __launch_bounds__(ROW_BLOCK, 2) void k_gn_persistent(MapView map, KpView kp, GnState *st_out, const double *pose_in, double tb, double te,

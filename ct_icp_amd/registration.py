@@ -497,6 +497,18 @@ class GnSolver:
         L.check(self._h, L.lib().ctgn_count_traffic(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def path_counters(self):
+        """(residual launches with per-XCD pre-sums, 1 if the last solve launch summed the group records) — ctgn_path_counters."""
+        out = (C.c_uint64 * 2)()
+        L.check(self._h, L.lib().ctgn_path_counters(self._h, out))
+        return int(out[0]), int(out[1])
+
+    def measure_hbm(self, nbytes=1 << 30, reps=10):
+        """(copy, triad) GB/s of bytes read + written by float4 streaming kernels on this device (ctgn_measure_hbm, measurement hook)."""
+        out = (C.c_double * 2)()
+        L.check(self._h, L.lib().ctgn_measure_hbm(self._h, int(nbytes), int(reps), out))
+        return float(out[0]), float(out[1])
+
     def set_profiling(self, on=True):
         L.check(self._h, L.lib().ctgn_set_profiling(self._h, int(on)))
 

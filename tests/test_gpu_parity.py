@@ -6,6 +6,7 @@ to the stated SE(3) tolerance of 1e-4 m / 1e-4 rad — the tests assert the much
 expected (1e-9 .. 1e-7), so a drift far below the contractual tolerance is still caught.
 """
 import numpy as np
+import ctypes as C
 import pytest
 
 import ct_icp_amd as cia
@@ -63,7 +64,7 @@ def test_radius_search_is_bit_exact(case_name, request):
     for q, g in zip(qs, got):
         want = om.radius_search(q, 0.0, 20, heap_mode=0)
         assert g.shape == want.shape and np.array_equal(g, want)
-        assert np.array_equal(want, om.radius_search(q, 0.0, 20, heap_mode=0))      # no ties in this data
+        assert np.array_equal(want, om.radius_search(q, 0.0, 20, heap_mode=1))      # no ties in this data: the reference's queue (0) and the total order (1) agree
         n_full += len(g) == 20
     assert n_full > 300
     # 1-NN identity (reference test/unit/SlamCore/test_map.cxx:25-33) through the GPU map
@@ -683,6 +684,37 @@ def test_home_voxel_ordering_changes_nothing_but_the_schedule(config_b_full, box
     assert sg.success and sg.num_residuals_used == so.num_residuals_used and sg.num_iters == so.num_iters
     tr, rot = se3.pose_error(pg, po)
     assert tr < 1e-7 and rot < 1e-7
+
+
+def test_per_xcd_presums_change_nothing_but_the_summation_order(config_b_full):
+    """Round 5, ctgn_kernels.hpp XcdReduce: on a full sweep the residual kernel's per-block records (518 of them) are pre-summed by the
+    last block of each of 32 groups (four per XCD, each out of its own L2) and the solve kernel adds 32 group records: same keypoints
+    used, system equal up to summation order, poses to rounding — and the path must actually have run (ctgn_path_counters), with the
+    placement check holding on this part; the pad entries of the packed system stay zero (a block record's last one carries its XCC id)."""
+    gm, sc = config_b_full
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=4)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t, sc.raw)
+    s = cia.GnSolver(gm)
+    out = {}
+    try:
+        for on in (1, 0):
+            L.lib().ctgn_set_tuning(b"xcd_reduce", float(on))
+            c0 = s.path_counters()
+            s.set_keypoints(sc.raw, world0, sc.t)
+            pose, summ, _ = s.solve(pose0, sc.t_begin_end, _opts(num_iters_icp=4, threshold_orientation_norm=0.0))
+            c1 = s.path_counters()
+            raw96 = np.zeros(96)
+            L.check(s._h, L.lib().ctgn_get_system(s._h, raw96.ctypes.data_as(C.POINTER(C.c_double))))
+            out[on] = (pose, summ, s.get_system(), c1[0] - c0[0], c1[1], raw96)
+    finally:
+        L.lib().ctgn_set_tuning(b"xcd_reduce", -1.0)
+    (p1, s1, (A1, b1, n1), launches1, groups1, r1), (p0, s0, (A0, b0, n0), launches0, groups0, r0) = out[1], out[0]
+    assert launches1 == 4 and groups1 == 1, (launches1, groups1)        # four residual launches pre-summed, the last solve summed group records
+    assert launches0 == 0                                               # (the solve kernel's path word is written only when pre-sums are on)
+    assert np.all(r1[91:] == 0.0) and np.all(r0[91:] == 0.0)
+    assert s1.num_residuals_used == s0.num_residuals_used and n1 == n0 and s1.num_iters == s0.num_iters == 4
+    assert np.abs(A1 - A0).max() < 1e-12 * np.abs(A0).max() and np.abs(b1 - b0).max() < 1e-12 * np.abs(b0).max() + 1e-16
+    assert np.abs(p1 - p0).max() < 1e-12
 
 
 def test_full_scan_undistortion(config_b_full):

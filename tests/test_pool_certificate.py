@@ -115,3 +115,4 @@ def test_a_point_just_outside_the_pool_is_never_missed():
         else:
             refused += 1
     assert refused > 0 and accepted > 0, (refused, accepted)
+
