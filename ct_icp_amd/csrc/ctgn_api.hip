@@ -76,6 +76,7 @@ struct Tuning {
     double persist_times = 0;       // per-block timeline of the persistent kernel -> ctgn_wave_timeline
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
+    double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = automatic (launch_accumulate), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 64 blocks on), 0 / 1 = never / always
 };
@@ -84,7 +85,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
     CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct)
-    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce)
+    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
 }
@@ -1061,6 +1062,8 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
                                        (int) persistent_kernel_smem<1>()) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_persistent<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) persistent_kernel_smem<2>()) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_robust_eval_step), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) sizeof(FuseScratch)) == hipSuccess;
         if (!ok) { ctgn_destroy(h); return CTGN_ERR_HIP; }
     }
     *out = h;
@@ -2727,6 +2730,13 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
     const int n = h->n_kp;
     const int grid_lane = std::max(1, std::min((n + 255) / 256, 2048));
     const int grid_eval = std::max(1, std::min((n + EVAL_BLOCK - 1) / EVAL_BLOCK, h->res_grid_cap));
+    // evaluation + step (+ the end-of-iteration bookkeeping) of the inner solver in ONE launch while ONE block evaluates the frame as fast as
+    // several do: measured, Register on the robust route, 1 024 keypoints 0.703 / 0.717 -> 0.684 / 0.685 ms (31 launches fewer), 1 679 keypoints
+    // 0.764 / 0.759 -> 0.827 / 0.825 ms (four tiles of Jacobians on one compute unit cost more than the launches they save): up to 1 024
+    // keypoints. tuning robust_fuse: -1 = that rule, 0 / 1 = never / always (profiles/r05_ab_s5_robust_fused_launch.txt)
+    constexpr int ROBUST_FUSE_MAX = 1024;
+    const int env_fuse_r = (int) tuning().robust_fuse;
+    const bool fuse_eval_step = env_fuse_r >= 0 ? env_fuse_r != 0 : n <= ROBUST_FUSE_MAX;
     const bool saved_prof = h->profiling;
     h->profiling = false;
     h->searches_in_solve = 0;
@@ -2737,12 +2747,17 @@ ctgn_status ctgn_solve_robust(ctgn_handle h, double pose_io[14], const double tb
         hipLaunchKernelGGL(k_robust_prepare, dim3(grid_lane), dim3(256), 0, h->stream, mv, kv, h->d_state, r, rb);
         hipLaunchKernelGGL(k_robust_cap, dim3(1), dim3(CAP_BLOCK), 0, h->stream, h->d_state, h->d_rstate, r, rb, n);
         for (int j = 0; j <= r.ls_max_iters; ++j) {        // ceres::Solve, :627: evaluation 0 at x, then one per candidate
+            if (fuse_eval_step) {                           // small frames: one launch, one block (k_robust_eval_step)
+                hipLaunchKernelGGL(k_robust_eval_step, dim3(1), dim3(FUSE_BLOCK), sizeof(FuseScratch), h->stream, kv, h->d_state, h->d_rstate, r, rb,
+                                   j == r.ls_max_iters ? 1 : 0);
+                continue;
+            }
             hipLaunchKernelGGL(k_robust_eval, dim3(grid_eval), dim3(EVAL_BLOCK), 0, h->stream, kv, h->d_state, h->d_rstate, r, rb,
                                h->d_partials);
             hipLaunchKernelGGL(k_robust_step, dim3(1), dim3(STEP_BLOCK), 0, h->stream, h->d_partials, grid_eval, h->d_state,
                                h->d_rstate, r);
         }
-        hipLaunchKernelGGL(k_robust_outer, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate, r);
+        if (!fuse_eval_step) hipLaunchKernelGGL(k_robust_outer, dim3(1), dim3(64), 0, h->stream, h->d_state, h->d_rstate, r);
         if (hipGetLastError() != hipSuccess) st = fail(h, CTGN_ERR_HIP, "[HIP] robust kernel launch failed");
     }
     h->profiling = saved_prof;
@@ -2894,8 +2909,10 @@ ctgn_status ctgn_get_system(ctgn_handle h, double out[CTGN_SYSTEM_DOUBLES]) {
 
 // What the box's HBM actually delivers to plain streaming kernels ("verify on the box with a device-to-device copy /
 // triad ... record both"): a float4 grid-stride copy (bytes read + bytes written) and the triad a = b + s c, `reps` launches each over
-// `bytes`-sized arrays, HIP events on the handle's stream. out_gbs[0] = copy, [1] = triad, GB/s of read + written bytes.
+// `bytes`-sized arrays, HIP events on the handle's stream. out_gbs[0] = copy, [1] = triad, [2] = hipMemcpyAsync device to device, GB/s of read + written bytes.
 namespace {
+// shape 0: one float4 per thread (n4 / 256 blocks); shape 1: grid-stride over 8 blocks per CU. (Four loads in flight per thread and
+// step were measured too: slower, 4.4 against 4.95 TB/s.)
 __global__ __launch_bounds__(256) void k_hbm_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -2906,7 +2923,7 @@ __global__ __launch_bounds__(256) void k_hbm_triad(const float4 *__restrict__ b,
     }
 }
 }  // namespace
-ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[2]) {
+ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[3]) {
     NEED_DEVICE(h);
     if (!out_gbs || bytes < (1u << 20) || reps < 1) return CTGN_ERR_INVALID_ARGUMENT;
     const size_t n4 = (size_t) bytes / sizeof(float4);
@@ -2917,18 +2934,30 @@ ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double
         if (hipMalloc(reinterpret_cast<void **>(&b), n4 * sizeof(float4)) != hipSuccess) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] ctgn_measure_hbm: out of device memory"); }
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] hipEventCreate"); }
     for (auto *b : buf) (void) hipMemsetAsync(b, 0, n4 * sizeof(float4), h->stream);
-    const int grid = h->num_cus * 8;                   // grid-stride: 8 blocks of 4 waves per CU
     float ms = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int r = -2; r < reps; ++r) {              // two untimed launches first
-            if (r == 0) (void) hipEventRecord(e0, h->stream);
-            if (pass == 0) hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], n4);
-            else hipLaunchKernelGGL(k_hbm_triad, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], buf[2], 0.5f, n4);
+    out_gbs[0] = out_gbs[1] = 0.0;
+    for (int shape = 0; shape < 2; ++shape) {          // the better of the two launch shapes per kernel
+        const unsigned grid = shape == 0 ? (unsigned) std::min<size_t>((n4 + 255) / 256, 0x7fffffffu) : (unsigned) (h->num_cus * 8);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int r = -2; r < reps; ++r) {          // two untimed launches first
+                if (r == 0) (void) hipEventRecord(e0, h->stream);
+                if (pass == 0) hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], n4);
+                else hipLaunchKernelGGL(k_hbm_triad, dim3(grid), dim3(256), 0, h->stream, buf[0], buf[1], buf[2], 0.5f, n4);
+            }
+            (void) hipEventRecord(e1, h->stream);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] ctgn_measure_hbm: timing failed"); }
+            out_gbs[pass] = std::max(out_gbs[pass], (double) (pass == 0 ? 2 : 3) * (double) (n4 * sizeof(float4)) * reps / ((double) ms * 1e-3) / 1e9);
         }
-        (void) hipEventRecord(e1, h->stream);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) { cleanup(); return fail(h, CTGN_ERR_HIP, "[HIP] ctgn_measure_hbm: timing failed"); }
-        out_gbs[pass] = (double) (pass == 0 ? 2 : 3) * (double) (n4 * sizeof(float4)) * reps / ((double) ms * 1e-3) / 1e9;
     }
+    // the runtime's own device-to-device copy of the same arrays, as a third figure
+    for (int r = -2; r < reps; ++r) {
+        if (r == 0) (void) hipEventRecord(e0, h->stream);
+        (void) hipMemcpyAsync(buf[1], buf[0], n4 * sizeof(float4), hipMemcpyDeviceToDevice, h->stream);
+    }
+    (void) hipEventRecord(e1, h->stream);
+    out_gbs[2] = 0.0;
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+        out_gbs[2] = 2.0 * (double) (n4 * sizeof(float4)) * reps / ((double) ms * 1e-3) / 1e9;
     cleanup();
     return CTGN_OK;
 }

@@ -65,12 +65,12 @@ ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 
 /* Measured streaming bandwidth of the device's HBM (the roofline's peak verified on the box): float4 copy and triad over
  * `bytes`-sized arrays (>= 1 MiB; three of them are allocated for the call), `reps` timed launches each. out_gbs[0] = copy, [1] = triad,
- * GB/s of bytes read + written. Measurement hook (bench.py: roofline.peak_measured). */
-ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[2]);
+ * [2] = the runtime's own device-to-device hipMemcpyAsync; GB/s of bytes read + written. Measurement hook (bench.py: roofline.peak_measured). */
+ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[3]);
 
 /* The A/B switches of the measurement sessions, one table (ctgn_api.hip, struct Tuning: host_threads, order, pool_min, res_small, res_grid_cap,
  * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct, tile_chunk,
- * xcd_reduce). Process-wide; none of
+ * xcd_reduce, robust_fuse). Process-wide; none of
  * them changes a result. A session script that cannot call into the library sets CTGN_TUNING="key=value,key=value" instead (read once). */
 ctgn_status ctgn_set_tuning(const char *key, double value);
 

@@ -307,23 +307,18 @@ __global__ __launch_bounds__(CAP_BLOCK) void k_robust_cap(GnState *st, RobustSta
 constexpr int EVAL_BLOCK = 256;
 constexpr int EVAL_REC = 15;                 // 12 J | r | cost | pad (odd stride: conflict-free LDS writes)
 
-__global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnState *st, const RobustState *rs, RobustParams prm,
-                                                             RobustBuf rb, double *partials) {
-    __shared__ double s_rec[EVAL_BLOCK / 64][64 * EVAL_REC];
-    __shared__ double s_comb[EVAL_BLOCK / 64][SYS_N];
-    __shared__ PoseCtx s_ctx;
-    if (st->done || rs->ls_done) return;
-    const int at_x = rs->eval_at_x;
-    if (!at_x && !rs->step_valid) return;        // the last step was invalid: nothing new to evaluate
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ctx = at_x ? rs->x : rs->cand;
-    __syncthreads();
-    typedef double d4_t __attribute__((ext_vector_type(4)));
-    d4_t accm = {0.0, 0.0, 0.0, 0.0};
-    const int ntiles = (kp.n + EVAL_BLOCK - 1) / EVAL_BLOCK;
+typedef double rb_d4_t __attribute__((ext_vector_type(4)));
+
+// One wave's share of an evaluation: its lanes take keypoints tile * BLK + tid of the tiles tile_first, tile_first + tile_step, ...;
+// the wave's records go through `rec` (64 x EVAL_REC doubles of LDS) into the 16 x 16 FP64 MFMA accumulator accm (U^T U).
+template <int BLK>
+__device__ __forceinline__ void robust_eval_tiles(const KpView &kp, const PoseCtx &ctx, const RobustParams &prm, const RobustBuf &rb, int tile_first,
+                                                  int tile_step, int tid, double *rec, rb_d4_t &accm) {
+    const int lane = tid & 63;
+    const int ntiles = (kp.n + BLK - 1) / BLK;
     const size_t ncap = (size_t) prm.num_closest * rb.cap;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int k = tile * EVAL_BLOCK + tid;
+    for (int tile = tile_first; tile < ntiles; tile += tile_step) {
+        const int k = tile * BLK + tid;
         int rank = -1;
         Vec3 raw{0, 0, 0}, m{0, 0, 0};
         double alpha = 0.0;
@@ -342,7 +337,7 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
             if (used) {
                 const size_t at = (size_t) i * rb.cap + k;
                 const Vec3 ref{rb.ref[at], rb.ref[ncap + at], rb.ref[2 * ncap + at]};
-                r = ct_residual<true>(s_ctx, alpha, raw, ref, m, J);
+                r = ct_residual<true>(ctx, alpha, raw, ref, m, J);
                 const double s = r * r;
                 if (prm.loss == LOSS_STANDARD) {
                     cost = 0.5 * s;
@@ -367,7 +362,6 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
             }
             // U = the wave's 64 x 15 records (J | r | cost | 1): the packed sums are entries of U^T U, sixteen FP64 MFMAs
             // (see k_residual_reduce); cost rides along as (U^T U)[13][14]
-            double *rec = s_rec[wave];
             double *my = rec + lane * EVAL_REC;
 #pragma unroll
             for (int c = 0; c < 12; ++c) my[c] = used ? J[c] : 0.0;
@@ -382,17 +376,34 @@ __global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnS
             }
         }
     }
-    if (lane < SYS_N - SYS_USED) s_comb[wave][SYS_USED + lane] = 0.0;
-    {
-        const int col = lane & 15;
+}
+// the wave's packed J^T J | -J^T r | cost out of the accumulator (the f64 MFMA's C / D layout) into comb[SYS_N]
+__device__ __forceinline__ void robust_unpack(const rb_d4_t &accm, int lane, double *comb) {
+    if (lane < SYS_N - SYS_USED) comb[SYS_USED + lane] = 0.0;
+    const int col = lane & 15;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int row = (lane >> 4) + 4 * m;
-            if (row < 12 && col >= row && col < 12) s_comb[wave][row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
-            if (row < 12 && col == 12) s_comb[wave][78 + row] = -accm[m];
-            if (row == 13 && col == 14) s_comb[wave][90] = accm[m];
-        }
+    for (int m = 0; m < 4; ++m) {
+        const int row = (lane >> 4) + 4 * m;
+        if (row < 12 && col >= row && col < 12) comb[row * 12 - (row * (row - 1)) / 2 + (col - row)] = accm[m];
+        if (row < 12 && col == 12) comb[78 + row] = -accm[m];
+        if (row == 13 && col == 14) comb[90] = accm[m];
     }
+}
+
+__global__ __launch_bounds__(EVAL_BLOCK) void k_robust_eval(KpView kp, const GnState *st, const RobustState *rs, RobustParams prm,
+                                                             RobustBuf rb, double *partials) {
+    __shared__ double s_rec[EVAL_BLOCK / 64][64 * EVAL_REC];
+    __shared__ double s_comb[EVAL_BLOCK / 64][SYS_N];
+    __shared__ PoseCtx s_ctx;
+    if (st->done || rs->ls_done) return;
+    const int at_x = rs->eval_at_x;
+    if (!at_x && !rs->step_valid) return;        // the last step was invalid: nothing new to evaluate
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ctx = at_x ? rs->x : rs->cand;
+    __syncthreads();
+    rb_d4_t accm = {0.0, 0.0, 0.0, 0.0};
+    robust_eval_tiles<EVAL_BLOCK>(kp, s_ctx, prm, rb, (int) blockIdx.x, (int) gridDim.x, tid, s_rec[wave], accm);
+    robust_unpack(accm, lane, s_comb[wave]);
     __syncthreads();
     if (tid < SYS_N) {
         double t = 0.0;
@@ -513,34 +524,22 @@ __device__ __forceinline__ double wave_spd_solve12(double (&rowr)[12], double bi
 constexpr int STEP_BLOCK = 1024;
 #define RWSYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-__global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partials, int nblocks, GnState *st, RobustState *rs,
-                                                             RobustParams prm) {
-    __shared__ double s_sys[SYS_N];
-    __shared__ __attribute__((aligned(8))) RobustState R;
-    __shared__ double s_Hc[144], s_gc[12];              // normal equations of the pose just evaluated
-    __shared__ double s_delta[12];
-    __shared__ int s_flag;
-    static_assert(sizeof(RobustState) % 8 == 0, "RobustState is copied as doubles");
-    constexpr int NW = (int) (sizeof(RobustState) / 8);
-    if (st->done || rs->ls_done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long tc0 = __builtin_readcyclecounter();
-    unsigned long long tc1 = tc0, tc2 = tc0, tc3 = tc0, tc4 = tc0, tc5 = tc0;
-    for (int w = tid; w < NW; w += STEP_BLOCK) reinterpret_cast<double *>(&R)[w] = reinterpret_cast<const double *>(rs)[w];
-    __syncthreads();
-    const bool have_eval = R.eval_at_x || R.step_valid;        // did the preceding k_robust_eval run?
-    // wave w sums entries w, w + 16, ... over the blocks: lane-strided, then a fixed shuffle tree (deterministic)
-    if (have_eval) {
-        for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
-            double acc = 0.0;
-            for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) b * SYS_N + e];
-            acc = wave_sum_fixed(acc);
-            if (lane == 0) s_sys[e] = acc;
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
+struct StepScratch {                   // LDS of one Levenberg-Marquardt step (wave 0)
+    double sys[SYS_N];
+    __attribute__((aligned(8))) RobustState R;
+    double Hc[144], gc[12];            // normal equations of the pose just evaluated
+    double delta[12];
+    int flag;
+};
+static_assert(sizeof(RobustState) % 8 == 0, "RobustState is copied as doubles");
 
+// Everything of a step behind the reduction, by ONE wave: S.sys holds the packed sums of the pose just evaluated (if have_eval), S.R the
+// solver state, which is written back to rs at the end.
+__device__ __forceinline__ void robust_step_wave0(StepScratch &S, bool have_eval, GnState *st, RobustState *rs, const RobustParams &prm, int lane,
+                                                  unsigned long long tc0) {
+    RobustState &R = S.R;
+    constexpr int NW = (int) (sizeof(RobustState) / 8);
+    unsigned long long tc1 = tc0, tc2 = tc0, tc3 = tc0, tc4 = tc0, tc5 = tc0;
     const double min_relative_decrease = 1e-3, min_diag = 1e-6, max_diag = 1e32;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const double max_radius = 1e16, min_radius = 1e-32;
@@ -551,17 +550,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
     if (have_eval) {
         for (int e = lane; e < 78; e += 64) {
             const int r = c_tri_i[e], c = c_tri_j[e];
-            s_Hc[12 * r + c] = s_sys[e];
-            s_Hc[12 * c + r] = s_sys[e];
+            S.Hc[12 * r + c] = S.sys[e];
+            S.Hc[12 * c + r] = S.sys[e];
         }
-        if (lane < 12) s_gc[lane] = -s_sys[78 + lane];
+        if (lane < 12) S.gc[lane] = -S.sys[78 + lane];
     }
     RWSYNC();
     if (lane == 0) {
-        int flag = 0, take = 0;                            // take: s_Hc / s_gc become the current normal equations
+        int flag = 0, take = 0;                            // take: S.Hc / S.gc become the current normal equations
         if (have_eval) {
             const double *pose_e = R.eval_at_x ? R.x.pose : R.cand.pose;
-            const double cost = s_sys[90] + robust_regularisers(prm, R.n_res, pose_e, s_Hc, s_gc);
+            const double cost = S.sys[90] + robust_regularisers(prm, R.n_res, pose_e, S.Hc, S.gc);
             if (R.eval_at_x) {                             // Ceres' iteration 0
                 R.x_cost = cost;
                 R.eval_at_x = 0;
@@ -592,16 +591,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
                 R.step_valid = 0;
             }
         }
-        s_flag = flag | (take << 1);
+        S.flag = flag | (take << 1);
     }
     RWSYNC();
-    if (s_flag & 2) {                                      // adopt the evaluated normal equations
-        for (int e = lane; e < 144; e += 64) R.H[e] = s_Hc[e];
-        if (lane < 12) R.g[lane] = s_gc[lane];
+    if (S.flag & 2) {                                      // adopt the evaluated normal equations
+        for (int e = lane; e < 144; e += 64) R.H[e] = S.Hc[e];
+        if (lane < 12) R.g[lane] = S.gc[lane];
     }
     RWSYNC();
     const double radius = R.radius;
-    if (lane == 0 && !(s_flag & 1)) {
+    if (lane == 0 && !(S.flag & 1)) {
         // FinalizeIterationAndCheckIfMinimizerCanContinue
         int flag = 0;
         if (R.ls_iter >= prm.ls_max_iters) { R.ls_done = 1; R.ls_term = 0; flag = 1; }
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
             if (mx <= gradient_tolerance || radius < min_radius) { R.ls_done = 1; R.ls_term = 1; flag = 1; }
         }
         if (!flag) { R.ls_iter += 1; R.ls_iters_total += 1; }
-        s_flag = flag;
+        S.flag = flag;
     }
     RWSYNC();
     tc2 = __builtin_readcyclecounter();
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
     RWSYNC();
     tc3 = __builtin_readcyclecounter();
     tc4 = tc3;
-    if (!(s_flag & 1)) {
+    if (!(S.flag & 1)) {
         // LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian: (Hs + clamp(diag Hs) / radius) y = -gs
         double rowr[12], hs[12];
 #pragma unroll
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
         const double model_cost_change = -wave_sum_fixed(lane < 12 ? y * (gs_i + 0.5 * row) : 0.0);   // -(J y).(r + J y / 2)
         const bool finite_all = ballot64(lane < 12 && !isfinite(y)) == 0ull;
         ok = ok && finite_all && model_cost_change > 0.0;
-        if (lane < 12) s_delta[lane] = y * sc_i;
+        if (lane < 12) S.delta[lane] = y * sc_i;
         RWSYNC();
         tc4 = __builtin_readcyclecounter();
         if (lane == 0) {
@@ -657,7 +656,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
                 R.model_cost_change = model_cost_change;
                 double delta[12];
 #pragma unroll
-                for (int c = 0; c < 12; ++c) delta[c] = s_delta[c];
+                for (int c = 0; c < 12; ++c) delta[c] = S.delta[c];
                 pose_plus(R.x.pose, delta, R.cand.pose);
                 pose_ctx_prepare(R.cand);
                 R.step_valid = 1;
@@ -683,6 +682,30 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partia
     if (lane == 0 && stop_all) st->done = 1;
 }
 
+__global__ __launch_bounds__(STEP_BLOCK) void k_robust_step(const double *partials, int nblocks, GnState *st, RobustState *rs,
+                                                             RobustParams prm) {
+    __shared__ StepScratch S;
+    constexpr int NW = (int) (sizeof(RobustState) / 8);
+    if (st->done || rs->ls_done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    for (int w = tid; w < NW; w += STEP_BLOCK) reinterpret_cast<double *>(&S.R)[w] = reinterpret_cast<const double *>(rs)[w];
+    __syncthreads();
+    const bool have_eval = S.R.eval_at_x || S.R.step_valid;        // did the preceding k_robust_eval run?
+    // wave w sums entries w, w + 16, ... over the blocks: lane-strided, then a fixed shuffle tree (deterministic)
+    if (have_eval) {
+        for (int e = wave; e < SYS_USED; e += STEP_BLOCK / 64) {
+            double acc = 0.0;
+            for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t) b * SYS_N + e];
+            acc = wave_sum_fixed(acc);
+            if (lane == 0) S.sys[e] = acc;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    robust_step_wave0(S, have_eval, st, rs, prm, lane, tc0);
+}
+
 // slam::AngularDistance (include/SlamCore/types.h:142-150), degrees
 __device__ inline double angular_distance_deg(const double *qa, const double *qb) {
     double Ra[9], Rb[9];
@@ -696,8 +719,8 @@ __device__ inline double angular_distance_deg(const double *qa, const double *qb
 }
 
 // End of one ICP iteration (ct_icp.cpp:633-667): normalise, pose change since the previous iteration, stop test.
-__global__ void k_robust_outer(GnState *st, RobustState *rs, RobustParams prm) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || st->done) return;
+__device__ __forceinline__ void robust_outer_body(GnState *st, RobustState *rs, const RobustParams &prm) {       // ONE lane
+    if (st->done) return;
     double p[14], prev[14];
     for (int i = 0; i < 14; ++i) { p[i] = st->pose[i]; prev[i] = rs->prev[i]; }
     const int icp_iter = rs->icp_iter, iter = st->iter;
@@ -720,6 +743,60 @@ __global__ void k_robust_outer(GnState *st, RobustState *rs, RobustParams prm) {
     st->iter = iter + 1;
     if (diff_rot < prm.thr_rot_deg && diff_trans < prm.thr_trans) { rs->converged = 1; st->done = 1; }   // :662-667: break
     else rs->icp_iter = icp_iter + 1;
+}
+
+__global__ void k_robust_outer(GnState *st, RobustState *rs, RobustParams prm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    robust_outer_body(st, rs, prm);
+}
+
+// Small frames (round 5): evaluation AND step in one launch by one block — the reference's own keypoint counts (<= max_num_residuals
+// blocks of 1-3 k keypoints) keep one compute unit busy for a few microseconds, while the two launches they replace cost a launch
+// latency each, thirty times per registration (5 ICP iterations x 6 evaluations). Same arithmetic per residual block; the packed sums
+// are taken per wave over its tiles, then over the block's waves in index order (a fixed order of its own, like every path here).
+constexpr int FUSE_BLOCK = 512;
+struct FuseScratch {
+    double rec[FUSE_BLOCK / 64][64 * EVAL_REC];
+    double comb[FUSE_BLOCK / 64][SYS_N];
+    StepScratch step;
+};
+// last: this is the inner solver's final launch of the ICP iteration — the end-of-iteration bookkeeping (k_robust_outer: normalise, pose
+// change, stop test) follows in the same launch, whether or not the inner solver had already stopped.
+__global__ __launch_bounds__(FUSE_BLOCK) void k_robust_eval_step(KpView kp, GnState *st, RobustState *rs, RobustParams prm, RobustBuf rb, int last) {
+    extern __shared__ __attribute__((aligned(16))) char fuse_smem[];
+    FuseScratch &F = *reinterpret_cast<FuseScratch *>(fuse_smem);
+    StepScratch &S = F.step;
+    constexpr int NW = (int) (sizeof(RobustState) / 8);
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rs->ls_done) {
+        if (last && tid == 0) robust_outer_body(st, rs, prm);
+        return;
+    }
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    for (int w = tid; w < NW; w += FUSE_BLOCK) reinterpret_cast<double *>(&S.R)[w] = reinterpret_cast<const double *>(rs)[w];
+    __syncthreads();
+    const bool have_eval = S.R.eval_at_x || S.R.step_valid;        // (an invalid last step: nothing new to evaluate)
+    if (have_eval) {
+        rb_d4_t accm = {0.0, 0.0, 0.0, 0.0};
+        robust_eval_tiles<FUSE_BLOCK>(kp, S.R.eval_at_x ? S.R.x : S.R.cand, prm, rb, 0, 1, tid, F.rec[wave], accm);
+        robust_unpack(accm, lane, F.comb[wave]);
+    }
+    __syncthreads();
+    if (have_eval && tid < SYS_N) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < FUSE_BLOCK / 64; ++w) t += F.comb[w][tid];
+        S.sys[tid] = t;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    robust_step_wave0(S, have_eval, st, rs, prm, lane, tc0);
+    if (last) {
+        __threadfence();                                   // the state this wave just wrote back, before lane 0 reads it again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) robust_outer_body(st, rs, prm);
+    }
 }
 
 __global__ void k_robust_init(const GnState *st, RobustState *rs) {

@@ -504,10 +504,10 @@ class GnSolver:
         return int(out[0]), int(out[1])
 
     def measure_hbm(self, nbytes=1 << 30, reps=10):
-        """(copy, triad) GB/s of bytes read + written by float4 streaming kernels on this device (ctgn_measure_hbm, measurement hook)."""
-        out = (C.c_double * 2)()
+        """(copy, triad, runtime device-to-device copy) GB/s of bytes read + written on this device (ctgn_measure_hbm, measurement hook)."""
+        out = (C.c_double * 3)()
         L.check(self._h, L.lib().ctgn_measure_hbm(self._h, int(nbytes), int(reps), out))
-        return float(out[0]), float(out[1])
+        return float(out[0]), float(out[1]), float(out[2])
 
     def set_profiling(self, on=True):
         L.check(self._h, L.lib().ctgn_set_profiling(self._h, int(on)))
