@@ -558,7 +558,9 @@ def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
     (rows_tiles, shared2) instead of eight dependent batches per row. Dense keypoints (every return of the scan) worked through in
     home-voxel order make that the rule; with pools on and off, four iterations: counts, farthest neighbours, gates and packed system
     are the ones of the per-row probes (bit 22 of the ablation mask switches the shared stage off) after every iteration, and the first
-    accumulation's neighbour sets are the oracle's."""
+    accumulation's neighbour sets are the oracle's. Round 5: the same against the batch loop run to its end (bit 26: no early stop
+    after the batches some row can reach), against a probe table that is never reused (bit 27), and with tiles of four consecutive
+    rounds (tuning tile_chunk: consecutive rounds share their home voxel, so the table IS reused)."""
     case = nclt_case
     om, gm = build_maps(case, 8, with_gpu=True)
     sc = case["scans"][8]
@@ -568,26 +570,31 @@ def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
     o = _opts(num_iters_icp=4, min_number_neighbors=10, threshold_orientation_norm=0.0)
     for pools in (0, 1):
         runs = []
-        for mask in (0, 1 << 22):
-            s = cia.GnSolver(gm)
-            s.set_ordering(1)
-            s.set_pools(pools)
-            s.set_ablation(mask)
-            s.set_debug(True)
-            s.set_keypoints(raw, world0, t)
-            s.gn_begin(pose0, sc.t_begin_end, o, None)
-            per_iter = []
-            for _ in range(o.num_iters_icp):
-                s.gn_iterate(1)
-                d = s.get_debug()
-                per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["farthest"].copy(), d["used"].copy(), d["a2d"].copy()))
-            pose, summ, _ = s.gn_end()
+        for mask, chunk in ((0, 0), (1 << 22, 0), (1 << 26, 0), (1 << 27, 0), (0, 4)):
+            L.lib().ctgn_set_tuning(b"tile_chunk", float(chunk))
+            try:
+                s = cia.GnSolver(gm)
+                s.set_ordering(1)
+                s.set_pools(pools)
+                s.set_ablation(mask)
+                s.set_debug(True)
+                s.set_keypoints(raw, world0, t)
+                s.gn_begin(pose0, sc.t_begin_end, o, None)
+                per_iter = []
+                for _ in range(o.num_iters_icp):
+                    s.gn_iterate(1)
+                    d = s.get_debug()
+                    per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["farthest"].copy(), d["used"].copy(), d["a2d"].copy()))
+                pose, summ, _ = s.gn_end()
+            finally:
+                L.lib().ctgn_set_tuning(b"tile_chunk", 0.0)
             runs.append((pose, per_iter))
-        assert np.array_equal(runs[0][0], runs[1][0])
-        for k_it, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
-            assert np.array_equal(a[0][0], b[0][0]) and a[0][2] == b[0][2], k_it
-            for x, y in zip(a[1:], b[1:]):
-                assert np.array_equal(x, y), k_it
+        for other in runs[1:]:
+            assert np.array_equal(runs[0][0], other[0])
+            for k_it, (a, b) in enumerate(zip(runs[0][1], other[1])):
+                assert np.array_equal(a[0][0], b[0][0]) and a[0][2] == b[0][2], k_it
+                for x, y in zip(a[1:], b[1:]):
+                    assert np.array_equal(x, y), k_it
     _, _, _, info = orc.gn_accumulate(om, raw, world0, t, pose0, sc.t_begin_end, _oopts(o), heap_mode=0, debug=True)
     first = runs[0][1][0]
     assert np.array_equal(first[1], info["n_neighbors"])
