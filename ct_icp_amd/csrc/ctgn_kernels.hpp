@@ -1168,7 +1168,12 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             // about the distance the keypoint has moved, so nearly everything it admits comes for free. A search bounded by the radius only
             // would have to carry the spare members through every cut of its long stream: it keeps the k neighbours and leaves no pool.
             const bool guessed = W.gs[src] != 0;         // (a guessed search keeps no pool: like the radius-only search it stands in for)
-            const int kpool = (!guessed && (double) W.kb[src] < map.r2thr) ? pool_cap : k;
+            // Round 5: ... and so does a search whose carried-over bound lies BEYOND the radius (a keypoint in a sparse part of the map, k-th
+            // neighbour near the radius): it admits everything within the radius, which in such a place is little more than k points — the
+            // pool is then complete out to the radius (or its last member), and the keypoint stops being searched on the whole radius in
+            // every later iteration, where those searches were the slowest rounds of the launch. Bit 29 of the ablation mask: as before.
+            const bool carried_beyond = !guessed && !((double) W.kb[src] < map.r2thr) && W.kb[src] < __int_as_float(0x7f800000) && !(ablate & (1 << 29));
+            const int kpool = (!guessed && ((double) W.kb[src] < map.r2thr || carried_beyond)) ? pool_cap : k;
 
             // Do the four keypoints of this round live in the same home voxel? (wave-uniform test on SGPRs)
             const bool uniform_home = SHARED && (NB == 1 && blk <= 32) && !(ablate & 32) && rows_share_home(kx, ky, kz);
@@ -1555,7 +1560,7 @@ CTGN_BATCH_UNROLL
                         o[0] = flagged; kp.cnt[kp_r] = flagged;
                         if (kp.kth) {
                             float kthv = 0.f;
-                            if (sorted && kpool > k) {
+                            if (sorted && kpool > k && !(carried_beyond && n < k)) {      // (fewer than k within the radius: no check could ever pass)
                                 // Everything this search did not put into the list lies farther than the admission bound it ended with
                                 // (culled voxels and rejected candidates were beyond the bound of their moment, and bounds only shrink);
                                 // everything the selections dropped lies at or beyond the last pool member. Inside the smaller of the two
