@@ -1960,19 +1960,22 @@ __device__ __forceinline__ double sc1_load(const double *p) {
 // group's counter; the group's LAST block sums the group's records in block order (sc1 loads: its own L1 bypassed, L2 hits; one trip,
 // every load in flight) into the group's record — 32 blocks doing that side by side behind the last of their group, each out of its own
 // L2, instead of one block behind the launch boundary. The solve kernel then adds 32 records. The idiom is k_gn_persistent's, and so is
-// the placement check: every block leaves the XCC it ran on (HW_REG_XCC_ID) in a pad entry of its record, and a last block that finds a
-// member on another XCC stamps the launch's epoch into the control block; the solve kernel takes the group records only when every group
-// stamped this launch's epoch and none flagged its placement — otherwise the per-block records (always written, as before). Whatever the
-// dispatcher does, the result is one of the two fixed-order sums, never a partial one.
+// the placement check, which must not depend on what a possibly foreign L2 returns: the ticket is ONE 64-bit atomic add (device-coherent,
+// like every atomic here) whose low byte counts arrivals and whose eight 7-bit fields above count them per XCC the block ran on
+// (HW_REG_XCC_ID); the last arriver sees every member's XCC in the value it gets back, and a group that arrived from more than one XCC
+// stamps the launch's epoch into the control block instead of its own stamp. The solve kernel takes the group records only when every
+// group stamped this launch's epoch and none flagged its placement — otherwise the per-block records (always written, as before).
+// Whatever the dispatcher does, the result is one of the two fixed-order sums, never a partial or a stale one.
 constexpr int XCD_GROUPS = 32;
 struct XcdReduce {
-    unsigned int *ctl;       // group g owns the 128-byte line ctl[32 g ..]: [0] arrivals, [1] epoch its record was last written in;
-                             // ctl[32 XCD_GROUPS] = epoch of the last launch whose placement check failed, [+1] = 1 iff the last solve launch summed the group records
+    unsigned int *ctl;       // group g owns the 128-byte line ctl[32 g ..]: words 0-1 = the 64-bit ticket (arrivals | per-XCC arrivals), word 2 = epoch
+                             // its record was last written in; ctl[32 XCD_GROUPS] = epoch of the last launch whose placement check failed,
+                             // [+1] = 1 iff the last solve launch summed the group records
     double *rec;             // [XCD_GROUPS][SYS_N] group records
     unsigned int epoch;      // this launch's number (never 0)
 };
 constexpr int XCD_CTL_WORDS = 32 * XCD_GROUPS + 4;
-constexpr int XCD_PAD_ENTRY = SYS_N - 1;     // entry 95 of a block record: the XCC the block ran on (as a double), never summed into the system
+static_assert(MAX_PARTIAL_BLOCKS / XCD_GROUPS <= 127, "a group's arrivals must fit the ticket's 7-bit per-XCC fields (and its 8-bit count)");
 
 // BLK = 256 (throughput: 4 waves share a CU's texture path) or 64 (small frames: the 60 scattered gathers per keypoint are bound by the
 // per-CU texture path — ~1 line per clock — so a 1 k-keypoint frame is spread over 16 CUs instead of 4)
@@ -2002,11 +2005,9 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
         residual_tile(map, kp, st, prm, dbg, ablate, tile * BLK + tid, lane, s_rec[wave], accm, n_used_wave, s_tie[wave]);
     unpack_wave_sums(lane, accm, n_used_wave, s_comb[wave]);
     __syncthreads();
-    const unsigned int my_xcc = (unsigned int) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
     for (int e = tid; e < SYS_N; e += BLK) {
         double s = 0.0;
         for (int w = 0; w < BLK / 64; ++w) s += s_comb[w][e];
-        if (xr.ctl && e == XCD_PAD_ENTRY) s = (double) my_xcc;  // pad entry: where this block ran (XcdReduce's placement check; never part of the system)
         partials[(size_t) blockIdx.x * SYS_N + e] = s;          // block-major: one contiguous 768-byte record per block (see reduce_partials)
     }
     if constexpr (BLK >= 2 * SYS_N) {
@@ -2017,17 +2018,26 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
             const int g = (int) (blockIdx.x % XCD_GROUPS);
             const int members = ((int) gridDim.x - g + XCD_GROUPS - 1) / XCD_GROUPS;
             if (tid == 0) {
-                const unsigned int t = __hip_atomic_fetch_add(xr.ctl + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = t == (unsigned int) members - 1u;
-                if (last) __hip_atomic_store(xr.ctl + 32 * g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // for the next launch (stream order)
+                // one 64-bit add: arrivals in bits 0-7 (a group has at most 64 members), arrivals from XCC x in bits 8 + 7 x .. 14 + 7 x
+                const unsigned int my_xcc = (unsigned int) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;       // HW_REG_XCC_ID
+                unsigned long long *ticket = reinterpret_cast<unsigned long long *>(xr.ctl + 32 * g);
+                const unsigned long long inc = 1ull + (1ull << (8 + 7 * my_xcc));
+                const unsigned long long t = __hip_atomic_fetch_add(ticket, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int last = 0;
+                if ((t & 0xffull) == (unsigned long long) (members - 1)) {
+                    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                  // for the next launch (stream order)
+                    const unsigned long long by_xcc = (t + inc) >> 8;
+                    if ((by_xcc & ~(0x7full << (7 * my_xcc))) != 0ull)                                              // members behind another L2: void
+                        __hip_atomic_store(xr.ctl + 32 * XCD_GROUPS, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else last = 1;
+                }
                 s_last = last;
             }
             __syncthreads();
             if (s_last) {
                 // thread (h, e), h = 0 / 1: entry e of the group's members h, h + 2, ... in that order, every load in flight at once (a group
-                // of a resident grid has at most 24 members: 12 per thread); then half 0 + half 1. The pad entry is not summed but compared.
+                // of a resident grid has at most 24 members: 12 per thread); then half 0 + half 1
                 constexpr int MAXM = (3 * 256 + XCD_GROUPS - 1) / XCD_GROUPS;      // members of a group at the residual kernel's largest grid (3 blocks per CU)
-                bool same_xcc = true;
                 if (tid < 2 * SYS_N) {
                     const int hh = tid / SYS_N, e2 = tid - hh * SYS_N;
                     const double *col = partials + (size_t) g * SYS_N + e2;          // member m = block g + XCD_GROUPS m
@@ -2037,19 +2047,13 @@ __global__ __launch_bounds__(BLK, 3) void k_residual_reduce(MapView map, KpView 
 #pragma unroll
                         for (int q = 0; q < (MAXM + 1) / 2; ++q) v[q] = (m0 + 2 * q < members) ? sc1_load(col + (size_t) (m0 + 2 * q) * XCD_GROUPS * SYS_N) : 0.0;
 #pragma unroll
-                        for (int q = 0; q < (MAXM + 1) / 2; ++q) {
-                            if (e2 == XCD_PAD_ENTRY) same_xcc = same_xcc && (m0 + 2 * q >= members || v[q] == (double) my_xcc);
-                            else sum += v[q];
-                        }
+                        for (int q = 0; q < (MAXM + 1) / 2; ++q) sum += v[q];
                     }
                     s_comb[hh][e2] = sum;
                 }
-                const bool placed = __syncthreads_and(same_xcc ? 1 : 0) != 0;
-                if (tid < SYS_N) xr.rec[(size_t) g * SYS_N + tid] = tid == XCD_PAD_ENTRY ? 0.0 : s_comb[0][tid] + s_comb[1][tid];
-                if (tid == 0) {
-                    if (placed) __hip_atomic_store(xr.ctl + 32 * g + 1, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // this group's record is this launch's
-                    else __hip_atomic_store(xr.ctl + 32 * XCD_GROUPS, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // a member ran behind another L2: void
-                }
+                __syncthreads();
+                if (tid < SYS_N) xr.rec[(size_t) g * SYS_N + tid] = s_comb[0][tid] + s_comb[1][tid];
+                if (tid == 0) __hip_atomic_store(xr.ctl + 32 * g + 2, xr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this group's record is this launch's
             }
         }
     }
@@ -2150,7 +2154,7 @@ __device__ __forceinline__ void reduce_partials(const double *partials, int nblo
         double sum = 0.0;
 #pragma unroll
         for (int g = 0; g < G; ++g) sum += s_tmp[g * SYS_N + tid];
-        if (tid >= SYS_USED) sum = 0.0;            // pad entries (a block record's last one may carry its XCC id, XcdReduce)
+        if (tid >= SYS_USED) sum = 0.0;            // pad entries
         sys_global[tid] = sum;
         s_sys[tid] = sum;
     }
@@ -2368,7 +2372,7 @@ __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, i
         // kernel 8 us, more than the reduction it replaces)
         bool groups = false;
         if (xr.ctl != nullptr && nblocks >= XCD_GROUPS) {
-            const unsigned int stamp = xr.ctl[32 * (lane & (XCD_GROUPS - 1)) + 1], bad = xr.ctl[32 * XCD_GROUPS];
+            const unsigned int stamp = xr.ctl[32 * (lane & (XCD_GROUPS - 1)) + 2], bad = xr.ctl[32 * XCD_GROUPS];
             groups = ballot64(stamp == xr.epoch && bad != xr.epoch) == ~0ull;
         }
         if (xr.ctl != nullptr && tid == 0) xr.ctl[32 * XCD_GROUPS + 1] = groups ? 1u : 0u;       // which sum this launch took (ctgn_path_counters)

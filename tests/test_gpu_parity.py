@@ -697,7 +697,8 @@ def test_per_xcd_presums_change_nothing_but_the_summation_order(config_b_full):
     """Round 5, ctgn_kernels.hpp XcdReduce: on a full sweep the residual kernel's per-block records (518 of them) are pre-summed by the
     last block of each of 32 groups (four per XCD, each out of its own L2) and the solve kernel adds 32 group records: same keypoints
     used, system equal up to summation order, poses to rounding — and the path must actually have run (ctgn_path_counters), with the
-    placement check holding on this part; the pad entries of the packed system stay zero (a block record's last one carries its XCC id)."""
+    placement check (per-XCC arrival counts inside the groups' 64-bit tickets) holding on this part; the pad entries of the packed system
+    stay zero."""
     gm, sc = config_b_full
     pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=4)
     world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t, sc.raw)
