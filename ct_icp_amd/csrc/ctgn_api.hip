@@ -77,8 +77,8 @@ struct Tuning {
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
-    double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = automatic (launch_accumulate), else that many
-    double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 64 blocks on), 0 / 1 = never / always
+    double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
+    double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
 };
 static double *tuning_slot(Tuning &t, const std::string &key) {
 #define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
@@ -679,7 +679,7 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
     // records to sum instead of 2 048 (config D: 0.6931 -> 0.6858 ms per iteration; 1 024: 0.6872, 1 536: 0.6885)
     const int grid = std::max(1, std::min(tiles256, env_cap > 0 ? env_cap : std::min(h->res_grid_cap, 3 * h->num_cus)));
     // per-XCD pre-sums of the block records (XcdReduce, ctgn_kernels.hpp) once there are enough records for the solve kernel's own
-    // reduction to show: B2 (518 records) solve kernel 13.5 -> ?? us
+    // reduction to show: B2 (518 records) solve kernel 13.7 -> 8.3 us, residual kernel + 1.5 us, -4 us per iteration; D (768) 19.1 -> 10.7 us
     const int env_xr = (int) tuning().xcd_reduce;
     const bool xr_on = env_xr >= 0 ? (env_xr != 0 && grid >= XCD_GROUPS) : grid >= 4 * XCD_GROUPS;
     if (xr_on) {

@@ -26,7 +26,9 @@ ctgn_status ctgn_set_ablation(ctgn_handle h, int32_t mask);
  * on the difference: identical gate decisions and n_used, normals to ~1e-12), 3 = fast only. Takes effect at the next ctgn_gn_begin /
  * solve. Bits 16-17 of the ablation mask override it; bit 18 toggles the first-search cull of the 27-voxel sweep's second probe batch,
  * bit 19 switches the split pool-check launches off and bit 25 forces them on below their size threshold, bit 22 switches the wave-shared
- * probes of the 125-voxel sweep off, bit 24 the guessed first-search bound (A/B hooks; these bits leave results valid). */
+ * probes of the 125-voxel sweep off, bit 24 the guessed first-search bound, bit 26 the 125-voxel sweep's early stop after the probe batches
+ * some row can reach, bit 27 the reuse of the wave's probe table across rounds of one home voxel, bit 29 the pools of searches whose
+ * carried-over bound lies beyond the radius (A/B hooks; these bits leave results valid). */
 ctgn_status ctgn_set_normals(ctgn_handle h, int32_t mode);
 /* The guessed bound of a first search (ctgn_api.hip, launch_accumulate; rows_tiles pass 1): factor < 0 = automatic (1.25 x the radius k
  * neighbours fill on a surface at the searched level's points per voxel, used only when its square is below 0.8 of the squared search radius), 0 = off,
