@@ -92,7 +92,9 @@ class FrameOutputs(C.Structure):
     _fields_ = [("all_world_base", C.c_void_p), ("all_world_stride_bytes", C.c_size_t), ("all_world_dtype", C.c_int32),
                 ("_pad0", C.c_int32), ("sampled_indices", C.c_void_p), ("sampled_world_base", C.c_void_p),
                 ("sampled_world_stride_bytes", C.c_size_t), ("sampled_world_dtype", C.c_int32), ("_pad1", C.c_int32),
-                ("keypoint_indices", C.c_void_p), ("num_sampled", C.c_uint64), ("num_keypoints", C.c_uint64)]
+                ("keypoint_indices", C.c_void_p), ("num_sampled", C.c_uint64), ("num_keypoints", C.c_uint64),
+                ("keypoint_world_base", C.c_void_p), ("keypoint_world_stride_bytes", C.c_size_t), ("keypoint_world_dtype", C.c_int32),
+                ("_pad2", C.c_int32), ("num_keypoint_candidates", C.c_uint64)]
 
 
 class View(C.Structure):
@@ -142,6 +144,10 @@ SYMBOLS = {
     "ctgn_frame_register": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
                                       C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior),
                                       C.POINTER(FrameOutputs), C.POINTER(Summary)]),
+    "ctgn_frame_begin": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(FrameOutputs)]),
+    "ctgn_frame_try_register": (C.c_int, [_H, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior),
+                                          C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.POINTER(FrameOutputs), C.POINTER(Summary)]),
+    "ctgn_frame_undistort": (C.c_int, [_H, _dp, _dp, C.POINTER(FrameOutputs)]),
     "ctgn_frame_update_map": (C.c_int, [_H, _dp, C.c_double, C.c_int32, C.c_void_p]),
     "ctgn_frame": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
                              C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.c_double,

@@ -104,6 +104,12 @@ static Tuning &tuning() {
                 at = end + 1;
             }
         }
+        // the per-switch variables of rounds 1-4 are no longer read: say so once, instead of letting an old session script measure the same
+        // configuration twice
+        for (const char *legacy : {"CTGN_ORDER", "CTGN_GRAPH", "CTGN_POOL_MIN", "CTGN_PERSISTENT", "CTGN_HOST_THREADS", "CTGN_FRAME_TIMING",
+                                   "CTGN_PERSIST_TIMES", "CTGN_RES_SMALL", "CTGN_SPLIT", "CTGN_XCD_SPLIT", "CTGN_FUSE_SMALL", "CTGN_GUESS_FACTOR"})
+            if (std::getenv(legacy))
+                std::fprintf(stderr, "[ctgn] %s is ignored: the measurement switches are CTGN_TUNING=\"key=value,...\" (ctgn_api.hip, struct Tuning)\n", legacy);
         return v;
     }();
     return t;
@@ -259,6 +265,12 @@ struct ctgn_context {
         int *h_counts = nullptr;        // pinned
         size_t cap = 0, stride = 0, n = 0, n1 = 0, n2 = 0;
         bool valid = false;             // a registered frame is resident (ctgn_frame_update_map may insert it)
+        // the step-by-step form (ctgn_frame_begin / _try_register / _undistort): what the later steps need from the earlier ones
+        bool staged = false;            // ctgn_frame_begin left a sampled scan on the device
+        bool direct_in = false;         // ... read in place from page-locked caller arrays (h_scan holds no records then)
+        double tmin = 0, tmax = 0;      // timestamp range of the staged scan
+        double frame_voxel = 0, kp_voxel = 0;   // voxel sizes the two samplers last ran with (d_sel1 / d_sel2 belong to them)
+        std::vector<uint32_t> order;    // the caller's processing order (empty: scan order)
     } fr;
 
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
@@ -539,7 +551,7 @@ ctgn_status make_map_view(ctgn_handle h, double radius, MapView *mv) {
 //    kernel's gathers coherent, worth ~5e-5 us per keypoint and iteration (6-9 us at 132 k), against a sort + permute of
 //    ~60 us + 1.5e-4 us per keypoint (seven short launches). Ordered when the caller's iteration budget covers that — a
 //    132 k-keypoint scan from 13 iterations on; a loop that stops early on its threshold has then paid ~80 us for nothing.
-// Never below 32 k keypoints. ctgn_set_ordering (or CTGN_ORDER=0 / 1 in the environment, for whole test-suite runs) forces it
+// Never below 32 k keypoints. ctgn_set_ordering (or CTGN_TUNING="order=0" / "order=1" in the environment, for whole test-suite runs) forces it
 // off / on.
 bool want_order(ctgn_handle h, uint64_t level_points) {
     const int env_forced = (int) tuning().order;
@@ -2035,7 +2047,7 @@ ctgn_status ctgn_transform_points(ctgn_handle h, ctgn_view raw, ctgn_view ts, si
     // behind the pose and go up chunk by chunk while the next chunk is being gathered; every chunk's kernel writes x y z records that
     // come back into pinned memory on a second stream, beside the uploads of the chunks behind them. Once everything is gathered (and
     // every timestamp checked: nothing reaches the caller's output before that) the chunks are handed over as they arrive. The step
-    // moves 56 bytes per point across PCIe for a few flops. Measured on the B2 scan (132 k points, 7.4 MB; CTGN_FRAME_TIMING marks):
+    // moves 56 bytes per point across PCIe for a few flops. Measured on the B2 scan (132 k points, 7.4 MB; tuning frame_timing marks):
     // gathered and enqueued after 0.17 ms, handed over at 0.28 ms; on one stream 0.35 ms (the copies then queue behind one another);
     // 16 k chunks cost more in runtime calls than they gain in overlap (0.39 ms); helper threads for the hand-over do not pay (0.30 ms).
     constexpr size_t CHUNK = 32768;
@@ -2208,41 +2220,38 @@ static ctgn_status frame_finish_map_update(ctgn_handle h) {
     return CTGN_OK;
 }
 
-static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
-                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
-                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
-                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance);
-// An error return must not leave transfers in flight: with page-locked caller arrays the DMA engine reads and writes the CALLER's
-// memory, which the caller may free as soon as the call is back.
-static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
-                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
-                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
-                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
-    const ctgn_status st = frame_register_body(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, fused_max_distance);
-    if (st != CTGN_OK && h && h->device >= 0) {
-        (void) hipStreamSynchronize(h->stream);
-        if (h->stream_down) (void) hipStreamSynchronize(h->stream_down);
-        (void) hipGetLastError();
-    }
-    return st;
+// every scan point's world point from the pinned read-back (F.h_out: x y z rows when all_rows, three planes c apart otherwise, both in
+// processing order) into the rows of the caller's array, a chunk per helper thread
+static void frame_scatter_all(ctgn_handle h, size_t n, size_t c, const uint32_t *order, const ctgn_frame_outputs *out, bool all_rows) {
+    auto &F = h->fr;
+    constexpr size_t CHUNK = 16384;
+    const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
+    char *ob = static_cast<char *>(out->all_world_base);
+    const size_t os = out->all_world_stride_bytes;
+    const bool o64 = out->all_world_dtype == CTGN_F64;
+    h->pool.run((n + CHUNK - 1) / CHUNK, [&](size_t k) {
+        const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
+        if (all_rows) {
+            std::memcpy(ob + j0 * os, F.h_out + 3 * j0, (j1 - j0) * 3 * sizeof(double));
+        } else if (o64) {
+            for (size_t j = j0; j < j1; ++j) {
+                double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
+                q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
+            }
+        } else {
+            for (size_t j = j0; j < j1; ++j) {
+                float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
+                q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
+            }
+        }
+    });
 }
-static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
-                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
-                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
-                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
-    NEED_DEVICE(h);
-    if (summary) std::memset(summary, 0, sizeof(*summary));
-    if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
-    if (!fo || !pose_io || !tbe || (!opts && !robust)) return CTGN_ERR_INVALID_ARGUMENT;
-    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
-    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
-    if (n && (on_device(raw.base) || on_device(ts.base)))
-        return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_register takes host views (the stage entry points accept device memory)");
-    const auto t_call = std::chrono::steady_clock::now();
-    // CTGN_FRAME_TIMING=1: host-clock marks of the call's phases on stderr (measurement hook; no extra synchronisation)
-    const bool timing = tuning().frame_timing != 0;
-    double marks[8] = {0};
-    auto mark = [&](int k) { if (timing) marks[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
+
+// Stage one scan for the frame pipeline: the caller's records -> x y z t records in processing order behind the pose (F.d_scan), uploaded
+// chunk by chunk while the next chunk is being staged; timestamp range -> F.tmin / F.tmax, checked against [t_begin, t_end]. Everything is
+// enqueued on the handle's stream; nothing of an earlier frame is valid afterwards.
+static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
+                               const double pose_io[14], const double tbe[2]) {
     auto &F = h->fr;
     HIPCHK(h, hipStreamSynchronize(h->stream));       // pinned staging reuse
     {
@@ -2254,10 +2263,11 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     // chunk is being staged
     const size_t c = std::min((n + 63) & ~(size_t) 63, F.cap);                      // plane stride of the undistorted outputs
     F.valid = false;
+    F.staged = false;
+    F.order.clear();
     F.stride = c; F.n = n; F.n1 = 0; F.n2 = 0;
     for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];
     double *hs = F.h_scan + 16;
-    const double *d_recs = F.d_scan + 16;
     double tmin = INFINITY, tmax = -INFINITY;
     constexpr size_t CHUNK = 16384;
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
@@ -2364,6 +2374,57 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         hipStreamSynchronize(h->stream);
         return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
     }
+    F.tmin = tmin; F.tmax = tmax; F.direct_in = direct_in;
+    return CTGN_OK;
+}
+
+static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance);
+// An error return must not leave transfers in flight: with page-locked caller arrays the DMA engine reads and writes the CALLER's
+// memory, which the caller may free as soon as the call is back.
+static ctgn_status frame_register_impl(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
+    const ctgn_status st = frame_register_body(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary, fused_max_distance);
+    if (st != CTGN_OK && h && h->device >= 0) {
+        (void) hipStreamSynchronize(h->stream);
+        if (h->stream_down) (void) hipStreamSynchronize(h->stream_down);
+        (void) hipGetLastError();
+    }
+    return st;
+}
+static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order,
+                                       const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                       const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                       ctgn_frame_outputs *out, ctgn_summary *summary, const double *fused_max_distance) {
+    NEED_DEVICE(h);
+    if (summary) std::memset(summary, 0, sizeof(*summary));
+    if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
+    if (!fo || !pose_io || !tbe || (!opts && !robust)) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    if (n && (on_device(raw.base) || on_device(ts.base)))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_register takes host views (the stage entry points accept device memory)");
+    const auto t_call = std::chrono::steady_clock::now();
+    // CTGN_TUNING="frame_timing=1": host-clock marks of the call's phases on stderr (measurement hook; no extra synchronisation)
+    const bool timing = tuning().frame_timing != 0;
+    double marks[8] = {0};
+    auto mark = [&](int k) { if (timing) marks[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
+    auto &F = h->fr;
+    {
+        ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose_io, tbe);
+        if (ss != CTGN_OK) return ss;
+    }
+    const size_t c = F.stride;                                                      // plane stride of the undistorted outputs
+    const double *hs = F.h_scan + 16;
+    const double *d_recs = F.d_scan + 16;
+    const double tmin = F.tmin, tmax = F.tmax;
+    const bool direct_in = F.direct_in;
+    const bool no_direct = tuning().frame_no_direct != 0;
+    const char *rb = static_cast<const char *>(raw.base);
     mark(0);                                          // staged + upload enqueued
     // ---- both samplers, then the one read-back that sizes the launches
     DMCHK(h, devmap_frame_sampling(h->dm, d_recs, 1, 4, n, fo->frame_voxel_size, fo->sample_voxel_size, F.d_flag1, F.d_flag2, F.d_sel1, F.d_sel2,
@@ -2519,28 +2580,8 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     if (out) {
         out->num_sampled = n1;
         out->num_keypoints = n2;
-        if (want_all && !direct_out) {
-            const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
-            char *ob = static_cast<char *>(out->all_world_base);
-            const size_t os = out->all_world_stride_bytes;
-            const bool o64 = out->all_world_dtype == CTGN_F64;
-            h->pool.run((n + CHUNK - 1) / CHUNK, [&](size_t k) {           // the rows of the caller's array, a chunk per thread
-                const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
-                if (all_rows) {
-                    std::memcpy(ob + j0 * os, F.h_out + 3 * j0, (j1 - j0) * 3 * sizeof(double));
-                } else if (o64) {
-                    for (size_t j = j0; j < j1; ++j) {
-                        double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
-                        q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
-                    }
-                } else {
-                    for (size_t j = j0; j < j1; ++j) {
-                        float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
-                        q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
-                    }
-                }
-            });
-        }
+        out->num_keypoint_candidates = (uint64_t) F.h_counts[1];
+        if (want_all && !direct_out) frame_scatter_all(h, n, c, order, out, all_rows);
         if (out->sampled_world_base)
             for (size_t k = 0; k < n1; ++k)
                 write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
@@ -2607,6 +2648,185 @@ ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, con
     ctgn_status st = ctgn_frame_register(h, raw, ts, n, order, fo, pose_io, tbe, opts, prior, robust, robust_prior, out, summary);
     if (st != CTGN_OK) return st;
     return ctgn_frame_update_map(h, pose_io + 11, max_distance, summary->success, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------- the frame pipeline, step by step
+// The same stages as frame_register_body behind the entry points a caller needs when it keeps Odometry::DoRegister's own control flow:
+// InitializeFrame (odometry.cpp:333-382) -> ctgn_frame_begin; TryRegister (:525-601), possibly several times on the same sampled frame (the
+// robust retry loop, :794-845) -> ctgn_frame_try_register; the two undistortion loops (:461-486) with the poses the HOST settled on ->
+// ctgn_frame_undistort; UpdateMap (:936-952) -> ctgn_frame_update_map. integration/odometry_gpu_arm.h is that caller.
+static ctgn_status frame_sample(ctgn_handle h, double frame_voxel, double kp_voxel) {
+    auto &F = h->fr;
+    DMCHK(h, devmap_frame_sampling(h->dm, F.d_scan + 16, 1, 4, F.n, frame_voxel, kp_voxel, F.d_flag1, F.d_flag2, F.d_sel1, F.d_sel2, F.d_counts, h->stream));
+    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    F.n1 = (size_t) F.h_counts[0];
+    F.n2 = (size_t) F.h_counts[1];
+    F.frame_voxel = frame_voxel;
+    F.kp_voxel = kp_voxel;
+    return CTGN_OK;
+}
+
+// the first 16 doubles of the scan block are the pose slot the undistortion kernels read
+static ctgn_status frame_upload_pose(ctgn_handle h, const double pose[14]) {
+    auto &F = h->fr;
+    for (int k = 0; k < 14; ++k) F.h_scan[k] = pose[k];
+    HIPCHK(h, hipMemcpyAsync(F.d_scan, F.h_scan, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return CTGN_OK;
+}
+
+static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
+                                    const double pose[14], const double tbe[2], ctgn_frame_outputs *out) {
+    NEED_DEVICE(h);
+    if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
+    if (!fo || !pose || !tbe) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    if (n && (on_device(raw.base) || on_device(ts.base)))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_begin takes host views (the stage entry points accept device memory)");
+    auto &F = h->fr;
+    {
+        ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose, tbe);
+        if (ss != CTGN_OK) return ss;
+    }
+    if (order) F.order.assign(order, order + n);
+    {
+        ctgn_status ss = frame_sample(h, fo->frame_voxel_size, fo->sample_voxel_size);
+        if (ss != CTGN_OK) return ss;
+    }
+    const size_t c = F.stride, n1 = F.n1;
+    if (out && out->sampled_indices && n1)
+        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out && out->sampled_world_base && n1) {      // the sampled frame under the initial estimate (odometry.cpp:371-375)
+        hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, F.d_scan + 16, F.d_corr, (int) n1, (size_t) 1,
+                           (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) F.d_sel1, c, (size_t) 4);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (out && (out->sampled_indices || out->sampled_world_base) && n1) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out) {
+        out->num_sampled = n1;
+        out->num_keypoints = fo->max_num_keypoints > 0 ? std::min<size_t>(F.n2, (size_t) fo->max_num_keypoints) : F.n2;
+        out->num_keypoint_candidates = F.n2;
+        if (out->sampled_indices)
+            for (size_t k = 0; k < n1; ++k) out->sampled_indices[k] = order ? order[F.h_sel[k]] : F.h_sel[k];
+        if (out->sampled_world_base)
+            for (size_t k = 0; k < n1; ++k)
+                write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
+                            F.h_out[4 * c + k], F.h_out[5 * c + k]);
+    }
+    F.staged = true;
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_frame_begin(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
+                             const double pose_initial[14], const double tbe[2], ctgn_frame_outputs *out) {
+    const ctgn_status st = frame_begin_body(h, raw, ts, n, order, fo, pose_initial, tbe, out);
+    if (st != CTGN_OK && h && h->device >= 0) {       // no transfer from the caller's arrays stays in flight behind an error
+        (void) hipStreamSynchronize(h->stream);
+        (void) hipGetLastError();
+    }
+    return st;
+}
+
+ctgn_status ctgn_frame_try_register(ctgn_handle h, const ctgn_frame_options *fo, double pose_io[14], const double tbe[2], const ctgn_options *opts,
+                                    const ctgn_motion_prior *prior, const ctgn_robust_options *robust, const ctgn_robust_prior *robust_prior,
+                                    ctgn_frame_outputs *out, ctgn_summary *summary) {
+    NEED_DEVICE(h);
+    if (summary) std::memset(summary, 0, sizeof(*summary));
+    if (out) out->num_keypoints = 0;
+    if (!fo || !pose_io || !tbe || (!opts && !robust)) return CTGN_ERR_INVALID_ARGUMENT;
+    auto &F = h->fr;
+    if (!F.staged) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no sampled scan is resident (ctgn_frame_begin)");
+    if (out) out->num_sampled = F.n1;
+    F.valid = false;                                   // d_corr is about to hold nothing the map may take
+    if (F.kp_voxel != fo->sample_voxel_size) {         // another keypoint voxel than the one sampled with (a robust retry): sample again
+        ctgn_status ss = frame_sample(h, F.frame_voxel, fo->sample_voxel_size);
+        if (ss != CTGN_OK) return ss;
+    }
+    size_t n2 = F.n2;
+    if (fo->max_num_keypoints > 0 && n2 > (size_t) fo->max_num_keypoints) n2 = (size_t) fo->max_num_keypoints;
+    h->pose_on_device = false;
+    {
+        ctgn_status rs = reserve_keypoints(h, n2);
+        if (rs != CTGN_OK) return rs;
+    }
+    const size_t kc = (size_t) h->kp_stride;
+    if (n2) {
+        ctgn_status ps = frame_upload_pose(h, pose_io);
+        if (ps != CTGN_OK) return ps;
+        hipLaunchKernelGGL(k_frame_keypoints, dim3(grid_for(n2)), dim3(256), 0, h->stream, F.d_scan + 16, F.d_sel2, (int) n2, h->d_kp, kc);
+        hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n2)), dim3(256), 0, h->stream, h->d_kp, h->d_kp + 4 * kc, (int) n2, kc,
+                           (const double *) F.d_scan, tbe[0], tbe[1]);
+        HIPCHK(h, hipGetLastError());
+    }
+    h->t_min = F.tmin; h->t_max = F.tmax;
+    h->kp_coherent = false;                            // a sampled frame in shuffled or scan order: let the cost model order large ones
+    {
+        ctgn_status ds = ensure_debug(h);
+        if (ds != CTGN_OK) return ds;
+    }
+    const bool want_world = out && out->keypoint_world_base && n2;
+    if (want_world && on_device(out->keypoint_world_base)) return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_try_register writes host memory");
+    h->prefetch_world = want_world;                    // the keypoints' final world points ride home with the final state
+    ctgn_status st = robust ? ctgn_solve_robust(h, pose_io, tbe, robust, robust_prior, summary) : ctgn_solve(h, pose_io, tbe, opts, prior, summary);
+    h->prefetch_world = false;
+    if (st != CTGN_OK) return st;
+    if (want_world) scatter_world_from_staging(h, out->keypoint_world_base, out->keypoint_world_stride_bytes, out->keypoint_world_dtype, n2);
+    if (out && out->keypoint_indices && n2) {
+        HIPCHK(h, hipMemcpyAsync(F.h_sel + F.stride, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const uint32_t *order = F.order.empty() ? nullptr : F.order.data();
+        for (size_t k = 0; k < n2; ++k) out->keypoint_indices[k] = order ? order[F.h_sel[F.stride + k]] : F.h_sel[F.stride + k];
+    }
+    if (out) { out->num_keypoints = n2; out->num_keypoint_candidates = F.n2; }
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const double tbe[2], ctgn_frame_outputs *out) {
+    NEED_DEVICE(h);
+    if (!pose || !tbe) return CTGN_ERR_INVALID_ARGUMENT;
+    auto &F = h->fr;
+    if (!F.staged) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no sampled scan is resident (ctgn_frame_begin)");
+    const size_t n = F.n, n1 = F.n1, c = F.stride;
+    if (out) { out->num_sampled = n1; }
+    // every point is undistorted: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
+    if (n && !(tbe[0] <= F.tmin && F.tmax <= tbe[1])) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+    const uint32_t *order = F.order.empty() ? nullptr : F.order.data();
+    const double *d_recs = F.d_scan + 16;
+    F.valid = false;
+    {
+        ctgn_status ps = frame_upload_pose(h, pose);
+        if (ps != CTGN_OK) return ps;
+    }
+    if (n1) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, d_recs, F.d_corr, (int) n1, (size_t) 1,
+                               (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) F.d_sel1, c, (size_t) 4);
+    const bool want_all = out && out->all_world_base && n;
+    const bool all_rows = want_all && !order && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
+    if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1,
+                                     (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, all_rows ? 1 : 0);
+    HIPCHK(h, hipGetLastError());
+    const bool direct_out = all_rows && tuning().frame_no_direct == 0 && host_pinned(out->all_world_base, n * 3 * sizeof(double));
+    // the sampled frame first: it is small, and the host scatters it while the scan-sized copy is still travelling
+    const bool want_sampled = out && out->sampled_world_base && n1;
+    if (want_sampled) {
+        HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (!h->ev_frame) HIPCHK(h, hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_frame, h->stream));
+    }
+    if (want_all)
+        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double),
+                                 hipMemcpyDeviceToHost, h->stream));
+    if (want_sampled) {
+        HIPCHK(h, hipEventSynchronize(h->ev_frame));
+        for (size_t k = 0; k < n1; ++k)
+            write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k], F.h_out[4 * c + k],
+                        F.h_out[5 * c + k]);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (want_all && !direct_out) frame_scatter_all(h, n, c, order, out, all_rows);
+    F.valid = true;                                    // d_corr = the sampled frame under these poses: ctgn_frame_update_map may insert it
+    return CTGN_OK;
 }
 
 // ---------------------------------------------------------------------------------------- robust-loss route

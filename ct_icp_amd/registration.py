@@ -285,6 +285,82 @@ class FramePipeline:
         return self._call(L.lib().ctgn_frame_register, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp,
                           want_all, want_sampled, (), all_world_out)
 
+    # ---- the same stages one by one (ctgn_frame_begin / _try_register / _undistort): the calls integration/odometry_gpu_arm.h makes from
+    # the reference's InitializeFrame, TryRegister and undistortion loops
+    def begin(self, raw, t, pose14, t_begin_end, order=None, override_timestamp=None, want_world=False) -> dict:
+        """InitializeFrame (odometry.cpp:333-382): stage + upload + sub_sample_frame (+ the keypoint sampler at sample_voxel_size).
+        Returns sampled_indices, num_keypoints and — want_world — the sampled frame under pose14 (the initial estimate)."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        n = len(raw)
+        pose = np.ascontiguousarray(pose14, dtype=np.float64)
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
+                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp))
+        out = L.FrameOutputs()
+        idx = np.zeros(max(n, 1), dtype=np.uint32)
+        out.sampled_indices = idx.ctypes.data
+        if want_world:
+            sw = np.zeros((max(n, 1), 3))
+            out.sampled_world_base, out.sampled_world_stride_bytes, out.sampled_world_dtype = sw.ctypes.data, 24, L.CTGN_F64
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            assert len(order) == n
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_frame_begin(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0), n,
+                                                 order.ctypes.data if order is not None else None, C.byref(fo), pose.ctypes.data_as(dp),
+                                                 tbe.ctypes.data_as(dp), C.byref(out)))
+        self._last_n, self._last_n1 = n, int(out.num_sampled)
+        res = dict(sampled_indices=idx[:out.num_sampled].copy(), num_keypoints=int(out.num_keypoints))
+        if want_world:
+            res["sampled_world"] = sw[:out.num_sampled].copy()
+        return res
+
+    def try_register(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None, sample_voxel_size=None, max_num_keypoints=None) -> dict:
+        """TryRegister (odometry.cpp:525-601) on the sampled frame begin() left on the device; may be called again with other options /
+        another sample_voxel_size (the robust retry loop). Returns pose, summary, keypoint_indices, keypoint_world."""
+        pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size if sample_voxel_size is None else sample_voxel_size),
+                            int(self.max_num_keypoints if max_num_keypoints is None else max_num_keypoints), 0, 0.0)
+        n1 = max(1, getattr(self, "_last_n1", 0))
+        out = L.FrameOutputs()
+        kp_idx = np.zeros(n1, dtype=np.uint32)
+        kp_world = np.zeros((n1, 3))
+        out.keypoint_indices = kp_idx.ctypes.data
+        out.keypoint_world_base, out.keypoint_world_stride_bytes, out.keypoint_world_dtype = kp_world.ctypes.data, 24, L.CTGN_F64
+        s = L.Summary()
+        dp = C.POINTER(C.c_double)
+        c_opts = c_prior = c_ropts = c_rprior = None
+        if options.solver == CERES:
+            c_ropts, c_rprior = _c_robust_options(options), _c_robust_prior(motion_model)
+        else:
+            c_opts, c_prior = _c_options(options), _c_prior(motion_model)
+        L.check(self._h, L.lib().ctgn_frame_try_register(
+            self._h, C.byref(fo), pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(c_opts) if c_opts is not None else None,
+            C.byref(c_prior) if c_prior is not None else None, C.byref(c_ropts) if c_ropts is not None else None,
+            C.byref(c_rprior) if c_rprior is not None else None, C.byref(out), C.byref(s)))
+        m = int(out.num_keypoints)
+        return dict(pose=pose, summary=_summary(s), keypoint_indices=kp_idx[:m].copy(), keypoint_world=kp_world[:m].copy())
+
+    def undistort(self, pose14, t_begin_end, want_all=True) -> dict:
+        """The two undistortion loops (odometry.cpp:461-486) with the poses the caller settled on; leaves the undistorted sampled frame
+        on the device for update_map(). Returns sampled_world and (want_all) all_world."""
+        pose = np.ascontiguousarray(pose14, dtype=np.float64)
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        n, n1 = getattr(self, "_last_n", 0), getattr(self, "_last_n1", 0)
+        out = L.FrameOutputs()
+        res = {}
+        if want_all:
+            res["all_world"] = np.zeros((n, 3))
+            out.all_world_base, out.all_world_stride_bytes, out.all_world_dtype = res["all_world"].ctypes.data, 24, L.CTGN_F64
+        sw = np.zeros((max(n1, 1), 3))
+        out.sampled_world_base, out.sampled_world_stride_bytes, out.sampled_world_dtype = sw.ctypes.data, 24, L.CTGN_F64
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_frame_undistort(self._h, pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp), C.byref(out)))
+        res["sampled_world"] = sw[:n1]
+        return res
+
     def update_map(self, location, max_distance: float, add_points: bool = True) -> np.ndarray | None:
         """UpdateMap for the frame register() left on the device; returns the `inserted` mask of the sampled frame."""
         loc = np.ascontiguousarray(location, dtype=np.float64)

@@ -45,7 +45,10 @@
 extern "C" {
 #endif
 
-#define CTGN_ABI_VERSION 5
+/* ABI history: 6 (round 6) = ctgn_frame_outputs grew keypoint_world_* at its end + ctgn_frame_begin / _try_register / _undistort;
+ * 5 (round 5) = ctgn_count_traffic, ctgn_kernel_timing_split and ctgn_set_variant left this header for ctgn_internal.h (the symbols are
+ * still exported; they are measurement hooks, not part of the contract). */
+#define CTGN_ABI_VERSION 6
 #define CTGN_MAX_RESOLUTIONS 8
 /* The hard-coded "not enough keypoints" bound of the reference (src/ct_icp/ct_icp.cpp:860). */
 #define CTGN_MIN_KEYPOINTS_USED 100
@@ -427,6 +430,12 @@ typedef struct {                         /* any pointer may be NULL = not wanted
     uint32_t *keypoint_indices;          /* capacity n: scan index of every keypoint                                             */
     uint64_t num_sampled;                /* out                                                                                  */
     uint64_t num_keypoints;              /* out                                                                                  */
+    void *keypoint_world_base;           /* ctgn_frame_try_register only; capacity num_keypoints records: the keypoints' world points
+                                            under the optimised poses (registration_summary.keypoints, odometry.cpp:597)         */
+    size_t keypoint_world_stride_bytes;
+    ctgn_dtype keypoint_world_dtype;
+    int32_t _pad2;
+    uint64_t num_keypoint_candidates;    /* out: keypoints before the max_num_keypoints cut (>= num_keypoints)                    */
 } ctgn_frame_outputs;
 
 /* Sampling -> keypoints -> registration -> undistortion of one scan. `robust` NULL: the GN route with `opts` (+ `prior`, may be
@@ -439,6 +448,27 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw_xyz, ctgn_view time
                                 const ctgn_frame_options *fopts, double pose_io[14], const double t_begin_end[2],
                                 const ctgn_options *opts, const ctgn_motion_prior *prior, const ctgn_robust_options *robust,
                                 const ctgn_robust_prior *robust_prior, ctgn_frame_outputs *out, ctgn_summary *summary);
+/* The same stages one by one, for a caller that keeps Odometry::DoRegister's own control flow around them — integration/odometry_gpu_arm.h
+ * puts them behind the reference's InitializeFrame, TryRegister, undistortion loops and UpdateMap:
+ *   ctgn_frame_begin         InitializeFrame (odometry.cpp:333-382): the scan is staged in processing order (`order` as above) and uploaded,
+ *                            sub_sample_frame runs on it, and — fopts->sample_voxel_size being the keypoint voxel the first TryRegister will
+ *                            ask for — the keypoint sampler behind it. out (may be NULL): sampled_indices, sampled_world_* = the sampled frame
+ *                            under pose_initial (odometry.cpp:371-375), num_sampled, num_keypoints.
+ *   ctgn_frame_try_register  TryRegister (odometry.cpp:525-601) on the resident sampled frame, any number of times (the robust retry loop,
+ *                            :794-845): keypoints = grid_sampling at fopts->sample_voxel_size (sampled again only if it differs from the last
+ *                            run's), the first max_num_keypoints of them; their world points from pose_io (the caller's current estimate, not
+ *                            ctgn_frame_begin's); then ctgn_solve / ctgn_solve_robust. out: keypoint_indices, keypoint_world_*, num_keypoints.
+ *   ctgn_frame_undistort     odometry.cpp:461-486 with the poses the host settled on (`pose` need not be what the registration returned):
+ *                            out->all_world_* = every scan point, out->sampled_world_* = the sampled frame; the latter stays on the device as
+ *                            the batch ctgn_frame_update_map inserts.
+ * fopts->frame_voxel_size / override_timestamp(s) are read by ctgn_frame_begin only. Same error conventions as ctgn_frame_register. */
+ctgn_status ctgn_frame_begin(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const uint32_t *order,
+                             const ctgn_frame_options *fopts, const double pose_initial[14], const double t_begin_end[2],
+                             ctgn_frame_outputs *out);
+ctgn_status ctgn_frame_try_register(ctgn_handle h, const ctgn_frame_options *fopts, double pose_io[14], const double t_begin_end[2],
+                                    const ctgn_options *opts, const ctgn_motion_prior *prior, const ctgn_robust_options *robust,
+                                    const ctgn_robust_prior *robust_prior, ctgn_frame_outputs *out, ctgn_summary *summary);
+ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const double t_begin_end[2], ctgn_frame_outputs *out);
 /* UpdateMap for the resident frame (odometry.cpp:936-952): RemoveElementsFarFromLocation(location, max_distance) on every level,
  * then — if add_points — insert the sampled frame's undistorted points. Needs the device-resident map (ctgn_map_set_update_mode 1).
  * inserted (host, num_sampled bytes, may be NULL): 1 where the point entered some level. */

@@ -6,6 +6,10 @@
 //   map_kind 0: MultipleResolutionVoxelMap::Options  (`map_type: MULTI_RESOLUTION_VOXEL_HASHMAP`, the reference's CPU map and CPU solver loops)
 //   map_kind 1: GpuVoxelMap::Options                 (`map_type: GPU_VOXEL_HASHMAP`, integration/gpu_map.h; Register reaches libctgn.so through
 //                                                     the one-line arms of integration/gn_gpu_arm.h, every map call through ISlamMap)
+//   map_kind 2: the same with `frame_pipeline` on:   in oracle/_ref/libctgn_ref_odometry_armed.so — odometry.cpp compiled with the four arms of
+//                                                     integration/odometry_gpu_arm.h — InitializeFrame, TryRegister, the undistortion loops and
+//                                                     the map half of UpdateMap run on the device too (map_kind 1 there: the arms stand down).
+//                                                     In the un-armed library the flag has nothing to switch and kind 2 is refused.
 // Nothing of Odometry is restated here: the functions below fill an OdometryOptions, construct ct_icp::Odometry and call RegisterFrame.
 // extern "C" so that the tests can feed both instances the same scans from Python (tests/test_odometry_glue.py, tests/odometry_vs_reference.py);
 // linked into oracle/_ref/libctgn_ref_odometry.so by oracle/Makefile (target `odometry`) with the reference's sources + libctgn.so.
@@ -20,6 +24,9 @@
 
 #include <ct_icp/odometry.h>
 #include <ct_icp/gpu_map.h>
+#ifdef CTGN_GLUE_ARMED
+#include <ct_icp/odometry_gpu_arm.h>
+#endif
 
 namespace {
     struct OdometryUnderTest {
@@ -104,6 +111,11 @@ struct glue_odometry_result {
     double milliseconds;             // wall time of the RegisterFrame call
     int32_t success, points_added, sample_size, number_of_residuals, number_of_attempts, robust_level, icp_num_iters, num_corrected;
     uint64_t map_points;             // only filled on request (O(map) on the CPU map)
+    // where the call's time went, from the reference's own logged_values (odometry.cpp:210-211,428,495-499), milliseconds:
+    // [0] odometry_total  [1] odometry_initialization(ms) = InitializeFrame + log  [2] odometry_try_register (0 on the robust-registration
+    // path, which does not log it)  [3] odometry_transform(ms) = the undistortion loops  [4] odometry_map_update(ms)  [5] odometry_initialization
+    // = compute_frame_info + InitializeMotion
+    double phase_ms[6];
 };
 
 const char *glue_odometry_last_error() { return g_error.c_str(); }
@@ -153,10 +165,14 @@ int glue_odometry_start(void *h, int map_kind) {
             mo->max_frames_to_keep = 1;                                    // src/ct_icp/map.cpp:63 reads it; the old loader sets 1 (:18)
             u->options.map_options = mo;
         } else {
+#ifndef CTGN_GLUE_ARMED
+            if (map_kind == 2) throw std::runtime_error("map kind 2 needs the armed library (oracle/_ref/libctgn_ref_odometry_armed.so)");
+#endif
             auto mo = std::make_shared<ct_icp::GpuVoxelMap::Options>();
             mo->resolutions = u->resolutions;
             mo->default_radius = u->default_radius;
             mo->device = u->device;
+            mo->frame_pipeline = map_kind == 2;
             u->options.map_options = mo;
         }
         u->map_kind = map_kind;
@@ -164,16 +180,26 @@ int glue_odometry_start(void *h, int map_kind) {
         const std::string want = map_kind == 0 ? "MULTI_RESOLUTION_VOXEL_HASHMAP" : "GPU_VOXEL_HASHMAP";
         if (u->options.map_options->GetType() != want) throw std::runtime_error("map options of the wrong type");
         const bool is_gpu = dynamic_cast<ct_icp::GpuVoxelMap *>(u->odometry->GetMapPointer().get()) != nullptr;
-        if (is_gpu != (map_kind == 1)) throw std::runtime_error("Odometry built the other map kind");
+        if (is_gpu != (map_kind >= 1)) throw std::runtime_error("Odometry built the other map kind");
     });
+}
+
+// 1 in oracle/_ref/libctgn_ref_odometry_armed.so, 0 in the un-armed library
+int glue_odometry_is_armed() {
+#ifdef CTGN_GLUE_ARMED
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 void glue_odometry_destroy(void *h) { delete static_cast<OdometryUnderTest *>(h); }
 
 // One Odometry::RegisterFrame(const slam::PointCloud&, frame_id) call (odometry.cpp:209-224). xyz: n x 3 raw points, t: n timestamps.
 // world_out (optional): n x 3, summary.all_corrected_points' world points (the undistorted scan, odometry.cpp:461-476).
+// sampled_raw_out (optional, capacity n x 3): the raw points of summary.corrected_points, i.e. the sampled frame (out->num_corrected rows).
 int glue_odometry_register_frame(void *h, const double *xyz, const double *t, size_t n, int frame_id, glue_odometry_result *out, double *world_out,
-                                 int want_map_points) {
+                                 int want_map_points, double *sampled_raw_out) {
     auto *u = static_cast<OdometryUnderTest *>(h);
     return guarded([&] {
         if (!u->odometry) throw std::runtime_error("glue_odometry_start was not called");
@@ -212,6 +238,15 @@ int glue_odometry_register_frame(void *h, const double *xyz, const double *t, si
         out->icp_num_iters = summary.icp_summary.num_iters;
         out->num_corrected = (int32_t) summary.corrected_points.size();
         out->map_points = want_map_points ? (uint64_t) u->odometry->MapSize() : 0;
+        const char *keys[6] = {"odometry_total", "odometry_initialization(ms)", "odometry_try_register", "odometry_transform(ms)",
+                               "odometry_map_update(ms)", "odometry_initialization"};
+        for (int k = 0; k < 6; ++k) {
+            auto it = summary.logged_values.find(keys[k]);
+            out->phase_ms[k] = it == summary.logged_values.end() ? 0.0 : it->second;
+        }
+        if (sampled_raw_out)
+            for (size_t i = 0; i < summary.corrected_points.size() && i < n; ++i)
+                for (int c = 0; c < 3; ++c) sampled_raw_out[3 * i + c] = summary.corrected_points[i].RawPoint()[c];
         if (world_out && summary.all_corrected_points.size() == n)
             for (size_t i = 0; i < n; ++i)
                 for (int c = 0; c < 3; ++c) world_out[3 * i + c] = summary.all_corrected_points[i].WorldPoint()[c];

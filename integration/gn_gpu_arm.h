@@ -51,6 +51,60 @@ namespace ct_icp {
             summary.avg_duration_solve = s.avg_duration_solve_ms;
             return summary;
         }
+
+        // the CTICPOptions fields DoRegisterGaussNewton reads (ct_icp.cpp:727,743,762,803,866,978)
+        inline void gn_options_of(const CTICPOptions &options, ctgn_options *co) {
+            ctgn_options_default(co);
+            co->num_iters_icp = options.num_iters_icp;
+            co->min_number_neighbors = options.min_number_neighbors;
+            co->max_number_neighbors = options.max_number_neighbors;
+            co->debug_print = options.debug_print ? 1 : 0;
+            co->max_dist_to_plane_ct_icp = options.max_dist_to_plane_ct_icp;
+            co->threshold_orientation_norm = options.threshold_orientation_norm;
+        }
+
+        inline void gn_prior_of(const PreviousFrameMotionModel &model, ctgn_motion_prior *prior) {       // ct_icp.cpp:885-908
+            prior->beta_location_consistency = model.GetOptionsConst().beta_location_consistency;
+            prior->beta_constant_velocity = model.GetOptionsConst().beta_constant_velocity;
+            for (int c = 0; c < 3; ++c) {
+                prior->previous_begin_tr[c] = model.PreviousFrame().BeginTr()[c];
+                prior->previous_end_tr[c] = model.PreviousFrame().EndTr()[c];
+            }
+        }
+
+        // the CTICPOptions fields DoRegisterCeres reads (ct_icp.h:58-132)
+        inline void robust_options_of(const CTICPOptions &options, ctgn_robust_options *ro) {
+            ctgn_robust_options_default(ro);
+            ro->num_iters_icp = options.num_iters_icp;
+            ro->min_number_neighbors = options.min_number_neighbors;
+            ro->max_number_neighbors = options.max_number_neighbors;
+            ro->debug_print = options.debug_print ? 1 : 0;
+            ro->max_num_residuals = options.max_num_residuals;
+            ro->loss_function = (int32_t) options.loss_function;                             // same enum order, ct_icp.h:41-47
+            ro->ls_max_num_iters = options.ls_max_num_iters;
+            ro->num_closest_neighbors = options.num_closest_neighbors;
+            ro->weight_alpha = options.weight_alpha;
+            ro->weight_neighborhood = options.weight_neighborhood;
+            ro->power_planarity = options.power_planarity;
+            ro->max_dist_to_plane_ct_icp = options.max_dist_to_plane_ct_icp;
+            ro->ls_sigma = options.ls_sigma;
+            ro->ls_tolerant_min_threshold = options.ls_tolerant_min_threshold;
+            ro->threshold_orientation_norm = options.threshold_orientation_norm;
+            ro->threshold_translation_norm = options.threshold_translation_norm;
+        }
+
+        inline void robust_prior_of(const PreviousFrameMotionModel &model, ctgn_robust_prior *prior) {   // motion_model.cpp:12-61
+            const auto &mo = model.GetOptionsConst();
+            prior->beta_location_consistency = mo.beta_location_consistency;
+            prior->beta_constant_velocity = mo.beta_constant_velocity;
+            prior->beta_small_velocity = mo.beta_small_velocity;
+            prior->beta_orientation_consistency = mo.beta_orientation_consistency;
+            for (int c = 0; c < 3; ++c) {
+                prior->previous_begin_tr[c] = model.PreviousFrame().BeginTr()[c];
+                prior->previous_end_tr[c] = model.PreviousFrame().EndTr()[c];
+            }
+            for (int c = 0; c < 4; ++c) prior->previous_end_quat[c] = model.PreviousFrame().EndQuat().coeffs()[c];
+        }
     }
 
     inline std::optional<ICPSummary> GpuGaussNewton(const ISlamMap &voxels_map,
@@ -66,21 +120,10 @@ namespace ct_icp {
             !ctgn_glue::view_of(timestamps, &ts))
             return std::nullopt;
         ctgn_options co;
-        ctgn_options_default(&co);
-        co.num_iters_icp = options.num_iters_icp;
-        co.min_number_neighbors = options.min_number_neighbors;
-        co.max_number_neighbors = options.max_number_neighbors;
-        co.debug_print = options.debug_print ? 1 : 0;
-        co.max_dist_to_plane_ct_icp = options.max_dist_to_plane_ct_icp;
-        co.threshold_orientation_norm = options.threshold_orientation_norm;
+        ctgn_glue::gn_options_of(options, &co);
         ctgn_motion_prior prior, *prior_ptr = nullptr;
         if (auto *model = dynamic_cast<const PreviousFrameMotionModel *>(motion_model)) {    // ct_icp.cpp:885-889
-            prior.beta_location_consistency = model->GetOptionsConst().beta_location_consistency;
-            prior.beta_constant_velocity = model->GetOptionsConst().beta_constant_velocity;
-            for (int c = 0; c < 3; ++c) {
-                prior.previous_begin_tr[c] = model->PreviousFrame().BeginTr()[c];
-                prior.previous_end_tr[c] = model->PreviousFrame().EndTr()[c];
-            }
+            ctgn_glue::gn_prior_of(*model, &prior);
             prior_ptr = &prior;
         }
         double pose[14], tbe[2];
@@ -105,35 +148,10 @@ namespace ct_icp {
             !ctgn_glue::view_of(raw_kpts, &raw) || !ctgn_glue::view_of(world_kpts, &world) || !ctgn_glue::view_of(timestamps, &ts))
             return std::nullopt;
         ctgn_robust_options ro;
-        ctgn_robust_options_default(&ro);
-        ro.num_iters_icp = options.num_iters_icp;
-        ro.min_number_neighbors = options.min_number_neighbors;
-        ro.max_number_neighbors = options.max_number_neighbors;
-        ro.debug_print = options.debug_print ? 1 : 0;
-        ro.max_num_residuals = options.max_num_residuals;
-        ro.loss_function = (int32_t) options.loss_function;                                  // same enum order, ct_icp.h:41-47
-        ro.ls_max_num_iters = options.ls_max_num_iters;
-        ro.num_closest_neighbors = options.num_closest_neighbors;
-        ro.weight_alpha = options.weight_alpha;
-        ro.weight_neighborhood = options.weight_neighborhood;
-        ro.power_planarity = options.power_planarity;
-        ro.max_dist_to_plane_ct_icp = options.max_dist_to_plane_ct_icp;
-        ro.ls_sigma = options.ls_sigma;
-        ro.ls_tolerant_min_threshold = options.ls_tolerant_min_threshold;
-        ro.threshold_orientation_norm = options.threshold_orientation_norm;
-        ro.threshold_translation_norm = options.threshold_translation_norm;
+        ctgn_glue::robust_options_of(options, &ro);
         ctgn_robust_prior prior, *prior_ptr = nullptr;
         if (auto *model = dynamic_cast<const PreviousFrameMotionModel *>(previous_frame)) {  // ct_icp.cpp:608-610, motion_model.cpp:12-61
-            const auto &mo = model->GetOptionsConst();
-            prior.beta_location_consistency = mo.beta_location_consistency;
-            prior.beta_constant_velocity = mo.beta_constant_velocity;
-            prior.beta_small_velocity = mo.beta_small_velocity;
-            prior.beta_orientation_consistency = mo.beta_orientation_consistency;
-            for (int c = 0; c < 3; ++c) {
-                prior.previous_begin_tr[c] = model->PreviousFrame().BeginTr()[c];
-                prior.previous_end_tr[c] = model->PreviousFrame().EndTr()[c];
-            }
-            for (int c = 0; c < 4; ++c) prior.previous_end_quat[c] = model->PreviousFrame().EndQuat().coeffs()[c];
+            ctgn_glue::robust_prior_of(*model, &prior);
             prior_ptr = &prior;
         }
         double pose[14], tbe[2];

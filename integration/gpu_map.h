@@ -9,7 +9,13 @@
 #ifndef CT_ICP_GPU_MAP_H
 #define CT_ICP_GPU_MAP_H
 
+#include <cstdint>
+#include <vector>
+
+#include <yaml-cpp/yaml.h>
+
 #include <ct_icp/map.h>
+#include <SlamCore/config_utils.h>
 #include <ctgn.h>
 
 namespace ct_icp {
@@ -41,6 +47,8 @@ namespace ct_icp {
             double default_radius = 0.8;
             int device = 0;
             bool device_updates = true;                                     // insert / evict rules run on the GPU (ctgn_map_set_update_mode)
+            bool frame_pipeline = true;                                     // Odometry::DoRegister's scan-sized loops run on the GPU too, where
+                                                                            // src/ct_icp/odometry.cpp carries the arms of odometry_gpu_arm.h
 
             static std::string Type() { return "GPU_VOXEL_HASHMAP"; }
 
@@ -71,6 +79,25 @@ namespace ct_icp {
         GpuVoxelMap(const GpuVoxelMap &) = delete;
 
         ctgn_handle handle() const { return handle_; }
+
+        const Options &GetOptions() const { return options_; }
+
+        // What the arms of odometry_gpu_arm.h hand from one step of Odometry::DoRegister to the next: the scan InitializeFrame's arm left
+        // on the device (ctgn_frame_begin) and the index lists that tie the host's vectors to it. Scratch vectors keep their capacity from
+        // frame to frame (a 132 k-point scan would otherwise cost a megabyte of page faults per frame).
+        struct FrameSession {
+            bool active = false;               // a sampled scan of THIS frame is resident
+            bool undistorted = false;          // ... and ctgn_frame_undistort has run on it (the map update may take it)
+            int registered_fid = -1;
+            size_t num_points = 0, num_sampled = 0;
+            std::vector<uint32_t> order;       // the first shuffle (odometry.cpp:349), as indices
+            std::vector<uint32_t> sampled;     // scan index of sampled point k
+            std::vector<uint32_t> position;    // position[sampled[k]] = k (only those entries are meaningful)
+            std::vector<uint32_t> keypoints;   // scan index of keypoint k
+            std::vector<double> world;         // world points of a read-back, x y z rows
+        };
+
+        FrameSession &frame_session() { return session_; }
 
         ////////////////////////////////////////////////////////////////////////////////////////////////////////////////
         /// UPDATE API (map.h:25-29, SlamCore/experimental/map.h:32-39)
@@ -212,7 +239,39 @@ namespace ct_icp {
 
         Options options_;
         ctgn_handle handle_ = nullptr;
+        FrameSession session_;
     };
+
+    // The YAML loader of `map_type: GPU_VOXEL_HASHMAP`: the keys of MULTI_RESOLUTION_VOXEL_HASHMAP (multi_resolution_map_options_from_yaml,
+    // src/ct_icp/map.cpp:32-65) + `device`, `device_updates`, `frame_pipeline`. The selector line in yaml_to_map_options (src/ct_icp/map.cpp:68-77):
+    //     if (map_type == GpuVoxelMap::Options::Type()) return gpu_map_options_from_yaml(node);
+    inline std::shared_ptr<ct_icp::IMapOptions> gpu_map_options_from_yaml(const YAML::Node &node) {
+        auto map_options = std::make_shared<GpuVoxelMap::Options>();
+        if (node["resolutions"]) {
+            auto resolutions_node = node["resolutions"];
+            SLAM_CHECK_STREAM(resolutions_node.IsSequence(), "The node 'resolutions' in the yaml is not a sequence:\n" << node);
+            map_options->resolutions.resize(0);
+            for (auto child_node: resolutions_node) {
+                SLAM_CHECK_STREAM(child_node.IsMap(), "The following child node is not a Map:\n" << child_node);
+                MultipleResolutionVoxelMap::ResolutionParam param;
+                FIND_OPTION(child_node, param, min_distance_between_points, double)
+                FIND_OPTION(child_node, param, max_num_points, double)
+                SLAM_CHECK_STREAM(child_node["resolution"], "Invalid Resolution Param in the yaml:\n" << child_node);
+                param.resolution = child_node["resolution"].as<double>();
+                map_options->resolutions.push_back(param);
+            }
+            SLAM_CHECK_STREAM(!map_options->resolutions.empty(), "The yaml does not define a valid set of resolutions for the map");
+            SLAM_CHECK_STREAM(map_options->resolutions.size() <= CTGN_MAX_RESOLUTIONS, "too many resolutions for libctgn");
+            std::sort(map_options->resolutions.begin(), map_options->resolutions.end(),
+                      [](const auto &lhs, const auto &rhs) { return lhs.resolution < rhs.resolution; });
+        }
+        FIND_OPTION(node, (*map_options), max_frames_to_keep, int)
+        FIND_OPTION(node, (*map_options), default_radius, double)
+        FIND_OPTION(node, (*map_options), device, int)
+        FIND_OPTION(node, (*map_options), device_updates, bool)
+        FIND_OPTION(node, (*map_options), frame_pipeline, bool)
+        return map_options;
+    }
 
 } // namespace ct_icp
 

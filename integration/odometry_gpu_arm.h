@@ -1,0 +1,273 @@
+// integration/odometry_gpu_arm.h — the GPU arms of ct_icp::Odometry::DoRegister (src/ct_icp/odometry.cpp:386-501): the scan-sized loops either
+// side of the registration handed to the same libctgn.so handle the map lives on, with the scan resident on the device from
+// InitializeFrame to UpdateMap. A maintainer drops this file into the reference tree as include/ct_icp/odometry_gpu_arm.h and adds
+// FOUR statements to src/ct_icp/odometry.cpp (after `#include <ct_icp/odometry_gpu_arm.h>`):
+//
+//   std::vector<slam::WPoint3D> Odometry::InitializeFrame(...) {                                          // :333, first statement
+//       if (auto gpu_frame = GpuInitializeFrame(map_.get(), const_frame, frame_info, options_, trajectory_[frame_info.registered_fid], g_))
+//           return std::move(*gpu_frame);
+//   void Odometry::TryRegister(...) {                                                                     // :525, first statement
+//       if (GpuTryRegister(map_.get(), frame, frame_info, options, registration_summary, sample_voxel_size, motion_model, options_, g_,
+//                          !callbacks_.empty())) return;
+//   // Distort the Frame using the current estimate                                                       // :461, the two loops become the else branch
+//       if (!GpuUndistortFrame(map_.get(), const_frame, frame_info, frame, summary, options_.ct_icp_options.ls_num_threads)) { ... :462-486 ... }
+//   map_->RemoveElementsFarFromLocation(location, kMaxDistance);                                          // :940, in front of it
+//       if (GpuUpdateMap(map_.get(), location, kMaxDistance, add_points)) {
+//           if (add_points) insertion_tracker_.InsertFrame(registered_fid); else insertion_tracker_.SkipFrame();
+//           return;
+//       }
+//
+// Everything else of Odometry is untouched and keeps deciding: InitializeMotion, the startup regimen, AssessRegistration (:604-684), the
+// robust retry loop (:780-852, it calls TryRegister — i.e. the arm — once per attempt on the same resident sampled frame), the insertion
+// policy of UpdateMap (:855-934), the trajectory. Every arm returns "not mine" (std::nullopt / false) and the reference's own code runs
+// when the map is not a GpuVoxelMap with `frame_pipeline`, when motion_compensation is not CONTINUOUS, for `sampling: ADAPTIVE`, for the
+// ROBUST solver or a CERES configuration libctgn has no route for, or when callbacks are registered (they are handed keypoints before
+// the registration, which the device only reports after it). oracle/Makefile applies exactly these insertions to the reference's
+// odometry.cpp on its way into the compiler (GLUE_PATCH2) and links the result into oracle/_ref/libctgn_ref_odometry_armed.so;
+// tests/test_odometry_glue.py runs it beside the un-armed library.
+//
+// The random stream. Odometry shuffles with its own std::mt19937_64 g_: the frame before sub_sample_frame (:349 — which point of a voxel
+// survives), the sampled frame (:361 — only the order robin_map's iteration left) and, above max_num_keypoints, the keypoints (:550).
+// std::shuffle's draws depend on the length of the range alone, so shuffling an INDEX vector with g_ gives the permutation the
+// reference applies to the points: the first shuffle is reproduced exactly and the sampled-frame SET of every frame is the reference's.
+// The other two shuffle what is already a uniformly random order here (the sampled frame stays in processing order, the keypoints are
+// its first points per voxel): the arms draw the same numbers from g_ (so the stream stays in step with an un-armed run, frame after
+// frame) and keep their order.
+#ifndef CT_ICP_ODOMETRY_GPU_ARM_H
+#define CT_ICP_ODOMETRY_GPU_ARM_H
+
+#include <algorithm>
+#include <numeric>
+#include <optional>
+#include <random>
+
+#include <ct_icp/odometry.h>
+#include <ct_icp/gn_gpu_arm.h>
+
+namespace ct_icp {
+
+    namespace ctgn_glue {
+        inline GpuVoxelMap *frame_pipeline_of(ISlamMap *map, const OdometryOptions &options) {
+            auto *gpu_map = dynamic_cast<GpuVoxelMap *>(map);
+            if (!gpu_map || !gpu_map->GetOptions().frame_pipeline || !gpu_map->GetOptions().device_updates) return nullptr;
+            if (options.motion_compensation != CONTINUOUS) return nullptr;       // TransformPoint's other modes (odometry.cpp:171-184)
+            if (options.sampling == sampling::ADAPTIVE) return nullptr;
+            const auto &icp = options.ct_icp_options;
+            if (icp.solver == ROBUST) return nullptr;
+            if (icp.solver == CERES && (icp.parametrization != CONTINUOUS_TIME || icp.distance != POINT_TO_PLANE)) return nullptr;
+            return gpu_map;
+        }
+
+        inline void fatal_unless_ok(ctgn_status st, ctgn_handle h) {             // the reference CHECK-aborts where libctgn reports
+            SLAM_CHECK_STREAM(st == CTGN_OK, "libctgn: " << ctgn_last_error(h));
+        }
+
+        // std::shuffle(first, last, g) for a range whose CONTENT does not matter: the same draws from g
+        inline void advance_like_shuffle(std::vector<uint32_t> &scratch, size_t n, std::mt19937_64 &g) {
+            scratch.resize(n);
+            std::shuffle(scratch.begin(), scratch.end(), g);
+        }
+    }
+
+    // InitializeFrame (odometry.cpp:333-382): shuffle, sub_sample_frame, timestamps of the first two frames, initial transform.
+    inline std::optional<std::vector<slam::WPoint3D>> GpuInitializeFrame(ISlamMap *map, const slam::PointCloud &const_frame,
+                                                                         const Odometry::FrameInfo &frame_info, const OdometryOptions &options,
+                                                                         const TrajectoryFrame &tr_frame, std::mt19937_64 &g) {
+        auto *gpu_map = ctgn_glue::frame_pipeline_of(map, options);
+        if (!gpu_map) return std::nullopt;
+        auto &session = gpu_map->frame_session();
+        session.active = false;
+        session.undistorted = false;
+        const auto view_timestamps = const_frame.TimestampsProxy<double>();
+        const auto view_xyz = const_frame.XYZConst<double>();
+        ctgn_view raw, ts;
+        const size_t n = const_frame.size();
+        if (n == 0 || !ctgn_glue::view_of(view_xyz, &raw) || !ctgn_glue::view_of(view_timestamps, &ts)) return std::nullopt;
+
+        const auto kIndexFrame = frame_info.registered_fid;
+        const bool kIsAtStartup = kIndexFrame < options.init_num_frames;
+        session.order.resize(n);
+        std::iota(session.order.begin(), session.order.end(), 0u);
+        std::shuffle(session.order.begin(), session.order.end(), g);                                       // :349
+
+        ctgn_frame_options fo;
+        ctgn_frame_options_default(&fo);
+        fo.frame_voxel_size = kIsAtStartup ? options.init_voxel_size : options.voxel_size;                 // :339-340
+        // the keypoint voxel TryRegister will ask for first (odometry.cpp:422-423, :1038-1039): sampled in the same pass
+        fo.sample_voxel_size = options.sampling == sampling::GRID
+                               ? (kIsAtStartup ? options.init_sample_voxel_size : options.sample_voxel_size) : -1.0;
+        fo.max_num_keypoints = -1;
+        fo.override_timestamps = kIndexFrame <= 1 ? 1 : 0;                                                 // :355-359
+        fo.override_timestamp = frame_info.end_timestamp;
+        double pose[14], tbe[2];
+        ctgn_glue::pose_to_array(tr_frame, pose, tbe);
+        session.sampled.resize(n);
+        session.world.resize(3 * n);
+        ctgn_frame_outputs out{};
+        out.sampled_indices = session.sampled.data();
+        out.sampled_world_base = session.world.data();                                                     // :371-375
+        out.sampled_world_stride_bytes = 3 * sizeof(double);
+        out.sampled_world_dtype = CTGN_F64;
+        ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw, ts, n, session.order.data(), &fo, pose, tbe, &out),
+                                   gpu_map->handle());
+        const size_t n1 = (size_t) out.num_sampled;
+        ctgn_glue::advance_like_shuffle(session.keypoints, n1, g);                                         // :361
+
+        std::vector<slam::WPoint3D> frame(n1);
+        session.position.resize(n);
+        for (size_t k = 0; k < n1; ++k) {
+            const size_t i = session.sampled[k];
+            session.position[i] = (uint32_t) k;
+            auto &point = frame[k];
+            point.raw_point.point = view_xyz[i];
+            point.raw_point.timestamp = kIndexFrame <= 1 ? frame_info.end_timestamp : double(view_timestamps[i]);
+            point.world_point = Eigen::Vector3d(session.world[3 * k], session.world[3 * k + 1], session.world[3 * k + 2]);
+            point.index_frame = frame_info.frame_id;                                                       // :377-379
+        }
+        session.registered_fid = kIndexFrame;
+        session.num_points = n;
+        session.num_sampled = n1;
+        session.active = true;
+        return frame;
+    }
+
+    // TryRegister (odometry.cpp:525-601): keypoints, startup regimen, Register, frame transform. The sampled frame is the one
+    // GpuInitializeFrame left on the device; `frame` is its host image.
+    inline bool GpuTryRegister(ISlamMap *map, std::vector<slam::WPoint3D> &frame, const Odometry::FrameInfo &frame_info,
+                               CTICPOptions &options, Odometry::RegistrationSummary &registration_summary, double sample_voxel_size,
+                               AMotionModel *motion_model, const OdometryOptions &odometry_options, std::mt19937_64 &g,
+                               bool callbacks_registered) {
+        auto *gpu_map = ctgn_glue::frame_pipeline_of(map, odometry_options);
+        if (!gpu_map || callbacks_registered) return false;
+        auto &session = gpu_map->frame_session();
+        if (!session.active || session.registered_fid != frame_info.registered_fid || frame.size() != session.num_sampled) return false;
+        if (options.solver == ROBUST ||
+            (options.solver == CERES && (options.parametrization != CONTINUOUS_TIME || options.distance != POINT_TO_PLANE)))
+            return false;
+        if (motion_model && !dynamic_cast<const PreviousFrameMotionModel *>(motion_model)) return false;
+
+        const auto kIndexFrame = frame_info.registered_fid;
+        const bool kIsAtStartup = kIndexFrame < odometry_options.init_num_frames;
+        const auto start = std::chrono::steady_clock::now();
+        ctgn_frame_options fo;
+        ctgn_frame_options_default(&fo);
+        fo.sample_voxel_size = odometry_options.sampling == sampling::GRID ? sample_voxel_size : -1.0;     // :537-547
+        fo.max_num_keypoints = !kIsAtStartup && odometry_options.max_num_keypoints > 0 ? odometry_options.max_num_keypoints : -1;   // :549
+        if (kIsAtStartup) {                                                                                // :561-565
+            options.threshold_voxel_occupancy = 1;
+            options.num_iters_icp = std::max(options.num_iters_icp, 15);
+        }
+
+        ctgn_options co;
+        ctgn_robust_options ro;
+        ctgn_motion_prior prior, *prior_ptr = nullptr;
+        ctgn_robust_prior rprior, *rprior_ptr = nullptr;
+        const bool robust_route = options.solver == CERES;
+        auto *model = dynamic_cast<const PreviousFrameMotionModel *>(motion_model);
+        if (robust_route) {
+            ctgn_glue::robust_options_of(options, &ro);
+            if (model) { ctgn_glue::robust_prior_of(*model, &rprior); rprior_ptr = &rprior; }
+        } else {
+            ctgn_glue::gn_options_of(options, &co);
+            if (model) { ctgn_glue::gn_prior_of(*model, &prior); prior_ptr = &prior; }
+        }
+        double pose[14], tbe[2];
+        ctgn_glue::pose_to_array(registration_summary.frame, pose, tbe);
+        session.keypoints.resize(session.num_sampled);
+        session.world.resize(3 * std::max(session.num_points, session.num_sampled));
+        ctgn_frame_outputs out{};
+        out.keypoint_indices = session.keypoints.data();
+        out.keypoint_world_base = session.world.data();
+        out.keypoint_world_stride_bytes = 3 * sizeof(double);
+        out.keypoint_world_dtype = CTGN_F64;
+        ctgn_summary s;
+        const ctgn_status st = ctgn_frame_try_register(gpu_map->handle(), &fo, pose, tbe, robust_route ? nullptr : &co, prior_ptr,
+                                                       robust_route ? &ro : nullptr, rprior_ptr, &out, &s);
+        if (st == CTGN_ERR_SOLVER) throw std::runtime_error("Error During Optimization");                  // ct_icp.cpp:628-631
+        if (out.num_keypoint_candidates > out.num_keypoints) {                                             // :549-552
+            std::vector<uint32_t> scratch;
+            ctgn_glue::advance_like_shuffle(scratch, (size_t) out.num_keypoint_candidates, g);
+        }
+        const size_t n2 = (size_t) out.num_keypoints;
+        registration_summary.sample_size = (int) n2;                                                       // :554-555
+        registration_summary.logged_values["odometry_duration_sampling"] = 0.;
+        if (st == CTGN_OK) ctgn_glue::array_to_pose(pose, registration_summary.frame);
+        registration_summary.icp_summary = ctgn_glue::to_summary(st, s, gpu_map->handle());                // :575-579
+        registration_summary.success = registration_summary.icp_summary.success;
+        registration_summary.number_of_residuals = registration_summary.icp_summary.num_residuals_used;
+        registration_summary.logged_values["odometry_gpu_try_register"] =
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count();
+        if (!registration_summary.success) return true;                                                    // :584-587
+
+        // :589-595 (the frame's world points under the new poses) is GpuUndistortFrame's work: DoRegister transforms the same points
+        // with the same poses again at :480-486. The keypoints with the world points the registration left them with (:597):
+        registration_summary.keypoints.resize(n2);
+        for (size_t k = 0; k < n2; ++k) {
+            auto &point = registration_summary.keypoints[k];
+            point = frame[session.position[session.keypoints[k]]];
+            point.world_point = Eigen::Vector3d(session.world[3 * k], session.world[3 * k + 1], session.world[3 * k + 2]);
+        }
+        return true;
+    }
+
+    // The two undistortion loops of DoRegister (odometry.cpp:461-486).
+    inline bool GpuUndistortFrame(ISlamMap *map, const slam::PointCloud &const_frame, const Odometry::FrameInfo &frame_info,
+                                  const std::vector<slam::WPoint3D> &frame, Odometry::RegistrationSummary &summary, int num_threads) {
+        auto *gpu_map = dynamic_cast<GpuVoxelMap *>(map);
+        if (!gpu_map) return false;
+        auto &session = gpu_map->frame_session();
+        if (!session.active || session.registered_fid != frame_info.registered_fid || frame.size() != session.num_sampled ||
+            const_frame.size() != session.num_points)
+            return false;
+        const size_t n = session.num_points;
+        summary.corrected_points = frame;                                                                  // :462
+        summary.all_corrected_points.resize(n);                                                            // :463
+        auto raw_points_view = const_frame.XYZConst<double>();
+        auto timestamps_view = const_frame.TimestampsProxy<double>();
+        const auto &begin_pose = summary.frame.begin_pose;
+        const auto &end_pose = summary.frame.end_pose;
+        // the first two frames were staged with every timestamp at the end of the sweep (:355-359), but all_corrected_points carries the
+        // points' own timestamps (:473): those two frames take the reference's loop for it
+        const bool all_on_device = session.registered_fid > 1;
+#pragma omp parallel for num_threads(num_threads)
+        for (auto i = 0; i < summary.all_corrected_points.size(); ++i) {                                   // :470-478
+            auto &point = summary.all_corrected_points[i];
+            point.RawPoint() = raw_points_view[i];
+            point.Timestamp() = timestamps_view[i];
+            point.index_frame = frame_info.frame_id;
+            if (!all_on_device) point.WorldPoint() = begin_pose.ContinuousTransform(point.RawPoint(), end_pose, point.Timestamp());
+        }
+        double pose[14], tbe[2];
+        ctgn_glue::pose_to_array(summary.frame, pose, tbe);
+        ctgn_frame_outputs out{};
+        if (all_on_device) {
+            out.all_world_base = summary.all_corrected_points[0].world_point.data();
+            out.all_world_stride_bytes = sizeof(slam::WPoint3D);
+            out.all_world_dtype = CTGN_F64;
+        }
+        if (!summary.corrected_points.empty()) {
+            out.sampled_world_base = summary.corrected_points[0].world_point.data();                       // :480-486
+            out.sampled_world_stride_bytes = sizeof(slam::WPoint3D);
+            out.sampled_world_dtype = CTGN_F64;
+        }
+        ctgn_glue::fatal_unless_ok(ctgn_frame_undistort(gpu_map->handle(), pose, tbe, &out), gpu_map->handle());
+        session.undistorted = true;
+        return true;
+    }
+
+    // The map half of UpdateMap (odometry.cpp:936-952): far-voxel eviction round the new location, then the corrected sampled frame —
+    // taken from where GpuUndistortFrame left it on the device.
+    inline bool GpuUpdateMap(ISlamMap *map, const Eigen::Vector3d &location, double max_distance, bool add_points) {
+        auto *gpu_map = dynamic_cast<GpuVoxelMap *>(map);
+        if (!gpu_map) return false;
+        auto &session = gpu_map->frame_session();
+        if (!session.active || !session.undistorted) return false;
+        const double loc[3] = {location[0], location[1], location[2]};
+        ctgn_glue::fatal_unless_ok(ctgn_frame_update_map(gpu_map->handle(), loc, max_distance, add_points ? 1 : 0, nullptr), gpu_map->handle());
+        session.active = false;
+        return true;
+    }
+
+} // namespace ct_icp
+
+#endif //CT_ICP_ODOMETRY_GPU_ARM_H

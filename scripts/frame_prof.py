@@ -1,8 +1,8 @@
-"""Phase timings of the frame pipeline on the bench's B2 frame (CTGN_FRAME_TIMING marks on stderr)."""
+"""Phase timings of the frame pipeline on the bench's B2 frame (CTGN_TUNING="frame_timing=1" marks on stderr)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CTGN_FRAME_TIMING"] = "1"
+os.environ["CTGN_TUNING"] = (os.environ.get("CTGN_TUNING", "") + ",frame_timing=1").lstrip(",")
 import bench
 import ct_icp_amd as cia
 from ct_icp_amd import synthetic as syn

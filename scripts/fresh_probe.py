@@ -34,7 +34,7 @@ for rep in range(3):
     sync(); print("  50 back-to-back solves: %.1f us per solve" % ((time.perf_counter() - t0) / 50 * 1e6))
     s.gn_end()
 
-if os.environ.get("CTGN_PERSIST_TIMES"):
+if "persist_times=1" in os.environ.get("CTGN_TUNING", ""):
     tl = s.wave_timeline(256).astype(np.int64)          # rows: iteration start, arrive, barrier passed, reduce done (10 ns ticks)
     t0 = tl[:, 0].min()
     print("blocks", len(tl), "start spread %.1f us" % ((tl[:, 0].max() - t0) / 100), " arrive (us after first start): min %.1f med %.1f max %.1f" %

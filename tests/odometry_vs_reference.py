@@ -3,6 +3,8 @@
   ref-cpu   the REFERENCE'S OWN ct_icp::Odometry::RegisterFrame (oracle/_ref/libctgn_ref_odometry.so: src/ct_icp/odometry.cpp compiled where it
             lies) on its own MULTI_RESOLUTION_VOXEL_HASHMAP — AssessRegistration, insertion policy, the init regime, everything
   ref-gpu   the same Odometry object code on GPU_VOXEL_HASHMAP (integration/gpu_map.h + the solver arms, libctgn.so underneath)
+  ref-gpu-armed   odometry.cpp compiled with the four arms of integration/odometry_gpu_arm.h (oracle/_ref/libctgn_ref_odometry_armed.so):
+            InitializeFrame, TryRegister, the undistortion loops and the map half of UpdateMap on the device as well
   ctgn      ct_icp_amd.sequence_runner: one ctgn_frame call per frame (the product's own loop, what bench.py's config_e times)
 
 The sequences are SURVEY.md 8d's config E (config-B generator, seeds 10-20, KITTI lengths / scale). All three loops start from the identity
@@ -58,8 +60,9 @@ def relative_truth(knots, j):
 
 def run_reference(scans, map_kind, solver, extra):
     from oracle import ref_odometry as ro
-    od = ro.RefOdometry(ro.GPU_MAP if map_kind == "gpu" else ro.CPU_MAP, solver=ro.GN if solver == "GN" else ro.CERES, **extra)
-    poses, rec = [], dict(success=[], residuals=[], keypoints=[], points_added=[], ms=[])
+    kind = {"cpu": ro.CPU_MAP, "gpu": ro.GPU_MAP, "gpu-armed": ro.GPU_MAP_ARMED}[map_kind]
+    od = ro.RefOdometry(kind, solver=ro.GN if solver == "GN" else ro.CERES, **extra)
+    poses, rec = [], dict(success=[], residuals=[], keypoints=[], points_added=[], ms=[], attempts=[], sampled=[], phases={k: [] for k in ro.PHASES})
     for raw, t, _ in scans:
         r = od.register_frame(raw, t)
         poses.append(r["pose"])
@@ -67,7 +70,11 @@ def run_reference(scans, map_kind, solver, extra):
         rec["residuals"].append(int(r["number_of_residuals"]))
         rec["keypoints"].append(int(r["sample_size"]))
         rec["points_added"].append(bool(r["points_added"]))
+        rec["attempts"].append(int(r["number_of_attempts"]))
+        rec["sampled"].append(int(r["num_corrected"]))
         rec["ms"].append(float(r["milliseconds"]))
+        for k, v in r["phase_ms"].items():
+            rec["phases"][k].append(float(v))
     return np.array(poses), rec
 
 
@@ -113,7 +120,7 @@ def main():
     for solver in args.solver.split(","):
         for impl in args.impl.split(","):
             t0 = time.perf_counter()
-            if impl in ("ref-cpu", "ref-gpu"):
+            if impl in ("ref-cpu", "ref-gpu", "ref-gpu-armed"):
                 p, rec = run_reference(scans, impl[4:], solver, extra)
             else:
                 p, rec = run_ctgn(scans, solver, impl == "ctgn-ref-regime")
@@ -136,7 +143,18 @@ def main():
                                        err_tr_max_after_rigid_alignment=float(aligned.max()), err_tr_rms_after_rigid_alignment=float(np.sqrt((aligned ** 2).mean())),
                                        first_frame_beyond_2m=lost, err_tr_every_10=[round(float(e), 4) for e in err[::10, 0]],
                                        keypoints_mean=float(np.mean(rec["keypoints"][2:])) if frames > 2 else 0.0,
-                                       ms_per_frame_mean=float(np.mean(rec["ms"])))
+                                       ms_per_frame_mean=float(np.mean(rec["ms"])), ms_per_frame_median=float(np.median(rec["ms"])),
+                                       ms_per_frame_mean_after_startup=float(np.mean(rec["ms"][25:])) if frames > 30 else None)
+            if "phases" in rec:
+                # where the reference's RegisterFrame spends its call, from its own logged_values (steady state: past the 20-frame start-up
+                # regime): compute_frame_info + InitializeMotion | InitializeFrame | TryRegister | the undistortion loops | UpdateMap; the
+                # rest of `total` is LogSummary and the summary's copies
+                lo = 25 if frames > 30 else 0
+                table = {k: round(float(np.mean(v[lo:])), 4) for k, v in rec["phases"].items()}
+                table["unaccounted"] = round(table["total"] - sum(table[k] for k in table if k != "total"), 4)
+                result["runs"][key]["host_time_table_ms"] = table
+                result["runs"][key]["sampled_frame_points_mean"] = float(np.mean(rec["sampled"][lo:]))
+                result["runs"][key]["attempts_max"] = int(max(rec["attempts"]))
             log(f"{key}: {seconds:.1f} s, failures {len(fails)} (first {fails[0] if fails else None}), max |dt| {err[:, 0].max():.3f} m, "
                 f"final {err[-1, 0]:.3f} m, beyond 2 m at frame {lost}; after rigid alignment max {aligned.max():.3f} m")
     keys = list(poses)

@@ -35,23 +35,25 @@ def test_library_exports_every_declared_symbol():
     # the contract header carries no ablation / instrumentation / test entry points
     assert not [n for n in declared if re.search(r"ablation|phase_cycles|wave_timeline|traffic_counters|ctgn_test_|count_traffic|timing_split|set_variant|upload_bytes", n)]
     assert set(declared) | set(internal) == set(L.SYMBOLS), (set(declared) | set(internal)) ^ set(L.SYMBOLS)
-    assert lib.ctgn_abi_version() == 5
+    assert lib.ctgn_abi_version() == 6
 
 
 def test_struct_layouts_match_the_header(tmp_path):
     """Compile a tiny C program against include/ctgn.h and compare sizeof/offsetof with the ctypes mirror."""
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ctgn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ctgn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(ctgn_map_options),sizeof(ctgn_options),sizeof(ctgn_motion_prior),sizeof(ctgn_summary),'
                     'sizeof(ctgn_view),sizeof(ctgn_resolution_param),offsetof(ctgn_summary,error_log),'
                     'offsetof(ctgn_map_options,initial_voxel_capacity),sizeof(ctgn_adaptive_sampling_options),'
-                    'offsetof(ctgn_adaptive_sampling_options,voxel_size));return 0;}\n')
+                    'offsetof(ctgn_adaptive_sampling_options,voxel_size),sizeof(ctgn_frame_outputs),offsetof(ctgn_frame_outputs,num_sampled),'
+                    'offsetof(ctgn_frame_outputs,keypoint_world_dtype),sizeof(ctgn_frame_options));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [C.sizeof(L.MapOptions), C.sizeof(L.Options), C.sizeof(L.MotionPrior), C.sizeof(L.Summary), C.sizeof(L.View),
             C.sizeof(L.ResolutionParam), L.Summary.error_log.offset, L.MapOptions.initial_voxel_capacity.offset,
-            C.sizeof(L.AdaptiveSamplingOptions), L.AdaptiveSamplingOptions.voxel_size.offset]
+            C.sizeof(L.AdaptiveSamplingOptions), L.AdaptiveSamplingOptions.voxel_size.offset, C.sizeof(L.FrameOutputs),
+            L.FrameOutputs.num_sampled.offset, L.FrameOutputs.keypoint_world_dtype.offset, C.sizeof(L.FrameOptions)]
     assert got == want
 
 

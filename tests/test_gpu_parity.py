@@ -932,6 +932,91 @@ def test_sequence_of_frames_end_to_end(street_case):
 
 
 @pytest.mark.parametrize("shuffled", [False, True])
+def test_frame_steps_equal_the_one_call_pipeline(street_case, shuffled):
+    """ctgn_frame_begin / ctgn_frame_try_register / ctgn_frame_undistort / ctgn_frame_update_map — the calls integration/odometry_gpu_arm.h makes
+    from the reference's InitializeFrame, TryRegister, undistortion loops and UpdateMap — against ctgn_frame_register + ctgn_frame_update_map,
+    which the test below pins to the stage calls and those to the oracle: identical sampled frame, keypoints, poses (bit for bit), undistorted
+    points, insert masks and maps, GN and robust route; a retry on the same resident frame with another keypoint voxel equals a fresh
+    one-call frame at that voxel; the keypoints' world points are the final poses applied to their raw points; undistortion with poses
+    the HOST chose (not the registration's) is what the map then receives."""
+    case = street_case
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    mk = lambda: cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius,
+                                                        device_updates=True))
+    ga, gb, gc = mk(), mk(), mk()             # a: one call, b: step by step, c: stage calls
+    fa = cia.FramePipeline(ga, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    fb = cia.FramePipeline(gb, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    o = _opts(num_iters_icp=5, threshold_orientation_norm=1e-4, min_number_neighbors=10)
+    o0 = _opts(num_iters_icp=0)
+    rng = np.random.default_rng(5)
+    for j in range(5):                        # map bootstrap through both spellings (no registration: the undistortion takes pose_gt)
+        sc = case["scans"][j]
+        order = rng.permutation(len(sc.t)).astype(np.uint32) if shuffled else None
+        a = fa.register(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, o0, order=order)
+        mask_a = fa.update_map(a["pose"][11:14], 60.0, True)
+        b0 = fb.begin(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, order=order, want_world=True)
+        assert np.array_equal(a["sampled_indices"], b0["sampled_indices"]) and b0["num_keypoints"] == len(a["keypoint_indices"])
+        b2 = fb.undistort(sc.pose_gt, sc.t_begin_end)
+        assert np.array_equal(a["sampled_world"], b2["sampled_world"]) and np.array_equal(a["all_world"], b2["all_world"])
+        assert np.array_equal(b0["sampled_world"], b2["sampled_world"])          # the initial estimate IS the final pose here
+        mask_b = fb.update_map(sc.pose_gt[11:14], 60.0, True)
+        assert np.array_equal(mask_a, mask_b)
+    prev = case["scans"][4].pose_gt.copy()
+    for j in range(5, 10):
+        sc = case["scans"][j]
+        order = rng.permutation(len(sc.t)).astype(np.uint32) if shuffled else None
+        pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=j)
+        mm = cia.PreviousFrameMotionModel()
+        mm.previous_frame = cia.TrajectoryFrame.from_pose14(prev, 0.0, 0.0)
+        options = o if j != 7 else cia.CTICPOptions(solver=cia.CERES, num_iters_icp=4, ls_max_num_iters=4, min_number_neighbors=10,
+                                                    debug_print=False)
+        a = fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, options, motion_model=mm, order=order)
+        b0 = fb.begin(sc.raw, sc.t, pose0, sc.t_begin_end, order=order, want_world=(j == 6))
+        assert np.array_equal(a["sampled_indices"], b0["sampled_indices"])
+        if j == 6:                            # InitializeFrame's transform (odometry.cpp:371-375): the sampled frame under the initial estimate
+            want = cia.transform_points(ga, sc.raw[b0["sampled_indices"]], sc.t[b0["sampled_indices"]], pose0, sc.t_begin_end)
+            assert np.array_equal(b0["sampled_world"], want)
+        if j == 8:                            # a first attempt with other settings, then the retry from the initial estimate (odometry.cpp:794-845)
+            first = fb.try_register(pose0, sc.t_begin_end, _opts(num_iters_icp=2, min_number_neighbors=10), motion_model=mm, sample_voxel_size=1.1)
+            assert first["summary"].success and len(first["keypoint_indices"]) < len(a["keypoint_indices"])
+            raw_p = sc.raw if order is None else sc.raw[order]                    # its keypoints = grid_sampling of the sampled frame at that voxel
+            keep = cia.grid_sampling(gc, raw_p, 0.5)
+            idx = keep if order is None else order[keep]
+            assert np.array_equal(first["keypoint_indices"], idx[cia.grid_sampling(gc, raw_p[keep], 1.1)])
+        b1 = fb.try_register(pose0, sc.t_begin_end, options, motion_model=mm)
+        assert a["summary"].success and b1["summary"].success and b1["summary"].num_iters > 0
+        assert a["summary"].num_residuals_used == b1["summary"].num_residuals_used and a["summary"].num_iters == b1["summary"].num_iters
+        assert np.array_equal(a["keypoint_indices"], b1["keypoint_indices"]) and np.array_equal(a["pose"], b1["pose"])
+        kp = b1["keypoint_indices"]
+        assert np.abs(b1["keypoint_world"] - cia.transform_points(ga, sc.raw[kp], sc.t[kp], b1["pose"], sc.t_begin_end)).max() < 1e-9
+        with pytest.raises(cia.CtgnError):    # nothing undistorted yet: the map has nothing to take
+            fb.update_map(b1["pose"][11:14], 60.0, True)
+        b2 = fb.undistort(b1["pose"], sc.t_begin_end)
+        assert np.array_equal(a["sampled_world"], b2["sampled_world"]) and np.array_equal(a["all_world"], b2["all_world"])
+        if j == 9:                            # the host settles on other poses (e.g. a rejected registration keeps the estimate): those count
+            b2 = fb.undistort(pose0, sc.t_begin_end)
+            idx = b0["sampled_indices"]
+            assert np.array_equal(b2["sampled_world"], cia.transform_points(ga, sc.raw[idx], sc.t[idx], pose0, sc.t_begin_end))
+            assert np.array_equal(b2["all_world"], cia.transform_points(ga, sc.raw, sc.t, pose0, sc.t_begin_end))
+            fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, o0, order=order, want_all=False)       # the same frame, unregistered, on the one-call side
+            a["pose"] = pose0
+        mask_a = fa.update_map(a["pose"][11:14], 60.0, True)
+        mask_b = fb.update_map(a["pose"][11:14], 60.0, True)
+        assert np.array_equal(mask_a, mask_b)
+        assert ga.NumPoints() == gb.NumPoints() and ga.NumVoxels(0) == gb.NumVoxels(0)
+        prev = b1["pose"]
+    assert np.array_equal(_sorted_rows(ga.MapAsPointCloud(0)), _sorted_rows(gb.MapAsPointCloud(0)))
+    # error paths: no resident scan on a fresh handle; timestamps outside the poses' interval at undistortion time
+    fresh = cia.FramePipeline(mk())
+    with pytest.raises(cia.CtgnError):
+        fresh.try_register(sc.pose_gt, sc.t_begin_end, o)
+    with pytest.raises(cia.CtgnError):
+        fresh.undistort(sc.pose_gt, sc.t_begin_end)
+    with pytest.raises(cia.CtgnError):
+        fb.undistort(sc.pose_gt, (sc.t_begin_end[0] + 0.05, sc.t_begin_end[1]))
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
 def test_frame_pipeline_equals_the_stage_by_stage_calls(street_case, shuffled):
     """ctgn_frame_register / ctgn_frame_update_map / ctgn_frame (scan resident on the device) against the same
     frame loop spelled with the stage entry points that the test above pins to the oracle: identical sampled frame, keypoints, poses

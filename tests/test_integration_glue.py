@@ -47,7 +47,7 @@ def test_glue_compiles_against_the_reference_headers_and_links():
 def test_integration_md_quotes_the_glue_files_verbatim():
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```cpp\n(.*?)```", md, flags=re.S)
-    for name in ("gpu_map.h", "gn_gpu_arm.h"):
+    for name in ("gpu_map.h", "gn_gpu_arm.h", "odometry_gpu_arm.h"):
         src = open(os.path.join(ROOT, "integration", name)).read()
         assert any(b.strip() == src.strip() for b in blocks), f"INTEGRATION.md must embed integration/{name} verbatim"
     # the real ProxyView members (SlamCore/data/view.h:113-116,186-189), not invented accessors

@@ -35,16 +35,66 @@ def street_sequence(frames: int, azimuth_steps: int, seed: int = 10, ramp_frames
 
 
 def test_library_builds_and_the_gpu_map_refuses_without_a_device():
-    assert ro.build() or os.path.exists(ro._SO)
-    L = ro.lib()
-    for sym in ("glue_odometry_options", "glue_odometry_set", "glue_odometry_start", "glue_odometry_register_frame", "glue_odometry_map_points"):
-        assert hasattr(L, sym)
+    assert ro.build() or (os.path.exists(ro._SO) and os.path.exists(ro._SO_ARMED))
+    for armed in (False, True):
+        L = ro.lib(armed)
+        for sym in ("glue_odometry_options", "glue_odometry_set", "glue_odometry_start", "glue_odometry_register_frame", "glue_odometry_map_points",
+                    "glue_odometry_is_armed"):
+            assert hasattr(L, sym)
+        assert L.glue_odometry_is_armed() == int(armed)
     with pytest.raises(KeyError):
         ro.RefOdometry(ro.CPU_MAP, no_such_option=1)
+    with pytest.raises(RuntimeError, match="armed library"):        # the un-armed library has no arms to switch on
+        L = ro.lib(False)
+        h = L.glue_odometry_options(0)
+        try:
+            if L.glue_odometry_start(h, ro.GPU_MAP_ARMED) != 0:
+                raise RuntimeError(L.glue_odometry_last_error().decode())
+        finally:
+            L.glue_odometry_destroy(h)
     import torch
     if not torch.cuda.is_available():
-        with pytest.raises(ro.NoDevice, match="no CPU fallback"):
-            ro.RefOdometry(ro.GPU_MAP)
+        for kind in (ro.GPU_MAP, ro.GPU_MAP_ARMED):
+            with pytest.raises(ro.NoDevice, match="no CPU fallback"):
+                ro.RefOdometry(kind)
+
+
+def test_the_armed_source_carries_exactly_the_documented_insertions():
+    """oracle/Makefile's GLUE_PATCH2 / GLUE_PATCH3 (what the armed library's odometry.cpp and map.cpp were compiled from) against the reference's
+    files: every line of the reference survives in order, and the inserted lines are the include, the four arm statements with the block they
+    open closed again, and the factory line — nothing else."""
+    import difflib
+    import subprocess
+    if not os.path.isdir(os.path.join(ro.REFERENCE_ROOT, "src", "ct_icp")):
+        pytest.skip("/root/reference absent: the patched stream is made from it at build time")
+    oracle_dir = os.path.dirname(os.path.abspath(ro.__file__))
+    for target, ref_file, want in (("glue-print2", "src/ct_icp/odometry.cpp",
+                                    ["#include <ct_icp/odometry_gpu_arm.h>", "GpuInitializeFrame(", "GpuUndistortFrame(", "}", "GpuTryRegister(", "GpuUpdateMap("]),
+                                   ("glue-print3", "src/ct_icp/map.cpp", ["#include <ct_icp/gpu_map.h>", "gpu_map_options_from_yaml(node)"])):
+        patched = subprocess.check_output(["make", "-s", "-C", oracle_dir, target], text=True).splitlines()
+        original = open(os.path.join(ro.REFERENCE_ROOT, ref_file)).read().splitlines()
+        added = []
+        for tag, i1, i2, j1, j2 in difflib.SequenceMatcher(None, original, patched, autojunk=False).get_opcodes():
+            assert tag in ("equal", "insert"), (target, tag, original[i1:i2], patched[j1:j2])
+            if tag == "insert":
+                added += [line.strip() for line in patched[j1:j2]]
+        assert len(added) == len(want), added
+        for line, fragment in zip(added, want):
+            assert fragment in line, (line, fragment)
+
+
+def test_the_arms_stand_down_on_the_reference_map():
+    """The armed library on MULTI_RESOLUTION_VOXEL_HASHMAP: every arm answers "not mine" and the reference's own code runs — same poses, bit
+    for bit, same map, as the library compiled from the untouched odometry.cpp (the random stream included: both shuffle the same g_)."""
+    scans, _ = street_sequence(6, 250)
+    kw = dict(solver=ro.CERES, ls_num_threads=1)
+    plain, armed = ro.RefOdometry(ro.CPU_MAP, **kw), ro.RefOdometry(ro.CPU_MAP, armed_library=True, **kw)
+    for raw, t in scans:
+        a, b = plain.register_frame(raw, t, want_sampled=True, want_map_points=True), armed.register_frame(raw, t, want_sampled=True, want_map_points=True)
+        assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["sampled_raw"], b["sampled_raw"])
+        for key in ("success", "sample_size", "number_of_residuals", "map_points"):
+            assert a[key] == b[key]
+    assert set(a["phase_ms"]) == set(ro.PHASES) and a["phase_ms"]["total"] > 0 and a["phase_ms"]["initialize_frame"] > 0
 
 
 def test_reference_odometry_runs_on_its_own_map():
@@ -93,3 +143,56 @@ def test_reference_register_frame_gives_the_same_trajectory_on_the_gpu_map(solve
     assert np.abs(pa[ka] - pb[kb]).max() < 1e-8
     print(f"Odometry::RegisterFrame x {frames} [{solver}]: max |pose(cpu map) - pose(gpu map)| = {worst:.2e}, world points {worst_world:.2e}, "
           f"{len(pa)} map points on both")
+
+
+def _rows_as_set(points: np.ndarray):
+    return set(map(bytes, np.ascontiguousarray(points)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["GN", "CERES"])
+def test_armed_register_frame_against_the_unarmed_one(solver):
+    """Odometry::RegisterFrame compiled with the four arms of integration/odometry_gpu_arm.h (oracle/_ref/libctgn_ref_odometry_armed.so, map kind
+    GPU_MAP_ARMED) beside the un-armed library on the same GPU map and on the reference's CPU map, 64 frames, GN and CERES profile:
+      * the first shuffle is reproduced: the sampled frame of EVERY frame is the same point set (corrected_points' raw points, bit for bit) —
+        which also proves g_ stays in step (the next frame's shuffle starts from the stream the previous frame left);
+      * same success flags, attempts, insertion decisions; the keypoints are another first-per-voxel choice from the same sampled frame (the
+        reference takes them in robin_map's iteration order, the device in processing order), so poses agree as two valid registrations of
+        the same frame do: inside the envelope the un-armed run itself keeps to the ground truth;
+      * all_corrected_points = the reference's own transform applied to the armed run's poses;
+      * with `frame_pipeline` off the armed library IS the un-armed one, bit for bit."""
+    frames = 64
+    scans, knots = street_sequence(frames, 500)
+    kw = dict(solver=ro.GN if solver == "GN" else ro.CERES, ls_num_threads=1)
+    plain = ro.RefOdometry(ro.GPU_MAP, **kw)
+    off = ro.RefOdometry(ro.GPU_MAP, armed_library=True, **kw)
+    armed = ro.RefOdometry(ro.GPU_MAP_ARMED, **kw)
+    from ct_icp_amd import se3
+    gap, ms = 0.0, {"plain": [], "armed": []}
+    for j, (raw, t) in enumerate(scans):
+        want_world = j in (0, 1, 2, 21, 40)
+        a = plain.register_frame(raw, t, want_sampled=True, want_map_points=(j % 8 == 0))
+        o = off.register_frame(raw, t, want_sampled=True, want_map_points=(j % 8 == 0))
+        b = armed.register_frame(raw, t, want_sampled=True, want_world=want_world, want_map_points=(j % 8 == 0))
+        assert np.array_equal(a["pose"], o["pose"]) and np.array_equal(a["sampled_raw"], o["sampled_raw"]) and a["map_points"] == o["map_points"]
+        assert _rows_as_set(a["sampled_raw"]) == _rows_as_set(b["sampled_raw"]), (solver, j, len(a["sampled_raw"]), len(b["sampled_raw"]))
+        for key in ("success", "points_added", "number_of_attempts", "num_corrected", "robust_level"):
+            assert a[key] == b[key], (solver, j, key, a[key], b[key])
+        assert a["success"] and a["sample_size"] == b["sample_size"]            # one keypoint per occupied voxel of the same sampled frame
+        assert np.array_equal(a["initial_pose"], b["initial_pose"]) or np.abs(a["initial_pose"] - b["initial_pose"]).max() < 0.05
+        gap = max(gap, float(np.abs(a["pose"][[4, 5, 6, 11, 12, 13]] - b["pose"][[4, 5, 6, 11, 12, 13]]).max()))
+        if want_world:
+            tbe = (t.min(), t.max())
+            want = se3.ct_transform(b["pose"], tbe, t, raw)
+            assert np.abs(b["world"] - want).max() < 1e-8, (solver, j)
+        if j >= 25:
+            ms["plain"].append(a["milliseconds"]); ms["armed"].append(b["milliseconds"])
+    truth = np.linalg.norm(syn.frame_pose14(knots, frames - 1)[11:14] - syn.frame_pose14(knots, 0)[4:7])
+    err_plain = abs(np.linalg.norm(a["pose"][11:14]) - truth)
+    err_armed = abs(np.linalg.norm(b["pose"][11:14]) - truth)
+    assert err_armed < max(2.0 * err_plain, 0.3), (err_plain, err_armed)
+    assert gap < 0.3, gap
+    pa, pb = plain.map_points(), armed.map_points()
+    assert abs(len(pa) - len(pb)) < 0.02 * len(pa)
+    print(f"Odometry::RegisterFrame x {frames} [{solver}] armed vs un-armed: identical sampled frames; max translation gap {gap:.3f} m; end-point error "
+          f"{err_plain:.3f} / {err_armed:.3f} m; {np.median(ms['plain']):.2f} -> {np.median(ms['armed']):.2f} ms per frame (median, frames 25+)")
