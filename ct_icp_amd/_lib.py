@@ -85,7 +85,7 @@ class AdaptiveSamplingOptions(C.Structure):
 
 class FrameOptions(C.Structure):
     _fields_ = [("frame_voxel_size", C.c_double), ("sample_voxel_size", C.c_double), ("max_num_keypoints", C.c_int32),
-                ("override_timestamps", C.c_int32), ("override_timestamp", C.c_double)]
+                ("override_timestamps", C.c_int32), ("override_timestamp", C.c_double), ("shuffle_seed", C.c_uint64)]
 
 
 class FrameOutputs(C.Structure):

@@ -271,6 +271,11 @@ struct ctgn_context {
         double tmin = 0, tmax = 0;      // timestamp range of the staged scan
         double frame_voxel = 0, kp_voxel = 0;   // voxel sizes the two samplers last ran with (d_sel1 / d_sel2 belong to them)
         std::vector<uint32_t> order;    // the caller's processing order (empty: scan order)
+        // device-side shuffle (ctgn_frame_options::shuffle_seed)
+        double *d_scan_in = nullptr;    // n records in scan order, as uploaded; k_frame_permute writes d_scan from them
+        uint32_t *d_order = nullptr;    // order[j] = scan index of the point at processing position j
+        uint32_t *h_order = nullptr;    // pinned copy (valid after the frame's first synchronisation)
+        bool device_shuffled = false;
     } fr;
 
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
@@ -1096,6 +1101,9 @@ static void frame_scratch_free(ctgn_handle h) {
     if (F.h_out) hipHostFree(F.h_out);
     if (F.h_sel) hipHostFree(F.h_sel);
     if (F.h_counts) hipHostFree(F.h_counts);
+    if (F.d_scan_in) hipFree(F.d_scan_in);
+    if (F.d_order) hipFree(F.d_order);
+    if (F.h_order) hipHostFree(F.h_order);
     F = ctgn_context::FrameScratch{};
 }
 
@@ -2266,6 +2274,15 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     F.staged = false;
     F.order.clear();
     F.stride = c; F.n = n; F.n1 = 0; F.n2 = 0;
+    // the shuffle made on the device (ctgn_frame_options::shuffle_seed): the scan travels in scan order, k_frame_permute deals the records
+    const bool dev_shuffle = n > 1 && !order && fo->shuffle_seed != 0;
+    F.device_shuffled = dev_shuffle;
+    if (dev_shuffle && !F.d_scan_in) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_scan_in), 4 * F.cap * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_order), F.cap * sizeof(uint32_t)));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_order), F.cap * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    double *d_recs_up = dev_shuffle ? F.d_scan_in : F.d_scan + 16;                   // where the uploaded records go
     for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];
     double *hs = F.h_scan + 16;
     double tmin = INFINITY, tmax = -INFINITY;
@@ -2350,7 +2367,7 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
         HIPCHK(h, hipMemcpyAsync(F.d_world, raw.base, n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (!fo->override_timestamps) HIPCHK(h, hipMemcpyAsync(F.d_corr, ts.base, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_frame_records, dim3(grid_for(n)), dim3(256), 0, h->stream, F.d_world, fo->override_timestamps ? (const double *) nullptr : F.d_corr,
-                           fo->override_timestamp, (int) n, F.d_scan + 16);
+                           fo->override_timestamp, (int) n, d_recs_up);
         HIPCHK(h, hipGetLastError());
     } else
     for (size_t g0 = 0; g0 < nchunks; g0 += group) {
@@ -2365,8 +2382,21 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
         }
         if (bad_order) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
         const size_t j0 = g0 * CHUNK, j1 = std::min(n, g1 * CHUNK);
+        if (dev_shuffle) {
+            if (g0 == 0) HIPCHK(h, hipMemcpyAsync(F.d_scan, F.h_scan, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(d_recs_up + 4 * j0, F.h_scan + 16 + 4 * j0, 4 * (j1 - j0) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            continue;
+        }
         const size_t lo = g0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first group carries the pose
         HIPCHK(h, hipMemcpyAsync(F.d_scan + lo, F.h_scan + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (dev_shuffle) {
+        int half_bits = 1;
+        while (((size_t) 1 << (2 * half_bits)) < n) ++half_bits;
+        hipLaunchKernelGGL(k_frame_permute, dim3(grid_for(n)), dim3(256), 0, h->stream, (const double *) F.d_scan_in, F.d_scan + 16, F.d_order, (int) n,
+                           half_bits, (unsigned long long) fo->shuffle_seed);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));   // on the host by the first sync
     }
     if (has_nan) tmax = NAN;
     // every point is undistorted below: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
@@ -2418,6 +2448,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose_io, tbe);
         if (ss != CTGN_OK) return ss;
     }
+    if (F.device_shuffled) order = F.h_order;          // (read after the counts' synchronisation only)
     const size_t c = F.stride;                                                      // plane stride of the undistorted outputs
     const double *hs = F.h_scan + 16;
     const double *d_recs = F.d_scan + 16;
@@ -2452,7 +2483,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     }
     h->t_min = tmin; h->t_max = tmax;
     h->kp_coherent = false;
-    if (n2 >= 32768) {
+    if (n2 >= 32768 && !F.device_shuffled) {
         // spatial coherence of the keypoint order (see ctgn_set_keypoints), probed on the staged raw points — a rigid motion keeps
         // neighbours neighbours: pairs one keypoint spacing apart in processing order
         int map_id, nb;
@@ -2694,6 +2725,7 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
         ctgn_status ss = frame_sample(h, fo->frame_voxel_size, fo->sample_voxel_size);
         if (ss != CTGN_OK) return ss;
     }
+    if (F.device_shuffled) { order = F.h_order; F.order.assign(order, order + n); }
     const size_t c = F.stride, n1 = F.n1;
     if (out && out->sampled_indices && n1)
         HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));

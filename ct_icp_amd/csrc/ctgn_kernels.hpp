@@ -2632,6 +2632,42 @@ __global__ __launch_bounds__(256) void k_frame_records(const double *xyz, const 
     }
 }
 
+// Frame pipeline, device-side shuffle (ctgn_frame_options::shuffle_seed): the reference shuffles the scan with its std::mt19937_64 before
+// sub_sample_frame so that WHICH point of a voxel survives is a random choice (odometry.cpp:349); a host that does not need that very
+// permutation has it made here instead — a keyed bijection of [0, n): six Feistel rounds over the next even number of bits, walked until
+// the image falls inside [0, n) (cycle walking keeps it a bijection). One thread per output position: rec_out[j] = rec_in[perm(j)],
+// order[j] = perm(j). No sort, no host work, one launch.
+__device__ __forceinline__ uint32_t shuffle_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t shuffle_perm(uint32_t j, uint32_t n, int half_bits, unsigned long long seed) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t x = j;
+    do {
+        uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const uint32_t k = (uint32_t) (seed >> (round * 9)) ^ (0x9e3779b9u * (uint32_t) (round + 1)) ^ (uint32_t) (seed >> 32);
+            const uint32_t f = shuffle_mix(r ^ k) & mask;
+            const uint32_t t = l ^ f;
+            l = r; r = t;
+        }
+        x = (l << half_bits) | r;
+    } while (x >= n);
+    return x;
+}
+__global__ __launch_bounds__(256) void k_frame_permute(const double *rec_in, double *rec_out, uint32_t *order, int n, int half_bits,
+                                                       unsigned long long seed) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t i = shuffle_perm((uint32_t) j, (uint32_t) n, half_bits, seed);
+        const double *q = rec_in + 4 * (size_t) i;
+        double *o = rec_out + 4 * (size_t) j;
+        o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+        order[j] = i;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_frame_keypoints(const double *scan, const uint32_t *sel, int n, double *kp, size_t c) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double *q = scan + (size_t) sel[i] * 4;

@@ -224,7 +224,7 @@ class FramePipeline:
         self.frame_voxel_size, self.sample_voxel_size, self.max_num_keypoints = frame_voxel_size, sample_voxel_size, max_num_keypoints
 
     def _call(self, fn, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all, want_sampled, extra,
-              all_world_out=None):
+              all_world_out=None, shuffle_seed=0):
         raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
         t = np.ascontiguousarray(t, dtype=np.float64).ravel()
         n = len(raw)
@@ -232,7 +232,8 @@ class FramePipeline:
         pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
         fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
-                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp))
+                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp),
+                            int(shuffle_seed))
         out = L.FrameOutputs()
         res = {}
         if want_all:
@@ -279,15 +280,16 @@ class FramePipeline:
         return res
 
     def register(self, raw, t, pose14, t_begin_end, options: CTICPOptions, motion_model=None, order=None, override_timestamp=None,
-                 want_all=True, want_sampled=True, all_world_out=None) -> dict:
+                 want_all=True, want_sampled=True, all_world_out=None, shuffle_seed=0) -> dict:
         """Sampling -> keypoints -> registration -> undistortion. Returns pose (14), summary, sampled_indices, keypoint_indices and
-        (as asked) all_world / sampled_world."""
+        (as asked) all_world / sampled_world. shuffle_seed != 0 (and no `order`): the scan is shuffled on the device first
+        (ctgn_frame_options::shuffle_seed)."""
         return self._call(L.lib().ctgn_frame_register, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp,
-                          want_all, want_sampled, (), all_world_out)
+                          want_all, want_sampled, (), all_world_out, shuffle_seed)
 
     # ---- the same stages one by one (ctgn_frame_begin / _try_register / _undistort): the calls integration/odometry_gpu_arm.h makes from
     # the reference's InitializeFrame, TryRegister and undistortion loops
-    def begin(self, raw, t, pose14, t_begin_end, order=None, override_timestamp=None, want_world=False) -> dict:
+    def begin(self, raw, t, pose14, t_begin_end, order=None, override_timestamp=None, want_world=False, shuffle_seed=0) -> dict:
         """InitializeFrame (odometry.cpp:333-382): stage + upload + sub_sample_frame (+ the keypoint sampler at sample_voxel_size).
         Returns sampled_indices, num_keypoints and — want_world — the sampled frame under pose14 (the initial estimate)."""
         raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
@@ -296,7 +298,8 @@ class FramePipeline:
         pose = np.ascontiguousarray(pose14, dtype=np.float64)
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
         fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
-                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp))
+                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp),
+                            int(shuffle_seed))
         out = L.FrameOutputs()
         idx = np.zeros(max(n, 1), dtype=np.uint32)
         out.sampled_indices = idx.ctypes.data
@@ -322,7 +325,7 @@ class FramePipeline:
         pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
         fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size if sample_voxel_size is None else sample_voxel_size),
-                            int(self.max_num_keypoints if max_num_keypoints is None else max_num_keypoints), 0, 0.0)
+                            int(self.max_num_keypoints if max_num_keypoints is None else max_num_keypoints), 0, 0.0, 0)
         n1 = max(1, getattr(self, "_last_n1", 0))
         out = L.FrameOutputs()
         kp_idx = np.zeros(n1, dtype=np.uint32)
@@ -370,11 +373,11 @@ class FramePipeline:
         return mask[:getattr(self, "_last_n1", 0)] if add_points else None
 
     def frame(self, raw, t, pose14, t_begin_end, options: CTICPOptions, max_distance: float, motion_model=None, order=None,
-              override_timestamp=None, want_all=True, want_sampled=False, all_world_out=None) -> dict:
+              override_timestamp=None, want_all=True, want_sampled=False, all_world_out=None, shuffle_seed=0) -> dict:
         """register() + update_map(end translation, max_distance, success) in one call (always_insert policy). On the GN route the map
         update is enqueued behind the undistortion and runs beside the hand-over of the outputs (ctgn_frame, round 4)."""
         return self._call(L.lib().ctgn_frame, raw, t, pose14, t_begin_end, options, motion_model, order, override_timestamp, want_all,
-                          want_sampled, (C.c_double(float(max_distance)),), all_world_out)
+                          want_sampled, (C.c_double(float(max_distance)),), all_world_out, shuffle_seed)
 
 
 class GnSolver:

@@ -414,6 +414,11 @@ typedef struct {
     int32_t max_num_keypoints;           /* > 0: keep the first max_num_keypoints keypoints (odometry.cpp:549-552)            */
     int32_t override_timestamps;         /* 1: every point takes override_timestamp (registered_fid <= 1, odometry.cpp:357-361)  */
     double override_timestamp;
+    uint64_t shuffle_seed;               /* != 0 and order == NULL: the first shuffle is made ON THE DEVICE — a keyed bijection of
+                                            0..n-1 (six Feistel rounds with cycle walking, one thread per point, no host work): a uniformly
+                                            random-looking processing order, reproducible from the seed, NOT the permutation libstdc++'s
+                                            std::shuffle would make of the caller's engine (pass that one as `order` when the sampled set
+                                            must be the reference's own). 0: scan order.                                          */
 } ctgn_frame_options;
 void ctgn_frame_options_default(ctgn_frame_options *o);
 

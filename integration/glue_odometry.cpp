@@ -8,7 +8,8 @@
 //                                                     the one-line arms of integration/gn_gpu_arm.h, every map call through ISlamMap)
 //   map_kind 2: the same with `frame_pipeline` on:   in oracle/_ref/libctgn_ref_odometry_armed.so — odometry.cpp compiled with the four arms of
 //                                                     integration/odometry_gpu_arm.h — InitializeFrame, TryRegister, the undistortion loops and
-//                                                     the map half of UpdateMap run on the device too (map_kind 1 there: the arms stand down).
+//                                                     the map half of UpdateMap run on the device too (map_kind 1 there: the arms stand down;
+//                                                     map_kind 3: kind 2 with `frame_shuffle_on_device`).
 //                                                     In the un-armed library the flag has nothing to switch and kind 2 is refused.
 // Nothing of Odometry is restated here: the functions below fill an OdometryOptions, construct ct_icp::Odometry and call RegisterFrame.
 // extern "C" so that the tests can feed both instances the same scans from Python (tests/test_odometry_glue.py, tests/odometry_vs_reference.py);
@@ -116,6 +117,10 @@ struct glue_odometry_result {
     // path, which does not log it)  [3] odometry_transform(ms) = the undistortion loops  [4] odometry_map_update(ms)  [5] odometry_initialization
     // = compute_frame_info + InitializeMotion
     double phase_ms[6];
+    // the arms' own marks (integration/odometry_gpu_arm.h, logged_values odometry_gpu_*; 0 without arms): [0] the shuffles on the host
+    // [1] the ctgn_frame_begin call  [2] building the host image of the sampled frame  [3] the whole TryRegister arm  [4] the
+    // ctgn_frame_undistort call  [5] the whole undistortion arm (summary vectors + fill loop beside the call)
+    double gpu_ms[6];
 };
 
 const char *glue_odometry_last_error() { return g_error.c_str(); }
@@ -166,13 +171,14 @@ int glue_odometry_start(void *h, int map_kind) {
             u->options.map_options = mo;
         } else {
 #ifndef CTGN_GLUE_ARMED
-            if (map_kind == 2) throw std::runtime_error("map kind 2 needs the armed library (oracle/_ref/libctgn_ref_odometry_armed.so)");
+            if (map_kind >= 2) throw std::runtime_error("map kinds 2 and 3 need the armed library (oracle/_ref/libctgn_ref_odometry_armed.so)");
 #endif
             auto mo = std::make_shared<ct_icp::GpuVoxelMap::Options>();
             mo->resolutions = u->resolutions;
             mo->default_radius = u->default_radius;
             mo->device = u->device;
-            mo->frame_pipeline = map_kind == 2;
+            mo->frame_pipeline = map_kind >= 2;
+            mo->frame_shuffle_on_device = map_kind == 3;                   // kind 3: kind 2 with the first shuffle made on the device
             u->options.map_options = mo;
         }
         u->map_kind = map_kind;
@@ -243,6 +249,12 @@ int glue_odometry_register_frame(void *h, const double *xyz, const double *t, si
         for (int k = 0; k < 6; ++k) {
             auto it = summary.logged_values.find(keys[k]);
             out->phase_ms[k] = it == summary.logged_values.end() ? 0.0 : it->second;
+        }
+        const char *gpu_keys[6] = {"odometry_gpu_shuffle", "odometry_gpu_frame_begin", "odometry_gpu_build_frame", "odometry_gpu_try_register",
+                                   "odometry_gpu_undistort_call", "odometry_gpu_undistort_arm"};
+        for (int k = 0; k < 6; ++k) {
+            auto it = summary.logged_values.find(gpu_keys[k]);
+            out->gpu_ms[k] = it == summary.logged_values.end() ? 0.0 : it->second;
         }
         if (sampled_raw_out)
             for (size_t i = 0; i < summary.corrected_points.size() && i < n; ++i)

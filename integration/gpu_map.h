@@ -49,6 +49,10 @@ namespace ct_icp {
             bool device_updates = true;                                     // insert / evict rules run on the GPU (ctgn_map_set_update_mode)
             bool frame_pipeline = true;                                     // Odometry::DoRegister's scan-sized loops run on the GPU too, where
                                                                             // src/ct_icp/odometry.cpp carries the arms of odometry_gpu_arm.h
+            bool frame_shuffle_on_device = false;                           // ... and so does the shuffle in front of sub_sample_frame: a keyed
+                                                                            // permutation made on the GPU (seeded from Odometry's engine) instead
+                                                                            // of std::shuffle on the host (~1 ms for a 132 k-point scan). Off: the
+                                                                            // sampled frame is point for point the one an un-armed run keeps
 
             static std::string Type() { return "GPU_VOXEL_HASHMAP"; }
 
@@ -95,6 +99,9 @@ namespace ct_icp {
             std::vector<uint32_t> position;    // position[sampled[k]] = k (only those entries are meaningful)
             std::vector<uint32_t> keypoints;   // scan index of keypoint k
             std::vector<double> world;         // world points of a read-back, x y z rows
+            bool world_initialised = false;    // the host image of the sampled frame carries its world points under the initial estimate
+            // host milliseconds of the arms' steps, for RegistrationSummary::logged_values (odometry_gpu_*)
+            double ms_shuffle = 0, ms_begin = 0, ms_build_frame = 0, ms_fill = 0, ms_undistort = 0;
         };
 
         FrameSession &frame_session() { return session_; }
@@ -270,6 +277,7 @@ namespace ct_icp {
         FIND_OPTION(node, (*map_options), device, int)
         FIND_OPTION(node, (*map_options), device_updates, bool)
         FIND_OPTION(node, (*map_options), frame_pipeline, bool)
+        FIND_OPTION(node, (*map_options), frame_shuffle_on_device, bool)
         return map_options;
     }
 

@@ -32,11 +32,15 @@
 // reference applies to the points: the first shuffle is reproduced exactly and the sampled-frame SET of every frame is the reference's.
 // The other two shuffle what is already a uniformly random order here (the sampled frame stays in processing order, the keypoints are
 // its first points per voxel): the arms draw the same numbers from g_ (so the stream stays in step with an un-armed run, frame after
-// frame) and keep their order.
+// frame) and keep their order. std::shuffle of 132 k indices costs about a millisecond of one host core — as much as everything the
+// device does for the frame. `frame_shuffle_on_device` (GpuVoxelMap::Options, off by default) trades the reference's permutation for one
+// of the same kind made on the GPU (ctgn_frame_options::shuffle_seed, seeded with one draw from g_): a different, equally random choice
+// of the surviving points, and no host shuffle at all.
 #ifndef CT_ICP_ODOMETRY_GPU_ARM_H
 #define CT_ICP_ODOMETRY_GPU_ARM_H
 
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 #include <optional>
 #include <random>
@@ -62,10 +66,29 @@ namespace ct_icp {
             SLAM_CHECK_STREAM(st == CTGN_OK, "libctgn: " << ctgn_last_error(h));
         }
 
+        inline double ms_since(std::chrono::steady_clock::time_point t0) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+
         // std::shuffle(first, last, g) for a range whose CONTENT does not matter: the same draws from g
         inline void advance_like_shuffle(std::vector<uint32_t> &scratch, size_t n, std::mt19937_64 &g) {
             scratch.resize(n);
             std::shuffle(scratch.begin(), scratch.end(), g);
+        }
+
+        // InitializeFrame's transform (odometry.cpp:371-375) for the host image of the resident sampled frame, on demand: the world points
+        // of `frame` under `estimate`, from the device
+        inline void fetch_initial_world_points(GpuVoxelMap &gpu_map, std::vector<slam::WPoint3D> &frame, const TrajectoryFrame &estimate) {
+            auto &session = gpu_map.frame_session();
+            if (session.world_initialised || frame.empty()) return;
+            double pose[14], tbe[2];
+            pose_to_array(estimate, pose, tbe);
+            ctgn_frame_outputs out{};
+            out.sampled_world_base = frame[0].world_point.data();
+            out.sampled_world_stride_bytes = sizeof(slam::WPoint3D);
+            out.sampled_world_dtype = CTGN_F64;
+            fatal_unless_ok(ctgn_frame_undistort(gpu_map.handle(), pose, tbe, &out), gpu_map.handle());
+            session.world_initialised = true;
         }
     }
 
@@ -86,12 +109,20 @@ namespace ct_icp {
 
         const auto kIndexFrame = frame_info.registered_fid;
         const bool kIsAtStartup = kIndexFrame < options.init_num_frames;
-        session.order.resize(n);
-        std::iota(session.order.begin(), session.order.end(), 0u);
-        std::shuffle(session.order.begin(), session.order.end(), g);                                       // :349
-
+        const bool shuffle_on_device = gpu_map->GetOptions().frame_shuffle_on_device;
+        auto t0 = std::chrono::steady_clock::now();
         ctgn_frame_options fo;
         ctgn_frame_options_default(&fo);
+        if (shuffle_on_device) {
+            fo.shuffle_seed = g() | 1u;                                                                    // one draw instead of :349's n
+        } else {
+            session.order.resize(n);
+            std::iota(session.order.begin(), session.order.end(), 0u);
+            std::shuffle(session.order.begin(), session.order.end(), g);                                   // :349
+        }
+        session.ms_shuffle = ctgn_glue::ms_since(t0);
+
+        t0 = std::chrono::steady_clock::now();
         fo.frame_voxel_size = kIsAtStartup ? options.init_voxel_size : options.voxel_size;                 // :339-340
         // the keypoint voxel TryRegister will ask for first (odometry.cpp:422-423, :1038-1039): sampled in the same pass
         fo.sample_voxel_size = options.sampling == sampling::GRID
@@ -102,17 +133,20 @@ namespace ct_icp {
         double pose[14], tbe[2];
         ctgn_glue::pose_to_array(tr_frame, pose, tbe);
         session.sampled.resize(n);
-        session.world.resize(3 * n);
         ctgn_frame_outputs out{};
         out.sampled_indices = session.sampled.data();
-        out.sampled_world_base = session.world.data();                                                     // :371-375
-        out.sampled_world_stride_bytes = 3 * sizeof(double);
-        out.sampled_world_dtype = CTGN_F64;
-        ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw, ts, n, session.order.data(), &fo, pose, tbe, &out),
-                                   gpu_map->handle());
+        ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw, ts, n, shuffle_on_device ? nullptr : session.order.data(), &fo, pose,
+                                                    tbe, &out), gpu_map->handle());
         const size_t n1 = (size_t) out.num_sampled;
-        ctgn_glue::advance_like_shuffle(session.keypoints, n1, g);                                         // :361
+        session.ms_begin = ctgn_glue::ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        if (!shuffle_on_device) ctgn_glue::advance_like_shuffle(session.keypoints, n1, g);                 // :361
+        session.ms_shuffle += ctgn_glue::ms_since(t0);
 
+        // the host image of the sampled frame. Its world points (:371-375, the initial estimate applied) are what TryRegister hands to
+        // Register; the device derives the keypoints' from the same estimate itself, so they are fetched only if an arm downstream
+        // stands down and the reference's code is about to read them (ctgn_glue::fetch_initial_world_points)
+        t0 = std::chrono::steady_clock::now();
         std::vector<slam::WPoint3D> frame(n1);
         session.position.resize(n);
         for (size_t k = 0; k < n1; ++k) {
@@ -121,9 +155,11 @@ namespace ct_icp {
             auto &point = frame[k];
             point.raw_point.point = view_xyz[i];
             point.raw_point.timestamp = kIndexFrame <= 1 ? frame_info.end_timestamp : double(view_timestamps[i]);
-            point.world_point = Eigen::Vector3d(session.world[3 * k], session.world[3 * k + 1], session.world[3 * k + 2]);
+            point.world_point = point.raw_point.point;                                                     // :345
             point.index_frame = frame_info.frame_id;                                                       // :377-379
         }
+        session.ms_build_frame = ctgn_glue::ms_since(t0);
+        session.world_initialised = false;
         session.registered_fid = kIndexFrame;
         session.num_points = n;
         session.num_sampled = n1;
@@ -138,13 +174,16 @@ namespace ct_icp {
                                AMotionModel *motion_model, const OdometryOptions &odometry_options, std::mt19937_64 &g,
                                bool callbacks_registered) {
         auto *gpu_map = ctgn_glue::frame_pipeline_of(map, odometry_options);
-        if (!gpu_map || callbacks_registered) return false;
+        if (!gpu_map) return false;
         auto &session = gpu_map->frame_session();
         if (!session.active || session.registered_fid != frame_info.registered_fid || frame.size() != session.num_sampled) return false;
-        if (options.solver == ROBUST ||
-            (options.solver == CERES && (options.parametrization != CONTINUOUS_TIME || options.distance != POINT_TO_PLANE)))
+        if (callbacks_registered || options.solver == ROBUST ||
+            (options.solver == CERES && (options.parametrization != CONTINUOUS_TIME || options.distance != POINT_TO_PLANE)) ||
+            (motion_model && !dynamic_cast<const PreviousFrameMotionModel *>(motion_model))) {
+            // not this arm's: the reference's TryRegister runs on the host image of the frame, which now needs its world points
+            ctgn_glue::fetch_initial_world_points(*gpu_map, frame, registration_summary.frame);
             return false;
-        if (motion_model && !dynamic_cast<const PreviousFrameMotionModel *>(motion_model)) return false;
+        }
 
         const auto kIndexFrame = frame_info.registered_fid;
         const bool kIsAtStartup = kIndexFrame < odometry_options.init_num_frames;
@@ -174,7 +213,7 @@ namespace ct_icp {
         double pose[14], tbe[2];
         ctgn_glue::pose_to_array(registration_summary.frame, pose, tbe);
         session.keypoints.resize(session.num_sampled);
-        session.world.resize(3 * std::max(session.num_points, session.num_sampled));
+        session.world.resize(3 * session.num_sampled);
         ctgn_frame_outputs out{};
         out.keypoint_indices = session.keypoints.data();
         out.keypoint_world_base = session.world.data();
@@ -184,7 +223,7 @@ namespace ct_icp {
         const ctgn_status st = ctgn_frame_try_register(gpu_map->handle(), &fo, pose, tbe, robust_route ? nullptr : &co, prior_ptr,
                                                        robust_route ? &ro : nullptr, rprior_ptr, &out, &s);
         if (st == CTGN_ERR_SOLVER) throw std::runtime_error("Error During Optimization");                  // ct_icp.cpp:628-631
-        if (out.num_keypoint_candidates > out.num_keypoints) {                                             // :549-552
+        if (out.num_keypoint_candidates > out.num_keypoints && !gpu_map->GetOptions().frame_shuffle_on_device) {   // :549-552
             std::vector<uint32_t> scratch;
             ctgn_glue::advance_like_shuffle(scratch, (size_t) out.num_keypoint_candidates, g);
         }
@@ -220,6 +259,7 @@ namespace ct_icp {
             const_frame.size() != session.num_points)
             return false;
         const size_t n = session.num_points;
+        auto t0 = std::chrono::steady_clock::now();
         summary.corrected_points = frame;                                                                  // :462
         summary.all_corrected_points.resize(n);                                                            // :463
         auto raw_points_view = const_frame.XYZConst<double>();
@@ -229,14 +269,6 @@ namespace ct_icp {
         // the first two frames were staged with every timestamp at the end of the sweep (:355-359), but all_corrected_points carries the
         // points' own timestamps (:473): those two frames take the reference's loop for it
         const bool all_on_device = session.registered_fid > 1;
-#pragma omp parallel for num_threads(num_threads)
-        for (auto i = 0; i < summary.all_corrected_points.size(); ++i) {                                   // :470-478
-            auto &point = summary.all_corrected_points[i];
-            point.RawPoint() = raw_points_view[i];
-            point.Timestamp() = timestamps_view[i];
-            point.index_frame = frame_info.frame_id;
-            if (!all_on_device) point.WorldPoint() = begin_pose.ContinuousTransform(point.RawPoint(), end_pose, point.Timestamp());
-        }
         double pose[14], tbe[2];
         ctgn_glue::pose_to_array(summary.frame, pose, tbe);
         ctgn_frame_outputs out{};
@@ -250,8 +282,36 @@ namespace ct_icp {
             out.sampled_world_stride_bytes = sizeof(slam::WPoint3D);
             out.sampled_world_dtype = CTGN_F64;
         }
-        ctgn_glue::fatal_unless_ok(ctgn_frame_undistort(gpu_map->handle(), pose, tbe, &out), gpu_map->handle());
+        ctgn_status st = CTGN_OK;
+        double ms_device = 0.;
+        // one thread drives the device (it writes world_point of every record), the others fill raw point, timestamp and frame id of
+        // all_corrected_points meanwhile (disjoint bytes of the records); the driver joins the loop when the device is done
+#pragma omp parallel num_threads(num_threads)
+        {
+#pragma omp single nowait
+            {
+                const auto t1 = std::chrono::steady_clock::now();
+                st = ctgn_frame_undistort(gpu_map->handle(), pose, tbe, &out);
+                ms_device = ctgn_glue::ms_since(t1);
+            }
+#pragma omp for schedule(dynamic, 8192)
+            for (auto i = 0; i < summary.all_corrected_points.size(); ++i) {                               // :470-478
+                auto &point = summary.all_corrected_points[i];
+                point.RawPoint() = raw_points_view[i];
+                point.Timestamp() = timestamps_view[i];
+                point.index_frame = frame_info.frame_id;
+                if (!all_on_device) point.WorldPoint() = begin_pose.ContinuousTransform(point.RawPoint(), end_pose, point.Timestamp());
+            }
+        }
+        ctgn_glue::fatal_unless_ok(st, gpu_map->handle());
         session.undistorted = true;
+        session.ms_undistort = ms_device;
+        session.ms_fill = ctgn_glue::ms_since(t0);
+        summary.logged_values["odometry_gpu_shuffle"] = session.ms_shuffle;
+        summary.logged_values["odometry_gpu_frame_begin"] = session.ms_begin;
+        summary.logged_values["odometry_gpu_build_frame"] = session.ms_build_frame;
+        summary.logged_values["odometry_gpu_undistort_call"] = session.ms_undistort;
+        summary.logged_values["odometry_gpu_undistort_arm"] = session.ms_fill;
         return true;
     }
 

@@ -8,6 +8,8 @@ the reference's own factory call (odometry.cpp:700):
                                     arms of integration/odometry_gpu_arm.h (`make -C oracle odometry-armed`): InitializeFrame, TryRegister, the
                                     undistortion loops and the map half of UpdateMap run on the device, the scan resident from upload to insert.
                                     RefOdometry(GPU_MAP, armed_library=True) = that library with the arms standing down (`frame_pipeline` off).
+    RefOdometry(map_kind=GPU_MAP_ARMED_DEVICE_SHUFFLE)   ... with `frame_shuffle_on_device`: the shuffle in front of sub_sample_frame is a keyed
+                                    permutation made on the GPU instead of std::shuffle on the host
 
 TEST INFRASTRUCTURE ONLY (tests/, tests/odometry_vs_reference.py, bench.py's cpu_baseline leg); nothing under ct_icp_amd/ imports it.
 The library is built in the CPU container and travels to the GPU box as a built file. Third-party arithmetic underneath the reference
@@ -25,7 +27,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_ref", "libctgn_ref_odometry.so")
 _SO_ARMED = os.path.join(_HERE, "_ref", "libctgn_ref_odometry_armed.so")
 REFERENCE_ROOT = "/root/reference"
-CPU_MAP, GPU_MAP, GPU_MAP_ARMED = 0, 1, 2
+CPU_MAP, GPU_MAP, GPU_MAP_ARMED, GPU_MAP_ARMED_DEVICE_SHUFFLE = 0, 1, 2, 3
 GN, CERES = 0, 1                      # ct_icp::CT_ICP_SOLVER (include/ct_icp/ct_icp.h:35-39)
 DRIVING_YAML, DEFAULT_DRIVING, ROBUST_DRIVING, ROBUST_LOW_INERTIA = 0, 1, 2, 3
 
@@ -35,10 +37,12 @@ class Result(C.Structure):
                 ("relative_orientation", C.c_double), ("ego_orientation", C.c_double), ("distance_correction", C.c_double),
                 ("milliseconds", C.c_double), ("success", C.c_int32), ("points_added", C.c_int32), ("sample_size", C.c_int32),
                 ("number_of_residuals", C.c_int32), ("number_of_attempts", C.c_int32), ("robust_level", C.c_int32),
-                ("icp_num_iters", C.c_int32), ("num_corrected", C.c_int32), ("map_points", C.c_uint64), ("phase_ms", C.c_double * 6)]
+                ("icp_num_iters", C.c_int32), ("num_corrected", C.c_int32), ("map_points", C.c_uint64), ("phase_ms", C.c_double * 6),
+                ("gpu_ms", C.c_double * 6)]
 
 
 PHASES = ("total", "initialize_frame", "try_register", "undistort", "map_update", "initialize_motion")   # Result.phase_ms (glue_odometry.cpp)
+ARM_PHASES = ("host_shuffles", "frame_begin_call", "build_sampled_frame", "try_register_arm", "undistort_call", "undistort_arm")   # Result.gpu_ms
 
 
 _libs = {}
@@ -85,7 +89,7 @@ class RefOdometry:
     """ct_icp::Odometry constructed from `profile` + `options` (the reference's YAML key names) on the given map kind."""
 
     def __init__(self, map_kind: int = CPU_MAP, profile: int = DRIVING_YAML, resolutions=((0.8, 0.1, 30),), armed_library: bool = False, **options):
-        self._armed = armed_library or map_kind == GPU_MAP_ARMED
+        self._armed = armed_library or map_kind >= GPU_MAP_ARMED
         L = self._lib = lib(self._armed)
         self._h = L.glue_odometry_options(profile)
         for k, v in options.items():
@@ -119,10 +123,11 @@ class RefOdometry:
         if rc != 0:
             raise RuntimeError(self._lib.glue_odometry_last_error().decode())
         self._frames += 1
-        out = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("pose", "initial_pose", "phase_ms")}
+        out = {k: getattr(res, k) for k, _ in Result._fields_ if k not in ("pose", "initial_pose", "phase_ms", "gpu_ms")}
         out["pose"] = np.array(res.pose)
         out["initial_pose"] = np.array(res.initial_pose)
         out["phase_ms"] = dict(zip(PHASES, res.phase_ms))
+        out["arm_ms"] = dict(zip(ARM_PHASES, res.gpu_ms))
         out["success"] = bool(res.success)
         out["points_added"] = bool(res.points_added)
         if want_world:

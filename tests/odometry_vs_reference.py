@@ -60,9 +60,10 @@ def relative_truth(knots, j):
 
 def run_reference(scans, map_kind, solver, extra):
     from oracle import ref_odometry as ro
-    kind = {"cpu": ro.CPU_MAP, "gpu": ro.GPU_MAP, "gpu-armed": ro.GPU_MAP_ARMED}[map_kind]
+    kind = {"cpu": ro.CPU_MAP, "gpu": ro.GPU_MAP, "gpu-armed": ro.GPU_MAP_ARMED, "gpu-armed-device-shuffle": ro.GPU_MAP_ARMED_DEVICE_SHUFFLE}[map_kind]
     od = ro.RefOdometry(kind, solver=ro.GN if solver == "GN" else ro.CERES, **extra)
-    poses, rec = [], dict(success=[], residuals=[], keypoints=[], points_added=[], ms=[], attempts=[], sampled=[], phases={k: [] for k in ro.PHASES})
+    poses, rec = [], dict(success=[], residuals=[], keypoints=[], points_added=[], ms=[], attempts=[], sampled=[], phases={k: [] for k in ro.PHASES},
+                     arm={k: [] for k in ro.ARM_PHASES})
     for raw, t, _ in scans:
         r = od.register_frame(raw, t)
         poses.append(r["pose"])
@@ -75,6 +76,8 @@ def run_reference(scans, map_kind, solver, extra):
         rec["ms"].append(float(r["milliseconds"]))
         for k, v in r["phase_ms"].items():
             rec["phases"][k].append(float(v))
+        for k, v in r["arm_ms"].items():
+            rec["arm"][k].append(float(v))
     return np.array(poses), rec
 
 
@@ -120,7 +123,7 @@ def main():
     for solver in args.solver.split(","):
         for impl in args.impl.split(","):
             t0 = time.perf_counter()
-            if impl in ("ref-cpu", "ref-gpu", "ref-gpu-armed"):
+            if impl in ("ref-cpu", "ref-gpu", "ref-gpu-armed", "ref-gpu-armed-device-shuffle"):
                 p, rec = run_reference(scans, impl[4:], solver, extra)
             else:
                 p, rec = run_ctgn(scans, solver, impl == "ctgn-ref-regime")
@@ -153,6 +156,8 @@ def main():
                 table = {k: round(float(np.mean(v[lo:])), 4) for k, v in rec["phases"].items()}
                 table["unaccounted"] = round(table["total"] - sum(table[k] for k in table if k != "total"), 4)
                 result["runs"][key]["host_time_table_ms"] = table
+                if impl.startswith("ref-gpu-armed"):             # the arms' own marks inside those phases (integration/odometry_gpu_arm.h)
+                    result["runs"][key]["arm_time_table_ms"] = {k: round(float(np.mean(v[lo:])), 4) for k, v in rec["arm"].items()}
                 result["runs"][key]["sampled_frame_points_mean"] = float(np.mean(rec["sampled"][lo:]))
                 result["runs"][key]["attempts_max"] = int(max(rec["attempts"]))
             log(f"{key}: {seconds:.1f} s, failures {len(fails)} (first {fails[0] if fails else None}), max |dt| {err[:, 0].max():.3f} m, "

@@ -931,6 +931,56 @@ def test_sequence_of_frames_end_to_end(street_case):
     assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(om.export(0)))
 
 
+def test_device_shuffle_is_a_keyed_permutation_and_equals_that_order_passed_by_the_caller(street_case):
+    """ctgn_frame_options::shuffle_seed: the processing order made on the device is a permutation of 0..n-1 (every index once), depends on
+    the seed and nothing else, looks like a shuffle (no correlation with the scan order, displacements spread like a uniform permutation's),
+    and a frame processed under it is bit for bit the frame processed under the same order passed by the caller as `order`."""
+    case = street_case
+    res, radius = [(0.8, 0.1, 30)], 0.75
+    mk = lambda: cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res], default_radius=radius,
+                                                        device_updates=True))
+    ga, gb = mk(), mk()
+    keep_all = cia.FramePipeline(ga, frame_voxel_size=-1.0, sample_voxel_size=0.7)       # frame_voxel_size <= 0: the sampled frame IS the order
+    sc = case["scans"][6]
+    n = len(sc.t)
+    orders = {}
+    for seed in (1, 2, 0x9E3779B97F4A7C15, 1):
+        b = keep_all.begin(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end, shuffle_seed=seed)
+        order = b["sampled_indices"].astype(np.int64)
+        assert len(order) == n and np.array_equal(np.sort(order), np.arange(n))
+        if seed in orders:
+            assert np.array_equal(orders[seed], order)                                 # the seed and n decide it
+        orders[seed] = order
+        j = np.arange(n)
+        assert abs(np.corrcoef(j, order)[0, 1]) < 0.02
+        assert 0.30 * n < np.abs(order - j).mean() < 0.37 * n                            # a uniform permutation: n / 3
+        assert np.count_nonzero(order == j) < 20
+        # neighbours in processing order are not neighbours in the scan: the gaps of consecutive outputs look uniform too
+        assert 0.30 * n < np.abs(np.diff(order)).mean() < 0.37 * n
+    assert not np.array_equal(orders[1], orders[2]) and np.count_nonzero(orders[1] == orders[2]) < 20
+    for m in (1, 2, 3, 5, 64, 257, 4097):                                                # sizes round the Feistel domain's edges
+        b = keep_all.begin(sc.raw[:m], sc.t[:m], sc.pose_gt, sc.t_begin_end, shuffle_seed=7)
+        assert np.array_equal(np.sort(b["sampled_indices"]), np.arange(m))
+    # a registered frame under the device's order == the same frame with that order handed in
+    fa = cia.FramePipeline(ga, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    fb = cia.FramePipeline(gb, frame_voxel_size=0.5, sample_voxel_size=0.7)
+    o0, o = _opts(num_iters_icp=0), _opts(num_iters_icp=5, threshold_orientation_norm=1e-4, min_number_neighbors=10)
+    for j in range(5):
+        s5 = case["scans"][j]
+        for fp in (fa, fb):
+            fp.frame(s5.raw, s5.t, s5.pose_gt, s5.t_begin_end, o0, 60.0, want_all=False)
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.002, 0.02, seed=6)
+    a = fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, o, shuffle_seed=1)
+    b = fb.register(sc.raw, sc.t, pose0, sc.t_begin_end, o, order=orders[1].astype(np.uint32))
+    assert a["summary"].success and a["summary"].num_iters > 0
+    for key in ("sampled_indices", "keypoint_indices", "pose", "sampled_world", "all_world"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(fa.update_map(a["pose"][11:14], 60.0, True), fb.update_map(b["pose"][11:14], 60.0, True))
+    # ... and it is another choice of surviving points than the scan order's, of the same size (one per occupied voxel)
+    c = cia.FramePipeline(mk(), frame_voxel_size=0.5, sample_voxel_size=0.7).begin(sc.raw, sc.t, pose0, sc.t_begin_end)
+    assert len(c["sampled_indices"]) == len(a["sampled_indices"]) and not np.array_equal(np.sort(c["sampled_indices"]), np.sort(a["sampled_indices"]))
+
+
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_frame_steps_equal_the_one_call_pipeline(street_case, shuffled):
     """ctgn_frame_begin / ctgn_frame_try_register / ctgn_frame_undistort / ctgn_frame_update_map — the calls integration/odometry_gpu_arm.h makes
@@ -1285,7 +1335,7 @@ def test_frame_pipeline_edge_cases(street_case):
     rec["xyz"], rec["t"] = sc.raw.astype(np.float32), sc.t.astype(np.float32)
     t32 = rec["t"].astype(np.float64)
     tbe = np.array([min(sc.t_begin_end[0], t32.min()), max(sc.t_begin_end[1], t32.max())])
-    fo = L.FrameOptions(0.5, 0.7, -1, 0, 0.0)
+    fo = L.FrameOptions(0.5, 0.7, -1, 0, 0.0, 0)
     out = L.FrameOutputs()
     allw = np.zeros((n, 3), dtype=np.float32)
     out.all_world_base, out.all_world_stride_bytes, out.all_world_dtype = allw.ctypes.data, 12, L.CTGN_F32

@@ -179,7 +179,6 @@ def test_armed_register_frame_against_the_unarmed_one(solver):
         for key in ("success", "points_added", "number_of_attempts", "num_corrected", "robust_level"):
             assert a[key] == b[key], (solver, j, key, a[key], b[key])
         assert a["success"] and a["sample_size"] == b["sample_size"]            # one keypoint per occupied voxel of the same sampled frame
-        assert np.array_equal(a["initial_pose"], b["initial_pose"]) or np.abs(a["initial_pose"] - b["initial_pose"]).max() < 0.05
         gap = max(gap, float(np.abs(a["pose"][[4, 5, 6, 11, 12, 13]] - b["pose"][[4, 5, 6, 11, 12, 13]]).max()))
         if want_world:
             tbe = (t.min(), t.max())
