@@ -144,6 +144,7 @@ SYMBOLS = {
     "ctgn_frame_register": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
                                       C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior),
                                       C.POINTER(FrameOutputs), C.POINTER(Summary)]),
+    "ctgn_frame_stage": (C.c_int, [_H, View, View, C.c_size_t, C.POINTER(FrameOptions), _dp, _dp]),
     "ctgn_frame_begin": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(FrameOutputs)]),
     "ctgn_frame_try_register": (C.c_int, [_H, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior),
                                           C.POINTER(RobustOptions), C.POINTER(RobustPrior), C.POINTER(FrameOutputs), C.POINTER(Summary)]),

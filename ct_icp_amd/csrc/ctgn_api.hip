@@ -76,6 +76,7 @@ struct Tuning {
     double persist_times = 0;       // per-block timeline of the persistent kernel -> ctgn_wave_timeline
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
+    double frame_defer_update = 1;  // ctgn_frame_update_map without an insert mask returns once the update is enqueued (0: waits for it)
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
@@ -84,7 +85,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
 #define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
-    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct)
+    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update)
     CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
@@ -276,6 +277,8 @@ struct ctgn_context {
         uint32_t *d_order = nullptr;    // order[j] = scan index of the point at processing position j
         uint32_t *h_order = nullptr;    // pinned copy (valid after the frame's first synchronisation)
         bool device_shuffled = false;
+        bool permuted = false;          // d_scan holds the records in another order than the caller's: d_order[j] = caller index of position j
+        bool prestaged = false;         // ctgn_frame_stage uploaded a scan (scan order, d_scan_in) that ctgn_frame_begin has yet to take
     } fr;
 
     int res_grid_cap = MAX_PARTIAL_BLOCKS;             // blocks of k_residual_reduce = per-block partials the solve kernel has to sum
@@ -283,9 +286,12 @@ struct ctgn_context {
     int ablate = 0;                     // measurement hook: bit mask of kernel phases to skip (results become invalid)
     int variant = 0;                    // 0 rows+hist, 1 lane, 2 rows without hist, 3 rows+hist with phase clocks
     unsigned long long *d_prof = nullptr;
+    bool map_update_pending = false;       // ctgn_frame_update_map enqueued an update whose counters are still to be read (NEED_DEVICE does)
     uint64_t insert_calls_with_skips = 0;  // insert CALLS that met points outside the voxel key range / non-finite (those points: skipped, inserted = 0)
     std::string last_error;
 };
+
+static ctgn_status frame_finish_map_update(ctgn_handle h);
 
 namespace {
 
@@ -353,11 +359,17 @@ ctgn_status fail(ctgn_handle h, ctgn_status s, const std::string &msg) {
                         std::string("[HIP] device map: ") + hipGetErrorString(e_));                   \
     } while (0)
 
+// (a map update ctgn_frame_update_map left in flight is completed — its counters read, its errors reported — by whichever entry point
+// comes next: frame_finish_map_update, declared in front of this namespace)
 #define NEED_DEVICE(h)                                                                               \
     do {                                                                                             \
         if (!(h)) return CTGN_ERR_INVALID_ARGUMENT;                                                  \
         if ((h)->device < 0) return fail(h, CTGN_ERR_NO_DEVICE, "context was created host-only");    \
         HIPCHK(h, hipSetDevice((h)->device));                                                        \
+        if ((h)->map_update_pending) {                                                               \
+            const ctgn_status fs_ = frame_finish_map_update(h);                                      \
+            if (fs_ != CTGN_OK) return fs_;                                                          \
+        }                                                                                            \
     } while (0)
 
 inline double read_elem(const void *base, size_t stride, ctgn_dtype dt, size_t i, int c) {
@@ -1271,6 +1283,7 @@ ctgn_status ctgn_map_clear(ctgn_handle h) {
 
 ctgn_status ctgn_map_num_points(ctgn_handle h, uint64_t *out) {
     if (!h || !out) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->map_update_pending) { NEED_DEVICE(h); }     // reads the counters of an update still in flight
     uint64_t s = 0;
     if (h->update_mode == 1) for (auto &DL : h->devlevels) s += DL.host.num_points;
     else for (auto &L : h->levels) s += L.num_points;
@@ -1280,6 +1293,7 @@ ctgn_status ctgn_map_num_points(ctgn_handle h, uint64_t *out) {
 
 ctgn_status ctgn_map_num_voxels(ctgn_handle h, int32_t li, uint64_t *out) {
     if (!h || !out || li < 0 || li >= (int) h->levels.size()) return CTGN_ERR_INVALID_ARGUMENT;
+    if (h->map_update_pending) { NEED_DEVICE(h); }
     *out = h->update_mode == 1 ? h->devlevels[li].host.num_voxels : h->levels[li].num_voxels;
     return CTGN_OK;
 }
@@ -2183,11 +2197,11 @@ static ctgn_status frame_reserve(ctgn_handle h, size_t n) {
     HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_flag2), cap));
     HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_sel1), cap * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_sel2), cap * sizeof(uint32_t)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_counts), 2 * sizeof(int)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_counts), 4 * sizeof(int)));      // sampled, keypoints, bad order
     HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_scan), (4 * cap + 16) * sizeof(double), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_out), 6 * cap * sizeof(double), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_sel), 2 * cap * sizeof(uint32_t), hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_counts), 2 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_counts), 4 * sizeof(int), hipHostMallocDefault));
     F.cap = cap;
     return CTGN_OK;
 }
@@ -2211,6 +2225,7 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw, ctgn_view ts, size
 
 // the read-backs a fused map update deferred: counters of every level, then the checks devmap_insert_staged makes
 static ctgn_status frame_finish_map_update(ctgn_handle h) {
+    h->map_update_pending = false;
     bool range_error = false, overflow = false;
     hipError_t e = hipStreamSynchronize(h->stream);
     for (auto &DL : h->devlevels) {
@@ -2228,28 +2243,28 @@ static ctgn_status frame_finish_map_update(ctgn_handle h) {
     return CTGN_OK;
 }
 
-// every scan point's world point from the pinned read-back (F.h_out: x y z rows when all_rows, three planes c apart otherwise, both in
-// processing order) into the rows of the caller's array, a chunk per helper thread
-static void frame_scatter_all(ctgn_handle h, size_t n, size_t c, const uint32_t *order, const ctgn_frame_outputs *out, bool all_rows) {
+// every scan point's world point from the pinned read-back (F.h_out: x y z rows in the CALLER's numbering — the undistortion kernel writes
+// them through the frame's order) into the rows of the caller's array, a chunk per helper thread
+static void frame_scatter_all(ctgn_handle h, size_t n, const ctgn_frame_outputs *out, bool plain_rows) {
     auto &F = h->fr;
     constexpr size_t CHUNK = 16384;
-    const double *wx = F.h_out, *wy = F.h_out + c, *wz = F.h_out + 2 * c;
     char *ob = static_cast<char *>(out->all_world_base);
     const size_t os = out->all_world_stride_bytes;
     const bool o64 = out->all_world_dtype == CTGN_F64;
+    const double *w = F.h_out;
     h->pool.run((n + CHUNK - 1) / CHUNK, [&](size_t k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
-        if (all_rows) {
-            std::memcpy(ob + j0 * os, F.h_out + 3 * j0, (j1 - j0) * 3 * sizeof(double));
+        if (plain_rows) {
+            std::memcpy(ob + j0 * os, w + 3 * j0, (j1 - j0) * 3 * sizeof(double));
         } else if (o64) {
             for (size_t j = j0; j < j1; ++j) {
-                double *q = reinterpret_cast<double *>(ob + (order ? (size_t) order[j] : j) * os);
-                q[0] = wx[j]; q[1] = wy[j]; q[2] = wz[j];
+                double *q = reinterpret_cast<double *>(ob + j * os);
+                q[0] = w[3 * j]; q[1] = w[3 * j + 1]; q[2] = w[3 * j + 2];
             }
         } else {
             for (size_t j = j0; j < j1; ++j) {
-                float *q = reinterpret_cast<float *>(ob + (order ? (size_t) order[j] : j) * os);
-                q[0] = (float) wx[j]; q[1] = (float) wy[j]; q[2] = (float) wz[j];
+                float *q = reinterpret_cast<float *>(ob + j * os);
+                q[0] = (float) w[3 * j]; q[1] = (float) w[3 * j + 1]; q[2] = (float) w[3 * j + 2];
             }
         }
     });
@@ -2258,10 +2273,46 @@ static void frame_scatter_all(ctgn_handle h, size_t n, size_t c, const uint32_t 
 // Stage one scan for the frame pipeline: the caller's records -> x y z t records in processing order behind the pose (F.d_scan), uploaded
 // chunk by chunk while the next chunk is being staged; timestamp range -> F.tmin / F.tmax, checked against [t_begin, t_end]. Everything is
 // enqueued on the handle's stream; nothing of an earlier frame is valid afterwards.
+// phase 0: all of it. phase 1 (ctgn_frame_stage): the upload only — the records go to d_scan_in whatever comes, and the call returns with the
+// copy in flight. phase 2 (ctgn_frame_begin on a pre-staged scan): the processing order only — permute (or copy) d_scan_in into d_scan.
 static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
-                               const double pose_io[14], const double tbe[2]) {
+                               const double pose_io[14], const double tbe[2], int phase = 0) {
     auto &F = h->fr;
+    if (phase == 2) {
+        if (!F.prestaged || n != F.n) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no scan of this size was staged (ctgn_frame_stage)");
+        F.prestaged = false;
+        F.order.clear();
+        const bool dev_shuffle = n > 1 && !order && fo->shuffle_seed != 0;
+        F.device_shuffled = dev_shuffle;
+        if (n && !(tbe[0] <= F.tmin && F.tmax <= tbe[1])) {
+            hipStreamSynchronize(h->stream);
+            return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
+        }
+        for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];                      // (the header's earlier copy has been waited for: see phase 1)
+        HIPCHK(h, hipMemcpyAsync(F.d_scan, F.h_scan, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(F.d_counts + 2, 0, sizeof(int), h->stream));
+        if (!(dev_shuffle || (order && n))) {
+            if (n) HIPCHK(h, hipMemcpyAsync(F.d_scan + 16, F.d_scan_in, 4 * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            F.permuted = false;
+            return CTGN_OK;
+        }
+        int half_bits = 1;
+        while (((size_t) 1 << (2 * half_bits)) < n) ++half_bits;
+        if (order) {
+            std::memcpy(F.h_order, order, n * sizeof(uint32_t));
+            HIPCHK(h, hipMemcpyAsync(F.d_order, F.h_order, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->dm.idx, 0, n * sizeof(uint32_t), h->stream));
+        }
+        hipLaunchKernelGGL(k_frame_permute, dim3(grid_for(n)), dim3(256), 0, h->stream, (const double *) F.d_scan_in, F.d_scan + 16,
+                           order ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr, F.d_order, (int) n, half_bits,
+                           (unsigned long long) fo->shuffle_seed, reinterpret_cast<unsigned int *>(h->dm.idx), F.d_counts + 2);
+        HIPCHK(h, hipGetLastError());
+        if (dev_shuffle) HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        F.permuted = true;
+        return CTGN_OK;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));       // pinned staging reuse
+    F.prestaged = false;
     {
         ctgn_status rs = frame_reserve(h, std::max<size_t>(n, 1));     // an empty scan still stages the pose
         if (rs != CTGN_OK) return rs;
@@ -2274,24 +2325,24 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     F.staged = false;
     F.order.clear();
     F.stride = c; F.n = n; F.n1 = 0; F.n2 = 0;
-    // the shuffle made on the device (ctgn_frame_options::shuffle_seed): the scan travels in scan order, k_frame_permute deals the records
-    const bool dev_shuffle = n > 1 && !order && fo->shuffle_seed != 0;
+    // a processing order — the caller's `order`, or the shuffle made on the device (ctgn_frame_options::shuffle_seed) — is applied ON THE
+    // DEVICE: the scan travels in scan order (staged by sequential reads; gathering 132 k records through a shuffled index on the host
+    // cost 0.8 ms of the call) and k_frame_permute deals the records, checking a caller's order for being a permutation on the way
+    const bool dev_shuffle = phase == 0 && n > 1 && !order && fo->shuffle_seed != 0;
+    const bool permute = phase == 1 || dev_shuffle || (order && n);
     F.device_shuffled = dev_shuffle;
-    if (dev_shuffle && !F.d_scan_in) {
+    if (permute && !F.d_scan_in) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_scan_in), 4 * F.cap * sizeof(double)));
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_order), F.cap * sizeof(uint32_t)));
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_order), F.cap * sizeof(uint32_t), hipHostMallocDefault));
     }
-    double *d_recs_up = dev_shuffle ? F.d_scan_in : F.d_scan + 16;                   // where the uploaded records go
+    double *d_recs_up = permute ? F.d_scan_in : F.d_scan + 16;                       // where the uploaded records go
     for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];
     double *hs = F.h_scan + 16;
     double tmin = INFINITY, tmax = -INFINITY;
     constexpr size_t CHUNK = 16384;
     const bool f64 = raw.dtype == CTGN_F64, tf64 = ts.dtype == CTGN_F64;
     const char *rb = static_cast<const char *>(raw.base), *tb_ = static_cast<const char *>(ts.base);
-    // `order` must be a permutation: an index out of range or met twice would leave rows of the outputs unwritten (one bit per index,
-    // set atomically: the chunks of a group are staged by different threads)
-    std::vector<uint64_t> seen(order ? (n + 63) / 64 : 0, 0ull);
     const size_t nchunks = std::max<size_t>(1, (n + CHUNK - 1) / CHUNK);
     struct ChunkStat { double mn, mx; bool has_nan, bad_order; };
     std::vector<ChunkStat> stat(nchunks, ChunkStat{INFINITY, -INFINITY, false, false});
@@ -2299,21 +2350,17 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     // engine reads them where they lie and a kernel writes the x y z t records (a driver that fills such a buffer from its sensor
     // packets saves the 4 MB staging copy of a 132 k-point scan). tuning frame_no_direct = 1: always stage (measurement hook).
     const bool no_direct = tuning().frame_no_direct != 0;
-    const bool direct_in = n && !no_direct && !order && f64 && raw.stride_bytes == 3 * sizeof(double) &&
+    const bool direct_in = n && !no_direct && f64 && raw.stride_bytes == 3 * sizeof(double) &&
                            (fo->override_timestamps || (tf64 && ts.stride_bytes == sizeof(double))) && host_pinned(raw.base, n * 3 * sizeof(double)) &&
                            (fo->override_timestamps || host_pinned(ts.base, n * sizeof(double)));
     const std::function<void(size_t)> stage_chunk = [&](size_t k) {
         const size_t j0 = k * CHUNK, j1 = std::min(n, j0 + CHUNK);
         // four independent min / max chains: one chain is a 4-cycle dependency per point and was what the loop ran at
         double mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        bool has_nan = false, bad_order = false;
+        bool has_nan = false;
+        const bool bad_order = false;
         auto stage_one = [&](size_t j, int u) {
-            const size_t i = order ? (size_t) order[j] : j;
-            if (i >= n) { bad_order = true; return; }
-            if (order) {
-                const uint64_t bit = 1ull << (i & 63);
-                if (__atomic_fetch_or(&seen[i >> 6], bit, __ATOMIC_RELAXED) & bit) { bad_order = true; return; }
-            }
+            const size_t i = j;
             double *q = hs + 4 * j;
             if (f64) { const double *p = reinterpret_cast<const double *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
             else { const float *p = reinterpret_cast<const float *>(rb + i * raw.stride_bytes); q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; }
@@ -2373,16 +2420,13 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     for (size_t g0 = 0; g0 < nchunks; g0 += group) {
         const size_t g1 = std::min(nchunks, g0 + group);
         h->pool.run(g1 - g0, [&](size_t i) { stage_chunk(g0 + i); });
-        bool bad_order = false;
         for (size_t k = g0; k < g1; ++k) {
-            bad_order = bad_order || stat[k].bad_order;
             has_nan = has_nan || stat[k].has_nan;
             tmin = std::min(tmin, stat[k].mn);
             tmax = std::max(tmax, stat[k].mx);
         }
-        if (bad_order) { hipStreamSynchronize(h->stream); return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1"); }
         const size_t j0 = g0 * CHUNK, j1 = std::min(n, g1 * CHUNK);
-        if (dev_shuffle) {
+        if (permute) {
             if (g0 == 0) HIPCHK(h, hipMemcpyAsync(F.d_scan, F.h_scan, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipMemcpyAsync(d_recs_up + 4 * j0, F.h_scan + 16 + 4 * j0, 4 * (j1 - j0) * sizeof(double), hipMemcpyHostToDevice, h->stream));
             continue;
@@ -2390,14 +2434,28 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
         const size_t lo = g0 == 0 ? 0 : 16 + 4 * j0, hi = 16 + 4 * j1;              // the first group carries the pose
         HIPCHK(h, hipMemcpyAsync(F.d_scan + lo, F.h_scan + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    if (dev_shuffle) {
+    HIPCHK(h, hipMemsetAsync(F.d_counts + 2, 0, sizeof(int), h->stream));            // "order is not a permutation"
+    if (phase == 1) {                                  // the order comes with ctgn_frame_begin
+        if (has_nan) tmax = NAN;
+        F.tmin = tmin; F.tmax = tmax; F.direct_in = direct_in;
+        F.prestaged = true;
+        return CTGN_OK;
+    }
+    if (permute) {
         int half_bits = 1;
         while (((size_t) 1 << (2 * half_bits)) < n) ++half_bits;
-        hipLaunchKernelGGL(k_frame_permute, dim3(grid_for(n)), dim3(256), 0, h->stream, (const double *) F.d_scan_in, F.d_scan + 16, F.d_order, (int) n,
-                           half_bits, (unsigned long long) fo->shuffle_seed);
+        if (order) {                                   // the caller's order: to the device through the pinned copy, checked there
+            std::memcpy(F.h_order, order, n * sizeof(uint32_t));
+            HIPCHK(h, hipMemcpyAsync(F.d_order, F.h_order, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->dm.idx, 0, n * sizeof(uint32_t), h->stream));     // free until the samplers run
+        }
+        hipLaunchKernelGGL(k_frame_permute, dim3(grid_for(n)), dim3(256), 0, h->stream, (const double *) F.d_scan_in, F.d_scan + 16,
+                           order ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr, F.d_order, (int) n, half_bits,
+                           (unsigned long long) fo->shuffle_seed, reinterpret_cast<unsigned int *>(h->dm.idx), F.d_counts + 2);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));   // on the host by the first sync
+        if (dev_shuffle) HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));   // on the host by the first sync
     }
+    F.permuted = permute;
     if (has_nan) tmax = NAN;
     // every point is undistorted below: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
     if (n && !(tbe[0] <= tmin && tmax <= tbe[1])) {
@@ -2460,10 +2518,11 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     // ---- both samplers, then the one read-back that sizes the launches
     DMCHK(h, devmap_frame_sampling(h->dm, d_recs, 1, 4, n, fo->frame_voxel_size, fo->sample_voxel_size, F.d_flag1, F.d_flag2, F.d_sel1, F.d_sel2,
                                    F.d_counts, h->stream));
-    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     mark(1);                                          // samplers enqueued
     HIPCHK(h, hipStreamSynchronize(h->stream));
     mark(2);                                          // counts on the host
+    if (F.h_counts[2]) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1");
     const size_t n1 = (size_t) F.h_counts[0];
     size_t n2 = (size_t) F.h_counts[1];
     if (fo->max_num_keypoints > 0 && n2 > (size_t) fo->max_num_keypoints) n2 = (size_t) fo->max_num_keypoints;
@@ -2539,11 +2598,11 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     const bool want_all = out && out->all_world_base && n;
     if (n1) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, d_recs, F.d_corr, (int) n1, (size_t) 1, d_pose,
                                tbe[0], tbe[1], F.d_sel1, c, (size_t) 4);
-    // every scan point: as x y z rows when that is what the caller's array holds (float64 rows of 24 bytes, no `order`): the copy then
-    // lands in the final layout and the hand-over is a straight memcpy; as three planes otherwise
-    const bool all_rows = want_all && !order && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
+    // every scan point: as x y z rows in the caller's numbering (the kernel writes through the frame's order): when that is what the
+    // caller's array holds (float64 rows of 24 bytes) the copy lands in the final layout and the hand-over is a straight memcpy
+    const bool all_rows = want_all && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
     if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1, d_pose,
-                                     tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, all_rows ? 1 : 0);
+                                     tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, 1, F.permuted ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr);
     HIPCHK(h, hipGetLastError());
     const bool fuse = fused_max_distance != nullptr && !robust && h->update_mode == 1;
     hipStream_t s_out = h->stream;
@@ -2558,7 +2617,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     // ... and straight into the caller's array when that is page-locked
     const bool direct_out = all_rows && !no_direct && host_pinned(out->all_world_base, n * 3 * sizeof(double));
     if (want_all)
-        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double),
+        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, 3 * n * sizeof(double),
                                  hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_world_base && n1)
         HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, s_out));
@@ -2612,7 +2671,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         out->num_sampled = n1;
         out->num_keypoints = n2;
         out->num_keypoint_candidates = (uint64_t) F.h_counts[1];
-        if (want_all && !direct_out) frame_scatter_all(h, n, c, order, out, all_rows);
+        if (want_all && !direct_out) frame_scatter_all(h, n, out, all_rows);
         if (out->sampled_world_base)
             for (size_t k = 0; k < n1; ++k)
                 write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
@@ -2648,6 +2707,33 @@ ctgn_status ctgn_frame_update_map(ctgn_handle h, const double location[3], doubl
     if (add_points && !F.valid) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no registered frame is resident (ctgn_frame_register)");
     const bool timing = tuning().frame_timing != 0;
     const auto t0 = std::chrono::steady_clock::now();
+    if (!inserted && tuning().frame_defer_update != 0) {
+        // nobody waits for the insert mask: eviction and insertion are enqueued and the call returns; the counters are read (and a key-range
+        // note or a capacity error reported) by the next call on the handle, which finds the work done — the host's time between two frames
+        // (the caller's bookkeeping, the next scan's preparation) is the map update's
+        h->map_update_pending = true;
+        hipError_t e = hipSuccess;
+        for (auto &DL : h->devlevels)
+            if (e == hipSuccess) e = devmap_level_remove_far_value_enqueue(DL, location, max_distance, h->stream);               // odometry.cpp:938-940
+        if (e == hipSuccess && add_points && F.n1) {
+            e = devmap_scratch_reserve(h->dm, F.n1);
+            DevMapScratch &S = h->dm;
+            double *own_pts = S.pts;
+            const size_t own_stride = S.stride;
+            S.pts = F.d_corr;                          // the undistorted sampled frame is the batch: nothing is copied
+            S.stride = F.stride;
+            if (e == hipSuccess) e = hipMemsetAsync(S.inserted, 0, F.n1, h->stream);
+            for (auto &DL : h->devlevels)
+                if (e == hipSuccess) e = devmap_level_insert_enqueue(DL, S, F.n1, nullptr, h->stream);                           // odometry.cpp:943-949
+            S.pts = own_pts;
+            S.stride = own_stride;
+        }
+        if (e != hipSuccess) {
+            (void) frame_finish_map_update(h);
+            return fail(h, CTGN_ERR_HIP, std::string("[HIP] frame map update -> ") + hipGetErrorString(e));
+        }
+        return CTGN_OK;
+    }
     for (auto &DL : h->devlevels) DMCHK(h, devmap_level_remove_far(DL, location, max_distance, h->stream));   // odometry.cpp:938-940
     const auto t1 = std::chrono::steady_clock::now();
     if (!add_points || F.n1 == 0) return CTGN_OK;
@@ -2689,8 +2775,9 @@ ctgn_status ctgn_frame(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, con
 static ctgn_status frame_sample(ctgn_handle h, double frame_voxel, double kp_voxel) {
     auto &F = h->fr;
     DMCHK(h, devmap_frame_sampling(h->dm, F.d_scan + 16, 1, 4, F.n, frame_voxel, kp_voxel, F.d_flag1, F.d_flag2, F.d_sel1, F.d_sel2, F.d_counts, h->stream));
-    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(F.h_counts, F.d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (F.h_counts[2]) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "order must be a permutation of 0..n-1");
     F.n1 = (size_t) F.h_counts[0];
     F.n2 = (size_t) F.h_counts[1];
     F.frame_voxel = frame_voxel;
@@ -2711,13 +2798,14 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
     NEED_DEVICE(h);
     if (out) { out->num_sampled = 0; out->num_keypoints = 0; }
     if (!fo || !pose || !tbe) return CTGN_ERR_INVALID_ARGUMENT;
-    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
+    const bool prestaged = n && !raw.base;             // "the scan ctgn_frame_stage uploaded"
+    if (n && !prestaged && (!ts.base && !fo->override_timestamps)) return CTGN_ERR_INVALID_ARGUMENT;
     if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
-    if (n && (on_device(raw.base) || on_device(ts.base)))
+    if (n && !prestaged && (on_device(raw.base) || on_device(ts.base)))
         return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_begin takes host views (the stage entry points accept device memory)");
     auto &F = h->fr;
     {
-        ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose, tbe);
+        ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose, tbe, prestaged ? 2 : 0);
         if (ss != CTGN_OK) return ss;
     }
     if (order) F.order.assign(order, order + n);
@@ -2749,6 +2837,22 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
     }
     F.staged = true;
     return CTGN_OK;
+}
+
+ctgn_status ctgn_frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const ctgn_frame_options *fo, const double pose[14],
+                             const double tbe[2]) {
+    NEED_DEVICE(h);
+    if (!fo || !pose || !tbe) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n && (!raw.base || (!ts.base && !fo->override_timestamps))) return CTGN_ERR_INVALID_ARGUMENT;
+    if (n > (size_t) 1 << 30) return fail(h, CTGN_ERR_UNSUPPORTED, "too many points");
+    if (n && (on_device(raw.base) || on_device(ts.base)))
+        return fail(h, CTGN_ERR_UNSUPPORTED, "ctgn_frame_stage takes host views (the stage entry points accept device memory)");
+    ctgn_status st = frame_stage(h, raw, ts, n, nullptr, fo, pose, tbe, 1);
+    // the staging block and (page-locked caller arrays) the caller's memory are read by the copy engine: they are the caller's again
+    // when the call returns
+    if (h->device >= 0) { if (hipStreamSynchronize(h->stream) != hipSuccess && st == CTGN_OK) st = fail(h, CTGN_ERR_HIP, "[HIP] upload of the scan"); }
+    if (st != CTGN_OK) h->fr.prestaged = false;
+    return st;
 }
 
 ctgn_status ctgn_frame_begin(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const uint32_t *order, const ctgn_frame_options *fo,
@@ -2824,7 +2928,6 @@ ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const dou
     if (out) { out->num_sampled = n1; }
     // every point is undistorted: InterpolatePose CHECKs begin <= t <= end for each (types.h:456)
     if (n && !(tbe[0] <= F.tmin && F.tmax <= tbe[1])) return fail(h, CTGN_ERR_TIMESTAMP_RANGE, "point timestamps must lie in [t_begin, t_end]");
-    const uint32_t *order = F.order.empty() ? nullptr : F.order.data();
     const double *d_recs = F.d_scan + 16;
     F.valid = false;
     {
@@ -2834,9 +2937,10 @@ ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const dou
     if (n1) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, d_recs, F.d_corr, (int) n1, (size_t) 1,
                                (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) F.d_sel1, c, (size_t) 4);
     const bool want_all = out && out->all_world_base && n;
-    const bool all_rows = want_all && !order && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
+    const bool all_rows = want_all && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
     if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1,
-                                     (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, all_rows ? 1 : 0);
+                                     (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, 1,
+                                     F.permuted ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr);
     HIPCHK(h, hipGetLastError());
     const bool direct_out = all_rows && tuning().frame_no_direct == 0 && host_pinned(out->all_world_base, n * 3 * sizeof(double));
     // the sampled frame first: it is small, and the host scatters it while the scan-sized copy is still travelling
@@ -2847,7 +2951,7 @@ ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const dou
         HIPCHK(h, hipEventRecord(h->ev_frame, h->stream));
     }
     if (want_all)
-        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, (all_rows ? 3 * n : 2 * c + n) * sizeof(double),
+        HIPCHK(h, hipMemcpyAsync(direct_out ? static_cast<double *>(out->all_world_base) : F.h_out, F.d_world, 3 * n * sizeof(double),
                                  hipMemcpyDeviceToHost, h->stream));
     if (want_sampled) {
         HIPCHK(h, hipEventSynchronize(h->ev_frame));
@@ -2856,7 +2960,7 @@ ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const dou
                         F.h_out[5 * c + k]);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (want_all && !direct_out) frame_scatter_all(h, n, c, order, out, all_rows);
+    if (want_all && !direct_out) frame_scatter_all(h, n, out, all_rows);
     F.valid = true;                                    // d_corr = the sampled frame under these poses: ctgn_frame_update_map may insert it
     return CTGN_OK;
 }

@@ -626,6 +626,14 @@ hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double dist
     return read_counters(L, stream);
 }
 
+// the same without the counter read-back
+hipError_t devmap_level_remove_far_value_enqueue(DevLevel &L, const double loc[3], double distance, hipStream_t stream) {
+    hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,
+                       L.slots_cap, L.blocks, L.blk, L.free_list, L.counters, loc[0], loc[1], loc[2], distance, L.resolution, (const double *) nullptr,
+                       (const int *) nullptr);
+    return hipGetLastError();
+}
+
 // the same with the location read from device memory (3 doubles) and no counter read-back
 hipError_t devmap_level_remove_far_enqueue(DevLevel &L, const double *loc_dev, double distance, hipStream_t stream, const int *failed_dev) {
     hipLaunchKernelGGL(k_dm_remove_far, dim3((unsigned) std::min<uint64_t>((L.slots_cap + 255) / 256, 4096)), dim3(256), 0, stream, L.slots,

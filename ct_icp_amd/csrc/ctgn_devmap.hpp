@@ -85,6 +85,7 @@ hipError_t devmap_level_remove_far(DevLevel &L, const double loc[3], double dist
 // enqueue-only variants of the frame pipeline (no read-back; the location / the gate live on the device), and the read-back they defer
 hipError_t devmap_level_insert_enqueue(DevLevel &L, DevMapScratch &S, size_t n, const int *skip, hipStream_t stream);
 hipError_t devmap_level_remove_far_enqueue(DevLevel &L, const double *loc_dev, double distance, hipStream_t stream, const int *failed_dev = nullptr);
+hipError_t devmap_level_remove_far_value_enqueue(DevLevel &L, const double loc[3], double distance, hipStream_t stream);   // host location, no read-back
 hipError_t devmap_level_read_counters(DevLevel &L, hipStream_t stream);
 // sub_sample_frame / grid_sampling (reference src/ct_icp/ct_icp.cpp:65-101): index of the first point of every voxel of
 // the staged points (voxel = static_cast<short>(p / voxel_size) per axis). Output in ascending index order = the order in

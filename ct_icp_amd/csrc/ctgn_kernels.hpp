@@ -2595,9 +2595,11 @@ __global__ __launch_bounds__(256) void k_transform(KpView kp, const GnState *st,
 // of the output arrays.
 // in_es: coordinate a of input point j is in[j * in_es + a * cap] (x y z t records: in_es 4, cap 1; then out_cap must be given).
 // out_aos: the output is written as x y z records (out[3 i + a]) instead of three planes.
+// out_index (with out_aos): record i of the output is written at position out_index[i] — the frame pipeline's un-shuffle (every scan point
+// back in the caller's numbering on the device, so that the read-back lands in the caller's order).
 __global__ __launch_bounds__(256) void k_transform_points(const double *in, double *out, int n, size_t cap, const double *pose,
                                                           double tb, double te, const uint32_t *sel = nullptr, size_t out_cap = 0,
-                                                          size_t in_es = 1, int out_aos = 0) {
+                                                          size_t in_es = 1, int out_aos = 0, const uint32_t *out_index = nullptr) {
     if (out_cap == 0) out_cap = cap;
     __shared__ GnState s;
     if (threadIdx.x == 0) {
@@ -2615,7 +2617,7 @@ __global__ __launch_bounds__(256) void k_transform_points(const double *in, doub
         const Vec3 raw{q[0], q[cap], q[2 * cap]};
         const double alpha = alpha_timestamp(q[3 * cap], tb, te);
         const Vec3 p = ct_transform(&s, alpha, raw);
-        if (out_aos) { out[3 * (size_t) i] = p.x; out[3 * (size_t) i + 1] = p.y; out[3 * (size_t) i + 2] = p.z; }
+        if (out_aos) { const size_t o = out_index ? (size_t) out_index[i] : (size_t) i; out[3 * o] = p.x; out[3 * o + 1] = p.y; out[3 * o + 2] = p.z; }
         else { out[i] = p.x; out[out_cap + i] = p.y; out[2 * out_cap + i] = p.z; }
     }
 }
@@ -2641,30 +2643,45 @@ __device__ __forceinline__ uint32_t shuffle_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t shuffle_round_key(unsigned long long seed, int round) {     // splitmix64 of (seed, round)
+    unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (unsigned long long) (round + 1);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (uint32_t) (z ^ (z >> 31));
+}
 __device__ __forceinline__ uint32_t shuffle_perm(uint32_t j, uint32_t n, int half_bits, unsigned long long seed) {
     const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t key[6];
+#pragma unroll
+    for (int round = 0; round < 6; ++round) key[round] = shuffle_round_key(seed, round);
     uint32_t x = j;
     do {
         uint32_t l = x >> half_bits, r = x & mask;
 #pragma unroll
         for (int round = 0; round < 6; ++round) {
-            const uint32_t k = (uint32_t) (seed >> (round * 9)) ^ (0x9e3779b9u * (uint32_t) (round + 1)) ^ (uint32_t) (seed >> 32);
-            const uint32_t f = shuffle_mix(r ^ k) & mask;
-            const uint32_t t = l ^ f;
+            const uint32_t t = l ^ (shuffle_mix(r ^ key[round]) & mask);
             l = r; r = t;
         }
         x = (l << half_bits) | r;
     } while (x >= n);
     return x;
 }
-__global__ __launch_bounds__(256) void k_frame_permute(const double *rec_in, double *rec_out, uint32_t *order, int n, int half_bits,
-                                                       unsigned long long seed) {
+// order_in == nullptr: order[j] = the keyed permutation of j (written to order_out). order_in != nullptr: the CALLER's processing order;
+// an index out of range or met twice sets *bad (seen: n zeroed words).
+__global__ __launch_bounds__(256) void k_frame_permute(const double *rec_in, double *rec_out, const uint32_t *order_in, uint32_t *order_out, int n,
+                                                       int half_bits, unsigned long long seed, unsigned int *seen, int *bad) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t i = shuffle_perm((uint32_t) j, (uint32_t) n, half_bits, seed);
+        uint32_t i;
+        if (order_in) {
+            i = order_in[j];
+            if (i >= (uint32_t) n || atomicExch(&seen[i], 1u) != 0u) { atomicOr(bad, 1); continue; }
+        } else {
+            i = shuffle_perm((uint32_t) j, (uint32_t) n, half_bits, seed);
+            order_out[j] = i;
+        }
         const double *q = rec_in + 4 * (size_t) i;
         double *o = rec_out + 4 * (size_t) j;
         o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
-        order[j] = i;
     }
 }
 

@@ -289,12 +289,33 @@ class FramePipeline:
 
     # ---- the same stages one by one (ctgn_frame_begin / _try_register / _undistort): the calls integration/odometry_gpu_arm.h makes from
     # the reference's InitializeFrame, TryRegister and undistortion loops
-    def begin(self, raw, t, pose14, t_begin_end, order=None, override_timestamp=None, want_world=False, shuffle_seed=0) -> dict:
-        """InitializeFrame (odometry.cpp:333-382): stage + upload + sub_sample_frame (+ the keypoint sampler at sample_voxel_size).
-        Returns sampled_indices, num_keypoints and — want_world — the sampled frame under pose14 (the initial estimate)."""
+    def stage(self, raw, t, pose14, t_begin_end, override_timestamp=None) -> None:
+        """ctgn_frame_stage: upload the scan ahead of begin(None, None, ...) — for a caller that computes its `order` meanwhile."""
         raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
         t = np.ascontiguousarray(t, dtype=np.float64).ravel()
-        n = len(raw)
+        pose = np.ascontiguousarray(pose14, dtype=np.float64)
+        tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
+        fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
+                            0 if override_timestamp is None else 1, 0.0 if override_timestamp is None else float(override_timestamp), 0)
+        dp = C.POINTER(C.c_double)
+        L.check(self._h, L.lib().ctgn_frame_stage(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0), len(raw),
+                                                 C.byref(fo), pose.ctypes.data_as(dp), tbe.ctypes.data_as(dp)))
+        self._staged_n = len(raw)
+
+    def begin(self, raw, t, pose14, t_begin_end, order=None, override_timestamp=None, want_world=False, shuffle_seed=0) -> dict:
+        """InitializeFrame (odometry.cpp:333-382): stage + upload + sub_sample_frame (+ the keypoint sampler at sample_voxel_size).
+        Returns sampled_indices, num_keypoints and — want_world — the sampled frame under pose14 (the initial estimate).
+        raw = t = None: the scan stage() uploaded."""
+        if raw is None:
+            n = self._staged_n
+            raw = np.zeros((0, 3))
+            t = np.zeros(0)
+            prestaged = True
+        else:
+            prestaged = False
+            raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 3)
+            t = np.ascontiguousarray(t, dtype=np.float64).ravel()
+            n = len(raw)
         pose = np.ascontiguousarray(pose14, dtype=np.float64)
         tbe = np.ascontiguousarray(t_begin_end, dtype=np.float64)
         fo = L.FrameOptions(float(self.frame_voxel_size), float(self.sample_voxel_size), int(self.max_num_keypoints),
@@ -310,7 +331,8 @@ class FramePipeline:
             order = np.ascontiguousarray(order, dtype=np.uint32)
             assert len(order) == n
         dp = C.POINTER(C.c_double)
-        L.check(self._h, L.lib().ctgn_frame_begin(self._h, L.View(raw.ctypes.data, 24, L.CTGN_F64, 0), L.View(t.ctypes.data, 8, L.CTGN_F64, 0), n,
+        L.check(self._h, L.lib().ctgn_frame_begin(self._h, L.View(None if prestaged else raw.ctypes.data, 24, L.CTGN_F64, 0),
+                                                 L.View(None if prestaged else t.ctypes.data, 8, L.CTGN_F64, 0), n,
                                                  order.ctypes.data if order is not None else None, C.byref(fo), pose.ctypes.data_as(dp),
                                                  tbe.ctypes.data_as(dp), C.byref(out)))
         self._last_n, self._last_n1 = n, int(out.num_sampled)

@@ -467,6 +467,12 @@ ctgn_status ctgn_frame_register(ctgn_handle h, ctgn_view raw_xyz, ctgn_view time
  *                            out->all_world_* = every scan point, out->sampled_world_* = the sampled frame; the latter stays on the device as
  *                            the batch ctgn_frame_update_map inserts.
  * fopts->frame_voxel_size / override_timestamp(s) are read by ctgn_frame_begin only. Same error conventions as ctgn_frame_register. */
+/* Optional first half of ctgn_frame_begin for a caller whose `order` takes time to make (std::shuffle of 132 k indices: 0.4-1 ms of one
+ * host core): stages and uploads the scan in scan order and returns; the caller computes the order on ANOTHER thread meanwhile and hands it
+ * to ctgn_frame_begin with raw_xyz.base == NULL and the same n ("the staged scan": the processing order is applied on the device either
+ * way). fopts: override_timestamp(s) are read here; pose_initial / t_begin_end as for ctgn_frame_begin (which may pass others). */
+ctgn_status ctgn_frame_stage(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const ctgn_frame_options *fopts,
+                             const double pose_initial[14], const double t_begin_end[2]);
 ctgn_status ctgn_frame_begin(ctgn_handle h, ctgn_view raw_xyz, ctgn_view timestamps, size_t n, const uint32_t *order,
                              const ctgn_frame_options *fopts, const double pose_initial[14], const double t_begin_end[2],
                              ctgn_frame_outputs *out);

@@ -113,16 +113,6 @@ namespace ct_icp {
         auto t0 = std::chrono::steady_clock::now();
         ctgn_frame_options fo;
         ctgn_frame_options_default(&fo);
-        if (shuffle_on_device) {
-            fo.shuffle_seed = g() | 1u;                                                                    // one draw instead of :349's n
-        } else {
-            session.order.resize(n);
-            std::iota(session.order.begin(), session.order.end(), 0u);
-            std::shuffle(session.order.begin(), session.order.end(), g);                                   // :349
-        }
-        session.ms_shuffle = ctgn_glue::ms_since(t0);
-
-        t0 = std::chrono::steady_clock::now();
         fo.frame_voxel_size = kIsAtStartup ? options.init_voxel_size : options.voxel_size;                 // :339-340
         // the keypoint voxel TryRegister will ask for first (odometry.cpp:422-423, :1038-1039): sampled in the same pass
         fo.sample_voxel_size = options.sampling == sampling::GRID
@@ -132,9 +122,36 @@ namespace ct_icp {
         fo.override_timestamp = frame_info.end_timestamp;
         double pose[14], tbe[2];
         ctgn_glue::pose_to_array(tr_frame, pose, tbe);
+        bool prestaged = false;
+        if (shuffle_on_device) {
+            fo.shuffle_seed = g() | 1u;                                                                    // one draw instead of :349's n
+        } else {
+            // the reference's shuffle on this thread, the upload of the scan (it travels in scan order; the order is applied on the device)
+            // on another one meanwhile — when the build has OpenMP threads to spare (the reference's own loops at :469,:480 use them)
+            session.order.resize(n);
+            ctgn_status staged = CTGN_ERR_UNSUPPORTED;
+#pragma omp parallel sections num_threads(2)
+            {
+#pragma omp section
+                {
+                    std::iota(session.order.begin(), session.order.end(), 0u);
+                    std::shuffle(session.order.begin(), session.order.end(), g);                           // :349
+                    session.ms_shuffle = ctgn_glue::ms_since(t0);
+                }
+#pragma omp section
+                {
+                    if (options.ct_icp_options.ls_num_threads > 1) staged = ctgn_frame_stage(gpu_map->handle(), raw, ts, n, &fo, pose, tbe);
+                }
+            }
+            prestaged = staged == CTGN_OK;
+        }
+        if (shuffle_on_device) session.ms_shuffle = ctgn_glue::ms_since(t0);
+
+        t0 = std::chrono::steady_clock::now();
         session.sampled.resize(n);
         ctgn_frame_outputs out{};
         out.sampled_indices = session.sampled.data();
+        if (prestaged) raw.base = nullptr;                                                                 // "the scan ctgn_frame_stage uploaded"
         ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw, ts, n, shuffle_on_device ? nullptr : session.order.data(), &fo, pose,
                                                     tbe, &out), gpu_map->handle());
         const size_t n1 = (size_t) out.num_sampled;

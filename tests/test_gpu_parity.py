@@ -1021,7 +1021,11 @@ def test_frame_steps_equal_the_one_call_pipeline(street_case, shuffled):
         options = o if j != 7 else cia.CTICPOptions(solver=cia.CERES, num_iters_icp=4, ls_max_num_iters=4, min_number_neighbors=10,
                                                     debug_print=False)
         a = fa.register(sc.raw, sc.t, pose0, sc.t_begin_end, options, motion_model=mm, order=order)
-        b0 = fb.begin(sc.raw, sc.t, pose0, sc.t_begin_end, order=order, want_world=(j == 6))
+        if j % 2:                             # both spellings of the upload: in one call, or ahead of the order (ctgn_frame_stage)
+            b0 = fb.begin(sc.raw, sc.t, pose0, sc.t_begin_end, order=order, want_world=(j == 6))
+        else:
+            fb.stage(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end)
+            b0 = fb.begin(None, None, pose0, sc.t_begin_end, order=order, want_world=(j == 6))
         assert np.array_equal(a["sampled_indices"], b0["sampled_indices"])
         if j == 6:                            # InitializeFrame's transform (odometry.cpp:371-375): the sampled frame under the initial estimate
             want = cia.transform_points(ga, sc.raw[b0["sampled_indices"]], sc.t[b0["sampled_indices"]], pose0, sc.t_begin_end)
@@ -1064,6 +1068,12 @@ def test_frame_steps_equal_the_one_call_pipeline(street_case, shuffled):
         fresh.undistort(sc.pose_gt, sc.t_begin_end)
     with pytest.raises(cia.CtgnError):
         fb.undistort(sc.pose_gt, (sc.t_begin_end[0] + 0.05, sc.t_begin_end[1]))
+    fb._staged_n = len(sc.t)
+    with pytest.raises(cia.CtgnError):        # nothing staged ahead
+        fb.begin(None, None, sc.pose_gt, sc.t_begin_end)
+    fb.stage(sc.raw, sc.t, sc.pose_gt, sc.t_begin_end)
+    with pytest.raises(cia.CtgnError):        # a staged scan, but an order that is no permutation (checked on the device)
+        fb.begin(None, None, sc.pose_gt, sc.t_begin_end, order=np.zeros(len(sc.t), dtype=np.uint32))
 
 
 @pytest.mark.parametrize("shuffled", [False, True])

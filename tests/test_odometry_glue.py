@@ -166,7 +166,7 @@ def test_armed_register_frame_against_the_unarmed_one(solver):
     kw = dict(solver=ro.GN if solver == "GN" else ro.CERES, ls_num_threads=1)
     plain = ro.RefOdometry(ro.GPU_MAP, **kw)
     off = ro.RefOdometry(ro.GPU_MAP, armed_library=True, **kw)
-    armed = ro.RefOdometry(ro.GPU_MAP_ARMED, **kw)
+    armed = ro.RefOdometry(ro.GPU_MAP_ARMED, **dict(kw, ls_num_threads=4))     # threads to spare: the scan is uploaded beside the shuffle
     from ct_icp_amd import se3
     gap, ms = 0.0, {"plain": [], "armed": []}
     for j, (raw, t) in enumerate(scans):
