@@ -144,6 +144,8 @@ SYMBOLS = {
     "ctgn_frame_register": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options),
                                       C.POINTER(MotionPrior), C.POINTER(RobustOptions), C.POINTER(RobustPrior),
                                       C.POINTER(FrameOutputs), C.POINTER(Summary)]),
+    "ctgn_host_alloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ctgn_host_free": (C.c_int, [_H, C.c_void_p]),
     "ctgn_frame_stage": (C.c_int, [_H, View, View, C.c_size_t, C.POINTER(FrameOptions), _dp, _dp]),
     "ctgn_frame_begin": (C.c_int, [_H, View, View, C.c_size_t, C.c_void_p, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(FrameOutputs)]),
     "ctgn_frame_try_register": (C.c_int, [_H, C.POINTER(FrameOptions), _dp, _dp, C.POINTER(Options), C.POINTER(MotionPrior),

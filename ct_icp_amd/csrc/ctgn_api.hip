@@ -2839,6 +2839,22 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
     return CTGN_OK;
 }
 
+ctgn_status ctgn_host_alloc(ctgn_handle h, size_t bytes, void **out) {
+    NEED_DEVICE(h);
+    if (!out || bytes == 0) return CTGN_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    HIPCHK(h, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return CTGN_OK;
+}
+
+ctgn_status ctgn_host_free(ctgn_handle h, void *p) {
+    NEED_DEVICE(h);
+    if (!p) return CTGN_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // no transfer of this handle is still using it
+    HIPCHK(h, hipHostFree(p));
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_t n, const ctgn_frame_options *fo, const double pose[14],
                              const double tbe[2]) {
     NEED_DEVICE(h);

@@ -480,6 +480,12 @@ ctgn_status ctgn_frame_try_register(ctgn_handle h, const ctgn_frame_options *fop
                                     const ctgn_options *opts, const ctgn_motion_prior *prior, const ctgn_robust_options *robust,
                                     const ctgn_robust_prior *robust_prior, ctgn_frame_outputs *out, ctgn_summary *summary);
 ctgn_status ctgn_frame_undistort(ctgn_handle h, const double pose[14], const double t_begin_end[2], ctgn_frame_outputs *out);
+/* Page-locked host memory for the caller's scan and output arrays: ctgn_frame_register / ctgn_frame / ctgn_frame_begin read x y z rows of
+ * doubles + timestamps living in such memory in place, and ctgn_frame_register / ctgn_frame_undistort write `all_world` rows of three doubles
+ * there in place (no staging copy either way). Plain hipHostMalloc / hipHostFree behind a C signature, for hosts that do
+ * not link the HIP runtime themselves. */
+ctgn_status ctgn_host_alloc(ctgn_handle h, size_t bytes, void **out);
+ctgn_status ctgn_host_free(ctgn_handle h, void *p);
 /* UpdateMap for the resident frame (odometry.cpp:936-952): RemoveElementsFarFromLocation(location, max_distance) on every level,
  * then — if add_points — insert the sampled frame's undistorted points. Needs the device-resident map (ctgn_map_set_update_mode 1).
  * inserted (host, num_sampled bytes, may be NULL): 1 where the point entered some level. */

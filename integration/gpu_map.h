@@ -78,7 +78,10 @@ namespace ct_icp {
             if (options.device_updates) ctgn_map_set_update_mode(handle_, 1);
         }
 
-        ~GpuVoxelMap() override { ctgn_destroy(handle_); }
+        ~GpuVoxelMap() override {
+            if (session_.rows) ctgn_host_free(handle_, session_.rows);
+            ctgn_destroy(handle_);
+        }
 
         GpuVoxelMap(const GpuVoxelMap &) = delete;
 
@@ -99,6 +102,8 @@ namespace ct_icp {
             std::vector<uint32_t> position;    // position[sampled[k]] = k (only those entries are meaningful)
             std::vector<uint32_t> keypoints;   // scan index of keypoint k
             std::vector<double> world;         // world points of a read-back, x y z rows
+            double *rows = nullptr;            // page-locked x y z rows for every scan point's world point (ctgn_host_alloc): the undistortion
+            size_t rows_capacity = 0;          // lands there by DMA, the fill loop of all_corrected_points reads it
             bool world_initialised = false;    // the host image of the sampled frame carries its world points under the initial estimate
             // host milliseconds of the arms' steps, for RegistrationSummary::logged_values (odometry_gpu_*)
             double ms_shuffle = 0, ms_begin = 0, ms_build_frame = 0, ms_fill = 0, ms_undistort = 0;

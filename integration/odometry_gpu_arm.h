@@ -66,6 +66,19 @@ namespace ct_icp {
             SLAM_CHECK_STREAM(st == CTGN_OK, "libctgn: " << ctgn_last_error(h));
         }
 
+        // element i of a view whose source is FLOAT32 / FLOAT64 (what view_of accepted), without the per-access dispatch of a ProxyView
+        inline Eigen::Vector3d point_of(const ctgn_view &v, size_t i) {
+            const char *p = static_cast<const char *>(v.base) + i * v.stride_bytes;
+            if (v.dtype == CTGN_F64) { const double *q = reinterpret_cast<const double *>(p); return Eigen::Vector3d(q[0], q[1], q[2]); }
+            const float *q = reinterpret_cast<const float *>(p);
+            return Eigen::Vector3d(q[0], q[1], q[2]);
+        }
+
+        inline double scalar_of(const ctgn_view &v, size_t i) {
+            const char *p = static_cast<const char *>(v.base) + i * v.stride_bytes;
+            return v.dtype == CTGN_F64 ? *reinterpret_cast<const double *>(p) : (double) *reinterpret_cast<const float *>(p);
+        }
+
         inline double ms_since(std::chrono::steady_clock::time_point t0) {
             return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -130,7 +143,9 @@ namespace ct_icp {
             // on another one meanwhile — when the build has OpenMP threads to spare (the reference's own loops at :469,:480 use them)
             session.order.resize(n);
             ctgn_status staged = CTGN_ERR_UNSUPPORTED;
-#pragma omp parallel sections num_threads(2)
+            const ctgn_view raw_in = raw, ts_in = ts;
+#pragma omp parallel num_threads(std::max(2, options.ct_icp_options.ls_num_threads))
+#pragma omp sections
             {
 #pragma omp section
                 {
@@ -140,7 +155,7 @@ namespace ct_icp {
                 }
 #pragma omp section
                 {
-                    if (options.ct_icp_options.ls_num_threads > 1) staged = ctgn_frame_stage(gpu_map->handle(), raw, ts, n, &fo, pose, tbe);
+                    if (options.ct_icp_options.ls_num_threads > 1) staged = ctgn_frame_stage(gpu_map->handle(), raw_in, ts_in, n, &fo, pose, tbe);
                 }
             }
             prestaged = staged == CTGN_OK;
@@ -151,9 +166,10 @@ namespace ct_icp {
         session.sampled.resize(n);
         ctgn_frame_outputs out{};
         out.sampled_indices = session.sampled.data();
-        if (prestaged) raw.base = nullptr;                                                                 // "the scan ctgn_frame_stage uploaded"
-        ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw, ts, n, shuffle_on_device ? nullptr : session.order.data(), &fo, pose,
-                                                    tbe, &out), gpu_map->handle());
+        ctgn_view raw_begin = raw;
+        if (prestaged) raw_begin.base = nullptr;                                                           // "the scan ctgn_frame_stage uploaded"
+        ctgn_glue::fatal_unless_ok(ctgn_frame_begin(gpu_map->handle(), raw_begin, ts, n, shuffle_on_device ? nullptr : session.order.data(), &fo,
+                                                    pose, tbe, &out), gpu_map->handle());
         const size_t n1 = (size_t) out.num_sampled;
         session.ms_begin = ctgn_glue::ms_since(t0);
         t0 = std::chrono::steady_clock::now();
@@ -170,8 +186,8 @@ namespace ct_icp {
             const size_t i = session.sampled[k];
             session.position[i] = (uint32_t) k;
             auto &point = frame[k];
-            point.raw_point.point = view_xyz[i];
-            point.raw_point.timestamp = kIndexFrame <= 1 ? frame_info.end_timestamp : double(view_timestamps[i]);
+            point.raw_point.point = ctgn_glue::point_of(raw, i);
+            point.raw_point.timestamp = kIndexFrame <= 1 ? frame_info.end_timestamp : ctgn_glue::scalar_of(ts, i);
             point.world_point = point.raw_point.point;                                                     // :345
             point.index_frame = frame_info.frame_id;                                                       // :377-379
         }
@@ -277,10 +293,22 @@ namespace ct_icp {
             return false;
         const size_t n = session.num_points;
         auto t0 = std::chrono::steady_clock::now();
+        ctgn_view raw, ts;
+        if (!ctgn_glue::view_of(const_frame.XYZConst<double>(), &raw) || !ctgn_glue::view_of(const_frame.TimestampsProxy<double>(), &ts)) return false;
+        if (session.rows_capacity < n) {                   // page-locked rows for the read-back (kept from frame to frame)
+            if (session.rows) ctgn_host_free(gpu_map->handle(), session.rows);
+            session.rows = nullptr;
+            session.rows_capacity = 0;
+            void *p = nullptr;
+            if (ctgn_host_alloc(gpu_map->handle(), (n + n / 4) * 3 * sizeof(double), &p) == CTGN_OK) {
+                session.rows = static_cast<double *>(p);
+                session.rows_capacity = n + n / 4;
+            } else {
+                session.world.resize(3 * n);               // plain memory does too (the library copies instead of the DMA engine)
+            }
+        }
+        double *rows = session.rows ? session.rows : session.world.data();
         summary.corrected_points = frame;                                                                  // :462
-        summary.all_corrected_points.resize(n);                                                            // :463
-        auto raw_points_view = const_frame.XYZConst<double>();
-        auto timestamps_view = const_frame.TimestampsProxy<double>();
         const auto &begin_pose = summary.frame.begin_pose;
         const auto &end_pose = summary.frame.end_pose;
         // the first two frames were staged with every timestamp at the end of the sweep (:355-359), but all_corrected_points carries the
@@ -290,8 +318,8 @@ namespace ct_icp {
         ctgn_glue::pose_to_array(summary.frame, pose, tbe);
         ctgn_frame_outputs out{};
         if (all_on_device) {
-            out.all_world_base = summary.all_corrected_points[0].world_point.data();
-            out.all_world_stride_bytes = sizeof(slam::WPoint3D);
+            out.all_world_base = rows;
+            out.all_world_stride_bytes = 3 * sizeof(double);
             out.all_world_dtype = CTGN_F64;
         }
         if (!summary.corrected_points.empty()) {
@@ -301,8 +329,8 @@ namespace ct_icp {
         }
         ctgn_status st = CTGN_OK;
         double ms_device = 0.;
-        // one thread drives the device (it writes world_point of every record), the others fill raw point, timestamp and frame id of
-        // all_corrected_points meanwhile (disjoint bytes of the records); the driver joins the loop when the device is done
+        // one thread drives the device (every scan point's world point arrives as rows), another sizes all_corrected_points meanwhile; then
+        // the team fills the records: raw point, timestamp, frame id (:472-474) and the world point from the rows
 #pragma omp parallel num_threads(num_threads)
         {
 #pragma omp single nowait
@@ -311,13 +339,17 @@ namespace ct_icp {
                 st = ctgn_frame_undistort(gpu_map->handle(), pose, tbe, &out);
                 ms_device = ctgn_glue::ms_since(t1);
             }
-#pragma omp for schedule(dynamic, 8192)
-            for (auto i = 0; i < summary.all_corrected_points.size(); ++i) {                               // :470-478
+#pragma omp single nowait
+            summary.all_corrected_points.resize(n);                                                        // :463
+#pragma omp barrier
+#pragma omp for schedule(static)
+            for (auto i = 0; i < n; ++i) {                                                                 // :470-478
                 auto &point = summary.all_corrected_points[i];
-                point.RawPoint() = raw_points_view[i];
-                point.Timestamp() = timestamps_view[i];
+                point.RawPoint() = ctgn_glue::point_of(raw, i);
+                point.Timestamp() = ctgn_glue::scalar_of(ts, i);
                 point.index_frame = frame_info.frame_id;
-                if (!all_on_device) point.WorldPoint() = begin_pose.ContinuousTransform(point.RawPoint(), end_pose, point.Timestamp());
+                if (all_on_device) point.WorldPoint() = Eigen::Vector3d(rows[3 * i], rows[3 * i + 1], rows[3 * i + 2]);
+                else point.WorldPoint() = begin_pose.ContinuousTransform(point.RawPoint(), end_pose, point.Timestamp());
             }
         }
         ctgn_glue::fatal_unless_ok(st, gpu_map->handle());
