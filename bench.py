@@ -111,16 +111,60 @@ def collect_pmc(args, workload=None, groups=None, steps=None, timeout: int = 150
                   "(all search-kernel launches of an iteration), means over the second half of the inner run")
 
 
+def arrays_sha256(d) -> str:
+    """SHA-256 over names, dtypes, shapes and bytes of a dict of arrays (sorted by name)."""
+    import hashlib
+    hs = hashlib.sha256()
+    for k in sorted(d):
+        a = np.ascontiguousarray(d[k])
+        hs.update(f"{k}|{a.dtype.str}|{a.shape}|".encode())
+        hs.update(a.tobytes())
+    return hs.hexdigest()
+
+
+def _generator_fingerprint() -> str:
+    """What the cached inputs depend on besides their parameters: the generator's source."""
+    import hashlib
+    with open(os.path.join(ROOT, "ct_icp_amd", "synthetic.py"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def cache_load(path: str, params: dict):
+    """A cached input set, or None when the file is absent, was written for other generator parameters (or another generator), or does not
+    hash to what it says it holds: .bench_cache/ is git-ignored and travels to the GPU box with the push, so nothing in it is trusted —
+    a mismatch means the inputs are ray-cast again."""
+    if not os.path.exists(path):
+        return None
+    try:
+        d = np.load(path, allow_pickle=False)
+        want = json.dumps(dict(params, generator=_generator_fingerprint()), sort_keys=True)
+        if "__params__" not in d.files or "__sha256__" not in d.files or str(d["__params__"]) != want:
+            return None
+        out = {k: d[k] for k in d.files if not k.startswith("__")}
+        return out if arrays_sha256(out) == str(d["__sha256__"]) else None
+    except Exception:        # noqa: BLE001 — a damaged cache file is a cache miss
+        return None
+
+
+def cache_save(path: str, out: dict, params: dict) -> None:
+    try:
+        np.savez(path, __params__=np.array(json.dumps(dict(params, generator=_generator_fingerprint()), sort_keys=True)),
+                 __sha256__=np.array(arrays_sha256(out)), **out)
+    except OSError:
+        pass
+
+
 def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, ".bench_cache")):
     """Deterministic config-B inputs: map insert list (world points of `map_frames` preceding sweeps after the 0.5 m
     frame grid) + the sweep to register. Cached as .npz because ray-casting 21 sweeps in NumPy takes ~30 s."""
     from ct_icp_amd import synthetic as syn
-    tag = f"ctgn_bench_B_v3_r{rank}_m{map_frames}.npz"
+    tag = f"ctgn_bench_B_v4_r{rank}_m{map_frames}.npz"
     os.makedirs(cache_dir, exist_ok=True)
     path = os.path.join(cache_dir, tag)
-    if os.path.exists(path):
-        d = np.load(path)
-        return {k: d[k] for k in d.files}
+    params = dict(workload="B", rank=rank, map_frames=map_frames, scene="street_scene(400, seed 1)", pattern="hdl64", trajectory_seed=0, noise=0.02)
+    cached = cache_load(path, params)
+    if cached is not None:
+        return cached
     scene = syn.street_scene(400.0, seed=1)
     dirs, rel_t = syn.lidar_pattern("hdl64")
     knots = syn.driving_trajectory(map_frames + 2, seed=0, start_x=20.0)
@@ -134,10 +178,7 @@ def make_inputs(rank: int, map_frames: int, cache_dir: str = os.path.join(ROOT, 
                            seed=1000 + 17 * rank)
     out = dict(map_points=np.concatenate(map_pts), map_counts=np.array([len(m) for m in map_pts]), raw=sc.raw, t=sc.t,
                pose_gt=sc.pose_gt, tbe=sc.t_begin_end, prev_b=knots[j - 1, 4:7], prev_e=knots[j, 4:7])
-    try:
-        np.savez(path, **out)
-    except OSError:
-        pass
+    cache_save(path, out, params)
     return out
 
 
@@ -151,20 +192,17 @@ def make_inputs_large(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cac
     scene = syn.suburb_scene(seed=7, n_buildings=220, n_trees=4000)
     knots = syn.driving_trajectory(3, seed=0, start_x=20.0)
     map_points = syn.sample_scene_surfaces(scene, knots[1, 4:7], radius=100.0, density=70.0, noise=0.02, seed=5)
-    tag = f"ctgn_bench_B2L_v1_r{rank}.npz"
+    tag = f"ctgn_bench_B2L_v2_r{rank}.npz"
     os.makedirs(cache_dir, exist_ok=True)
     path = os.path.join(cache_dir, tag)
-    if os.path.exists(path):
-        d = np.load(path)
-        scan = {k: d[k] for k in d.files}
-    else:
+    params = dict(workload="B2", rank=rank, scene="suburb_scene(seed 7, 220 buildings, 4000 trees)", pattern="hdl64", trajectory_seed=0, noise=0.02,
+                  scan_seed=1000 + 17 * rank)
+    scan = cache_load(path, params)
+    if scan is None:
         dirs, rel_t = syn.lidar_pattern("hdl64")
         sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 1), 0.1, 0.2, noise=0.02, seed=1000 + 17 * rank)
         scan = dict(raw=sc.raw, t=sc.t, pose_gt=sc.pose_gt, tbe=sc.t_begin_end)
-        try:
-            np.savez(path, **scan)
-        except OSError:
-            pass
+        cache_save(path, scan, params)
     return dict(map_points=map_points, prev_b=knots[0, 4:7], prev_e=knots[1, 4:7], **scan)
 
 
@@ -175,10 +213,11 @@ def make_inputs_nclt(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cach
     Cached: nine small ray-cast sweeps."""
     from ct_icp_amd import synthetic as syn
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"ctgn_bench_C_v1_r{rank}.npz")
-    if os.path.exists(path):
-        d = np.load(path)
-        return {k: d[k] for k in d.files}
+    path = os.path.join(cache_dir, f"ctgn_bench_C_v2_r{rank}.npz")
+    params = dict(workload="C", rank=rank, scene="street_scene(150, seed 2, half width 7-9)", pattern="hdl32 x 1800", trajectory_seed=2, noise=0.02)
+    cached = cache_load(path, params)
+    if cached is not None:
+        return cached
     scene = syn.street_scene(150.0, seed=2, half_width=(7.0, 9.0))
     dirs, rel_t = syn.lidar_pattern("hdl32", azimuth_steps=1800)
     knots = syn.driving_trajectory(10, dt=0.1, speed=2.0, yaw_rate=0.3, height=1.0, jitter=0.02, seed=2, start_x=20.0)
@@ -188,10 +227,7 @@ def make_inputs_nclt(rank: int, cache_dir: str = os.path.join(ROOT, ".bench_cach
         map_pts.append(sc.world_gt[syn.grid_sample_indices(sc.raw, 0.5)])                   # odometry voxel_size 0.5 (nclt_config.yaml:32)
     sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, 8), 0.8, 0.9, max_range=60.0, noise=0.02, seed=208 + 17 * rank)
     out = dict(map_points=np.concatenate(map_pts), raw=sc.raw, t=sc.t, pose_gt=sc.pose_gt, tbe=sc.t_begin_end, prev_b=knots[7, 4:7], prev_e=knots[8, 4:7])
-    try:
-        np.savez(path, **out)
-    except OSError:
-        pass
+    cache_save(path, out, params)
     return out
 
 
@@ -244,6 +280,8 @@ def build_workload(name, rank, world, args, cia, syn, se3):
         inp = make_inputs_nclt(rank)
     else:
         inp = make_inputs(rank, args.map_frames)
+    # what was measured, whatever it was loaded from: the scan to register, its poses and the map's insert list
+    inputs_sha16 = arrays_sha256({k: inp[k] for k in ("map_points", "raw", "t", "pose_gt", "tbe")})[:16]
     gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in res_list], default_radius=radius, device=args.local_rank))
     for s0 in range(0, len(inp["map_points"]), 2_000_000):
         gm.InsertPointCloud(inp["map_points"][s0:s0 + 2_000_000])
@@ -265,7 +303,7 @@ def build_workload(name, rank, world, args, cia, syn, se3):
     lv = searched[0]
     level_mb = (gm.NumVoxels(lv) * res_list[lv][2] * 24 + (1 << int(np.ceil(np.log2(max(gm.NumVoxels(lv), 1) * 4)))) * 16) / 1e6
     return dict(name=name, inp=inp, gm=gm, res_list=res_list, radius=radius, ipf=ipf, min_nb=min_nb, raw=raw, t=t, world0=world0, pose0=pose0,
-                mm=mm, level=lv, level_mb=level_mb, nb=searched[2])
+                mm=mm, level=lv, level_mb=level_mb, nb=searched[2], inputs_sha16=inputs_sha16)
 
 
 def oracle_map(W):
@@ -817,7 +855,12 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"keypoints sharded x{world} (home-voxel sort, contiguous chunks), map replicated, "
                                                                       + ("1 ncclAllReduce(96 f64) per iteration issued by the library" if not args.torch_collective else
                                                                          f"1 torch.distributed all_reduce(96 f64) per iteration, backend {args.dist_backend}"),
-                       "kernel_variant": args.variant, "keypoint_ordering": args.order},
+                       "kernel_variant": args.variant, "keypoint_ordering": args.order, "inputs_sha16": W["inputs_sha16"],
+                       "inputs_note": "synthetic, deterministic from the seeds in bench.py; cached scans under .bench_cache/ carry their generator "
+                                      "parameters + a SHA-256 of their arrays, verified on load (mismatch = regenerated); inputs_sha16 = SHA-256 of "
+                                      "the arrays actually measured (map insert list, scan, timestamps, ground-truth pose)"
+                                      + ("; the map is the scene's surfaces within the 100 m eviction radius sampled directly (6.9 M points after the "
+                                         "insert rule = the steady-state driving-profile map), larger than SURVEY 8d's 20-frame map" if args.workload == "B2" else "")},
             "step_definition": f"one GN iteration; the K timed steps are FRESH solves of the profile's budget ({res['iterations_per_solve']} iterations each, "
                                "ct_icp.cpp:745): per solve the uploaded world points are put back on the device, gn_begin, then the iterations — the first search "
                                "of every solve has no carried-over bound, exactly as a frame pays it",
@@ -862,6 +905,17 @@ def main():
                     result["config_e"] = ce
                 except Exception as e:
                     result["config_e_error"] = f"{type(e).__name__}: {e}"[:300]
+                # ... and what the same scans cost through the reference's own Odometry::RegisterFrame (bounded: 100 frames of sequence 0)
+                if not args.no_cpu_baseline and world == 1 and isinstance(result.get("config_e"), dict):
+                    try:
+                        ro_ = measure_reference_odometry(syn, 100, local_rank)
+                        if ro_:
+                            result["config_e"]["reference_odometry"] = ro_
+                            result["config_e"]["reference_odometry_on_gpu_map_frames_per_sec"] = {
+                                "unarmed": ro_["gpu_map"]["frames_per_sec"], "armed": ro_["gpu_map_armed"]["frames_per_sec"],
+                                "armed_device_shuffle": ro_["gpu_map_armed_device_shuffle"]["frames_per_sec"], "cpu_map": ro_["cpu_map"]["frames_per_sec"]}
+                    except Exception as e:
+                        result["config_e"]["reference_odometry_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline and args.workload in ("B2", "B2-small") and world == 1:      # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(inp, W["pose0"], W["world0"], args, om)
             if result["cpu_baseline"]["value"]:
@@ -895,6 +949,7 @@ def main():
                 sres, som = measure_workload(Ws, args, cia, torch, None, False, sub_steps, 10 if small else 5, 100 if small else 10, want_steady=True,
                                              cpu_seconds=8.0, register_extras=small, pmc_live=(name in args.sub_pmc.split(",") and not args.no_pmc))
                 sres["config"] = NAMES[name]
+                sres["inputs_sha16"] = Ws["inputs_sha16"]
                 if name == "D":
                     sres["config_detail"] = {"rays": int(Ws["inp"]["rays"]), "returns": int(Ws["inp"]["returns"])}
                 sres["wall_seconds"] = time.perf_counter() - t_sub
@@ -1007,9 +1062,9 @@ def compact_line(result) -> str:
     is in the detail file (`bench_detail.json`, next to this script and under gpurun_out/ when that directory exists)."""
     line = _pick(result, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     cfg = result.get("config", {})
-    line["config"] = _pick(cfg, "workload_id", "keypoints_per_gpu", "keypoints_total", "map_points", "searched_level_mb", "iterations_per_solve")
-    line["config"]["workload"] = {"B2": "config B2 = BASELINE.json configs[1]: synthetic HDL-64E sweep, every return a keypoint, driving-profile map 0.8 m x 30 pts, "
-                                        "radius 0.75 (27 voxels), k=20, 5-iteration fresh solves",
+    line["config"] = _pick(cfg, "workload_id", "keypoints_per_gpu", "keypoints_total", "map_points", "searched_level_mb", "iterations_per_solve", "inputs_sha16")
+    line["config"]["workload"] = {"B2": "config B2 = BASELINE.json configs[1]: synthetic HDL-64E sweep, every return a keypoint, sampled steady-state driving-profile map "
+                                        "(6.9 M pts, 0.8 m x 30 pts), radius 0.75 (27 voxels), k=20, 5-iteration fresh solves",
                                   "D": "config D = BASELINE.json configs[3]: Ouster-128-style 2.1 M-ray scan, 0.05 m grid keypoints, map 0.5 m x 40 pts within "
                                        "100 m, radius 0.8 (125 voxels), k=20"}.get(cfg.get("workload_id"), str(cfg.get("workload", ""))[:160])
     if "parallelism" in cfg:
@@ -1030,7 +1085,8 @@ def compact_line(result) -> str:
         if isinstance(result["frame_pipeline"].get("page_locked_arrays"), dict):
             line["frame_pipeline"]["page_locked_frame_ms"] = _round(result["frame_pipeline"]["page_locked_arrays"].get("frame_ms"))
     if isinstance(result.get("config_e"), dict):
-        line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures", "scale")
+        line["config_e"] = _pick(result["config_e"], "frames_per_sec", "frames", "sequences", "failures", "scale",
+                                 "reference_odometry_on_gpu_map_frames_per_sec")
     for k in ("strong_scaling_single_gpu_reference", "weak_scaling_line"):
         if isinstance(result.get(k), dict):
             line[k] = _pick(result[k], "value", "ms_per_step", "keypoints", "keypoints_per_gpu", "scaling")
@@ -1093,6 +1149,42 @@ def usable_cores() -> int:
         except (OSError, ValueError, IndexError):
             pass
     return max(1, n)
+
+
+def measure_reference_odometry(syn, frames: int = 100, device: int = 0):
+    """What a caller of the REFERENCE gets: `ct_icp::Odometry::RegisterFrame` — the reference's own src/ct_icp/odometry.cpp, compiled where
+    it lies (oracle/_ref, the checker-side build; the cpu_baseline leg of this file is the one place outside tests/ that may load it) — fed
+    the first `frames` scans of config E's sequence 0 (133 k points each; the vehicle pulls away over 20 frames because that loop starts
+    from the identity, odometry.cpp:276-300), GN solver, driving profile, on four maps: its own MULTI_RESOLUTION_VOXEL_HASHMAP (CPU);
+    GPU_VOXEL_HASHMAP with only Register and the map on the device (integration/gpu_map.h + gn_gpu_arm.h); the same with the four arms of
+    integration/odometry_gpu_arm.h compiled into odometry.cpp (scan resident on the device from InitializeFrame to UpdateMap), once with the
+    reference's own std::shuffle reproduced on the host and once with the shuffle made on the device. Milliseconds per RegisterFrame call
+    past the 20-frame start-up regime (frames 25+)."""
+    from oracle import ref_odometry as ro
+    if not ro.available():
+        return None
+    seed = 10
+    scene = syn.street_scene(max(300.0, frames * 1.2 + 60.0), seed=seed)
+    dirs, rel_t = syn.lidar_pattern("hdl64", azimuth_offset=np.pi)
+    knots = syn.driving_trajectory(frames + 1, seed=seed, start_x=20.0, ramp_frames=20, centered=True)
+    scans = []
+    for j in range(frames):
+        sc = syn.generate_scan(scene, dirs, rel_t, syn.frame_pose14(knots, j), 0.1 * j, 0.1 * (j + 1), noise=0.02, seed=1000 * seed + j, use_torch=True)
+        scans.append((sc.raw, sc.t))
+    out = {"frames": frames, "steady_state_from_frame": 25, "points_per_frame": float(np.mean([len(t) for _, t in scans])), "solver": "GN",
+           "scans": "config E sequence 0 (seed 10), 20-frame ramp from rest"}
+    end = {}
+    for name, kind in (("cpu_map", ro.CPU_MAP), ("gpu_map", ro.GPU_MAP), ("gpu_map_armed", ro.GPU_MAP_ARMED),
+                       ("gpu_map_armed_device_shuffle", ro.GPU_MAP_ARMED_DEVICE_SHUFFLE)):
+        od = ro.RefOdometry(kind, solver=ro.GN, device=device)
+        rs = [od.register_frame(raw, t) for raw, t in scans]
+        od.close()
+        ms = np.array([r["milliseconds"] for r in rs[25:]])
+        end[name] = rs[-1]["pose"][11:14]
+        out[name] = {"ms_per_frame": float(ms.mean()), "ms_per_frame_median": float(np.median(ms)), "frames_per_sec": float(1e3 / ms.mean()),
+                     "failures": int(sum(0 if r["success"] else 1 for r in rs)), "keypoints_mean": float(np.mean([r["sample_size"] for r in rs[25:]]))}
+    out["end_position_gap_to_cpu_map_m"] = {k: float(np.linalg.norm(v - end["cpu_map"])) for k, v in end.items() if k != "cpu_map"}
+    return out
 
 
 def measure_frames_per_sec(cia, gm, inp, syn, se3, mm, reps: int = 30):
