@@ -36,5 +36,5 @@ for it in shown:
     tot = float(sum(pc[:7])) or 1.0
     per_kp = {k_: round(v / solves / n, 1) for k_, v in zip(names, pc[:7])}
     print(json.dumps(dict(workload=wl, iteration=it, launches=solves, wave_cycles_per_keypoint=round(tot / solves / n, 1), waves=pc[11] // max(solves, 1),
-                          certified_frac=round(pc[8] / solves / n, 4),  search_rounds_per_wave=round(pc[9] / max(pc[11], 1), 2),
+                          certified_frac=round(pc[8] / solves / n, 4), certified_same_order_frac=round(pc[7] / solves / n, 4), search_rounds_per_wave=round(pc[9] / max(pc[11], 1), 2),
                           phases_frac={k_: round(v / tot, 3) for k_, v in zip(names, pc[:7])}, wave_cycles_per_keypoint_by_phase=per_kp)))
