@@ -77,7 +77,6 @@ struct Tuning {
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
     double frame_defer_update = 1;  // ctgn_frame_update_map without an insert mask returns once the update is enqueued (0: waits for it)
-    double pool_sums = 1;           // pool checks hand the neighbourhood sums of the keypoints they certify to the residual kernel (0: it gathers them again)
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
@@ -86,7 +85,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
 #define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
-    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update) CTGN_TUNING_KEY(pool_sums)
+    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update)
     CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
@@ -159,7 +158,6 @@ struct ctgn_context {
     bool pose_on_device = false;            // ... and it has been uploaded behind the keypoint arrays
     double *d_kp = nullptr;
     uint32_t *d_res = nullptr;          // [cap_kp][SEL_STRIDE] row-phase -> lane-phase hand-over records
-    double *d_sums = nullptr;           // [cap_kp][12] neighbourhood sums a pool check hands over with a certified keypoint (KpView::sums)
     double *h_kp = nullptr;             // pinned staging, same layout
     double t_min = 0, t_max = 0;
     bool keep_world0 = false;           // ctgn_set_rewind: every upload leaves a copy of its world arrays in d_world0
@@ -645,8 +643,6 @@ KpView kp_view(ctgn_handle h, bool working = false) {
     v.n_dev = nullptr;
     v.resume = 0;
     v.guess2 = 0.f;                     // set per launch (launch_accumulate: first searches over a dense level)
-    v.sums = h->d_sums;
-    v.sums_on = 0;                      // set per launch (launch_accumulate: the GN route's pool checks)
     return v;
 }
 
@@ -740,9 +736,6 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
         if (os != CTGN_OK) return os;
     }
     KpView kv = kp_view(h, !search_only);
-    // the pool checks of the GN route hand the covariance sums of the keypoints they certify to the residual kernel (the robust route's
-    // reader wants the points themselves); tuning pool_sums = 0 switches that off, bit 30 of the ablation mask too
-    kv.sums_on = (!search_only && tuning().pool_sums != 0 && !(h->ablate & (1 << 30)) && h->d_sums) ? 1 : 0;
     h->xr_last = XcdReduce{nullptr, nullptr, 0u};      // set again by launch_residual when the block records get per-XCD pre-sums
     if (!search_only) kv.clk_iter_start = &h->d_state->clk_iter_start;
     // the previous search's k-th distances bound this one — only inside one solve (same keypoints, same map, world points untouched)
@@ -1145,7 +1138,6 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->stream_down) hipStreamDestroy(h->stream_down);
         if (h->ev_frame) hipEventDestroy(h->ev_frame);
         if (h->d_res) hipFree(h->d_res);
-        if (h->d_sums) hipFree(h->d_sums);
         if (h->h_kp) hipHostFree(h->h_kp);
         if (h->d_state) hipFree(h->d_state);
         if (h->h_state) hipHostFree(h->h_state);
@@ -1385,9 +1377,6 @@ static ctgn_status reserve_keypoints(ctgn_handle h, size_t n) {
         // records | counts | pool radius, k-th distance | fail list of the split launches | its two counters (alternating per launch)
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_res), (cap * SEL_STRIDE + 4 * cap + 16) * sizeof(uint32_t)));
         HIPCHK(h, hipMemsetAsync(h->d_res + cap * (SEL_STRIDE + 4), 0, 16 * sizeof(uint32_t), h->stream));
-        if (h->d_sums) HIPCHK(h, hipFree(h->d_sums));
-        h->d_sums = nullptr;
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_sums), cap * 12 * sizeof(double)));      // KpView::sums
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_kp), (cap * 7 + KP_TAIL) * sizeof(double), hipHostMallocDefault));
         h->cap_kp = (int) cap;
     }

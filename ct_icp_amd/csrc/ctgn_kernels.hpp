@@ -74,9 +74,6 @@ struct KpView {
                              // radius; a keypoint it leaves with fewer than k candidates is searched again on the radius (rows_tiles, pass 1)
     int resume;              // k_accumulate_rows: 1 = the positions come from `order` (= a fail list), their world points are current (the
                              // check kernel wrote them) and kth[1] is the bound to search within: no transform, nothing moved
-    double *sums;            // [n][12] neighbourhood sums handed over by a pool check (round 6): Sx Sy Sz | Sxx Sxy Sxz Syy Syz Szz | farthest
-                             // neighbour x y z — valid where cnt[] carries SUMS_FLAG: the residual kernel then gathers nothing for that keypoint
-    int sums_on;             // 1: phase V / k_pool_check compute them for the keypoints they certify
 };
 
 // working copy of the keypoint block in position order (ctgn_api.hip, order_keypoints): dst[a][pos] = src[a][order[pos]]
@@ -813,38 +810,7 @@ __device__ __forceinline__ int row_select(RL &R, int Ln, int k, int sub, int row
 // ---- keypoints whose candidates (nearly) tie: the reference's queue decides, so it is replayed — by the kernels that CONSUME the
 // neighbour records (k_residual_reduce, k_robust_prepare), not by the search kernel, whose registers and instruction stream stay as
 // they are (an inlined replay cost the search kernel 4 % on the B2 sweep). The search kernel only sets TIE_FLAG in the record's count.
-#ifndef CTGN_POOL_SUMS
-#define CTGN_POOL_SUMS 1                       // 0: compile the neighbourhood sums out of the pool checks (A/B builds)
-#endif
 constexpr uint32_t TIE_FLAG = 0x80000000u;
-// cnt[] only (never the record's word 0): the pool check that certified this keypoint's neighbours also left their covariance sums and
-// the farthest of them in KpView::sums — it had the points in registers; the residual kernel would gather the same twenty points again.
-// Cleared by whatever writes the count next (a search hands over offsets only).
-constexpr uint32_t SUMS_FLAG = 0x40000000u;
-constexpr int SUMS_CAP = 20;                   // neighbours whose coordinates the row's LDS corner holds for the summation (k of every shipped profile)
-
-// The sums of ComputeNeighborhood (neighborhood.h:236-244) over the row's n kept points in the reference's order — farthest first, i.e.
-// rank n - 1 down to rank 0 — with products and sums rounded separately (the reference build has no fused multiply-add): bit for bit what
-// residual_tile computes from the gathered points. P: the row's points by rank (x y z rows, LDS). Lane a < 9 of the row owns one of the
-// nine accumulators, lanes 9-11 carry the farthest point; the four rows of a wave run in lockstep to the largest n among them.
-__device__ __forceinline__ void row_neighbourhood_sums(const double *P, int n, bool on, int sub, double *out) {
-#pragma clang fp contract(off)
-    const int a = sub;
-    const int ci = a < 3 ? a : (a < 6 ? 0 : (a < 8 ? 1 : 2));
-    const int cj = a < 3 ? a : (a == 3 ? 0 : (a == 4 || a == 6) ? 1 : 2);
-    const int nmax = max_over_rows(on ? n : 0);
-    double acc = 0.0;
-    for (int r = nmax - 1; r >= 0; --r) {
-        const int rc = min(r, SUMS_CAP - 1);
-        const double pi = P[3 * rc + ci], pj = P[3 * rc + cj];
-        const double term = a < 3 ? pi : pi * pj;
-        if (on && r < n && a < 9) acc = acc + term;
-    }
-    if (on) {
-        if (a < 9) out[a] = acc;
-        else if (a < 12) out[a] = P[3 * (n - 1) + (a - 9)];
-    }
-}
 constexpr uint32_t REC_N_MASK = 63u;           // record word 0: bits 0-5 neighbours kept (n), bits 8-13 pool size (m >= n), bit 31 TIE_FLAG
 constexpr int POOL_REFILL = 4;                 // a keypoint whose pool check fails is searched up to its (k + POOL_REFILL)-th pool member
 constexpr int POOL_EXTRA = 8;                  // spare pool members behind the k neighbours (k + POOL_EXTRA <= KMAX or as many as fit)
@@ -1046,11 +1012,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // search below, bounded by its pool.
         if (POOLS && pool_on && kp.kth_valid && !first_iter && !(ablate & 256) && any64(W.rr2[lane] > 0.f)) {
             compact = true;
-            // the row's probe scratch is idle until phase B: its last 128 bytes hold the row's pool (point byte offsets by pool index), its
-            // front the coordinates of the kept points by rank (row_neighbourhood_sums)
-            uint32_t *T = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&RP) + sizeof(RP) - 128);
-            double *P = reinterpret_cast<double *>(&RP);
-            static_assert(sizeof(RP) >= 128 + 24 * SUMS_CAP && sizeof(RP) % 8 == 0, "the row's probe scratch holds the pool offsets and SUMS_CAP points");
+            uint32_t *T = reinterpret_cast<uint32_t *>(RP.chunk);            // the row's pool: point byte offsets by pool index
             struct PoolRec { uint32_t hdr, o0, o1; };
             struct PoolPts { double x0, y0, z0, x1, y1, z1; };
             auto request = [&](int r, PoolRec &q) {                          // round r's record words
@@ -1095,8 +1057,6 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 const double need2 = n_in >= k ? R.d2[k - 1] : map.r2thr;
                 const bool pass = vrow && need2 * (1.0 + 1e-8) < (double) rr2;
                 const int kp_r = W.id[src];
-                // a certified keypoint the residual kernel will use leaves with its covariance sums (the points are in this row's registers)
-                const bool do_sums = CTGN_POOL_SUMS && kp.sums_on && pass && !tie && n >= prm.min_nb && n >= 5 && n <= SUMS_CAP;
                 if (PROF) pc[8] += (unsigned long long) __popcll(ballot64(pass && sub == 0));
                 if (PROF) {            // pc[7]: certified AND the n neighbours are the previous ones in the previous order
                     const bool same = (sub >= n || R.vis[sub] == (uint32_t) sub) && (sub + 16 >= n || R.vis[sub + 16] == (uint32_t) (sub + 16));
@@ -1108,7 +1068,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     if (sub == 0) {
                         const uint32_t flagged = (uint32_t) n | ((uint32_t) m << 8) | (tie ? TIE_FLAG : 0u);
                         if (flagged != rec_cur.hdr) o[0] = flagged;
-                        kp.cnt[kp_r] = flagged | (do_sums ? SUMS_FLAG : 0u);
+                        kp.cnt[kp_r] = flagged;
                         kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
                         kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
                         W.todo[src] = 0;
@@ -1123,19 +1083,6 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                 } else if (vrow && sub == 0 && n_in >= k + POOL_REFILL) {
                     // searched below, admitting what lies within the (k + 4)-th pool member (a pool again, at the price of four candidates)
                     W.kb[src] = __double2float_ru(R.d2[k + POOL_REFILL - 1] * (1.0 + 0x1p-40));
-                }
-                if (CTGN_POOL_SUMS && any64(do_sums)) {
-                    // rank of this lane's two pool members (the inverse of R.vis, through the selection's idle histogram words), their
-                    // coordinates to the row's LDS corner by rank, then the nine sums in the reference's order
-                    uint8_t *inv = reinterpret_cast<uint8_t *>(R.hist);
-                    if (do_sums) {
-                        if (v0) inv[R.vis[sub]] = (uint8_t) sub;
-                        if (v1) inv[R.vis[sub + 16]] = (uint8_t) (sub + 16);
-                    }
-                    const int r0 = (do_sums && v0) ? (int) inv[sub] : 255, r1 = (do_sums && v1) ? (int) inv[sub + 16] : 255;
-                    if (r0 < n) { P[3 * r0] = pts_cur.x0; P[3 * r0 + 1] = pts_cur.y0; P[3 * r0 + 2] = pts_cur.z0; }
-                    if (r1 < n) { P[3 * r1] = pts_cur.x1; P[3 * r1 + 1] = pts_cur.y1; P[3 * r1 + 2] = pts_cur.z1; }
-                    row_neighbourhood_sums(P, n, do_sums, sub, kp.sums + (size_t) max(kp_r, 0) * 12);
                 }
                 }
                 rec_cur = rec_nxt; rec_nxt = rec_far; pts_cur = pts_nxt;
@@ -1724,9 +1671,6 @@ struct CheckScratch {
     uint8_t todo[64];
     PoolList list[4];
     uint32_t T[4][32];                 // the row's pool: point byte offsets by pool index
-#if CTGN_POOL_SUMS
-    double P[4][32 * 3];               // the row's pool: coordinates by pool index, then — for the summation — by rank
-#endif
 };
 
 template <bool HIST, int WPS>
@@ -1813,13 +1757,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_pool_check(MapView map, KpVi
                     R.d2[sub] = sq_norm3(pts_cur.x0 - qx, pts_cur.y0 - qy, pts_cur.z0 - qz); R.vis[sub] = (uint32_t) sub;
                     R.d2[sub + 16] = sq_norm3(pts_cur.x1 - qx, pts_cur.y1 - qy, pts_cur.z1 - qz); R.vis[sub + 16] = (uint32_t) (sub + 16);
                     T[sub] = rec_cur.o0; T[sub + 16] = rec_cur.o1;
-#if CTGN_POOL_SUMS
-                    if (kp.sums_on) {
-                        double *Pa = W.P[row];
-                        Pa[3 * sub] = pts_cur.x0; Pa[3 * sub + 1] = pts_cur.y0; Pa[3 * sub + 2] = pts_cur.z0;
-                        Pa[3 * (sub + 16)] = pts_cur.x1; Pa[3 * (sub + 16) + 1] = pts_cur.y1; Pa[3 * (sub + 16) + 2] = pts_cur.z1;
-                    }
-#endif
                 }
                 // round r's points and record words are in LDS now: their registers take the next round's points (in flight while this
                 // round is ranked) and the record after that — one set of point registers instead of two
@@ -1835,13 +1772,12 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_pool_check(MapView map, KpVi
                     const double need2 = n_in >= k ? R.d2[k - 1] : map.r2thr;
                     const bool pass = vrow && need2 * (1.0 + 1e-8) < (double) rr2;
                     const int kp_r = W.id[src];
-                    const bool do_sums = CTGN_POOL_SUMS && kp.sums_on && pass && !tie && n >= prm.min_nb && n >= 5 && n <= SUMS_CAP;
                     if (pass) {
                         uint32_t *o = kp.sel + (size_t) kp_r * SEL_STRIDE;
                         if (sub == 0) {
                             const uint32_t flagged = (uint32_t) n | ((uint32_t) m << 8) | (tie ? TIE_FLAG : 0u);
                             if (flagged != rec_cur.hdr) o[0] = flagged;
-                            kp.cnt[kp_r] = flagged | (do_sums ? SUMS_FLAG : 0u);
+                            kp.cnt[kp_r] = flagged;
                             kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
                             kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
                             W.todo[src] = 0;
@@ -1855,19 +1791,6 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_pool_check(MapView map, KpVi
                     } else if (vrow && sub == 0 && n_in >= k + POOL_REFILL) {
                         W.kb[src] = __double2float_ru(R.d2[k + POOL_REFILL - 1] * (1.0 + 0x1p-40));
                     }
-#if CTGN_POOL_SUMS
-                    if (any64(do_sums)) {
-                        // the kept points by rank (they lie in LDS by pool index: each lane moves the two of ranks sub and sub + 16), then the
-                        // nine sums in the reference's order (row_neighbourhood_sums)
-                        double *Pa = W.P[row];
-                        const int e0 = (do_sums && sub < n) ? (int) R.vis[sub] : 0, e1 = (do_sums && sub + 16 < n) ? (int) R.vis[sub + 16] : 0;
-                        const double ax = Pa[3 * e0], ay = Pa[3 * e0 + 1], az = Pa[3 * e0 + 2];
-                        const double bx = Pa[3 * e1], by = Pa[3 * e1 + 1], bz = Pa[3 * e1 + 2];
-                        if (do_sums && sub < n) { Pa[3 * sub] = ax; Pa[3 * sub + 1] = ay; Pa[3 * sub + 2] = az; }
-                        if (do_sums && sub + 16 < n) { Pa[3 * (sub + 16)] = bx; Pa[3 * (sub + 16) + 1] = by; Pa[3 * (sub + 16) + 2] = bz; }
-                        row_neighbourhood_sums(Pa, n, do_sums, sub, kp.sums + (size_t) max(kp_r, 0) * 12);
-                    }
-#endif
                 }
                 rec_cur = rec_nxt; rec_nxt = rec_far;
             }
@@ -1932,14 +1855,10 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             Vec3 res_S{0, 0, 0}, res_q{0, 0, 0};
             Sym3 res_SS{0, 0, 0, 0, 0, 0};
             const uint32_t cnt_raw = kp.cnt[my_kp];
-            // SUMS_FLAG: the pool check that certified this keypoint's neighbours left their sums and the farthest of them (it had the
-            // points in registers): nothing to gather here, no record to read. (The count is read first and the record behind it for the
-            // lanes that need it: the flag is known one load earlier than the offsets would be.)
-            const bool have_sums = CTGN_POOL_SUMS && (cnt_raw & SUMS_FLAG) != 0u;
             uint32_t rec32[SEL_STRIDE];
             {
                 const uint4 *in4 = reinterpret_cast<const uint4 *>(kp.sel + (size_t) my_kp * SEL_STRIDE);
-                const int nq = have_sums ? 0 : (dbg.n_nb != nullptr ? SEL_STRIDE / 4 : min(SEL_STRIDE / 4, (prm.max_nb + 4) >> 2));      // words 0 .. k
+                const int nq = dbg.n_nb != nullptr ? SEL_STRIDE / 4 : min(SEL_STRIDE / 4, (prm.max_nb + 4) >> 2);      // words 0 .. k
 #pragma unroll
                 for (int q = 0; q < SEL_STRIDE / 4; ++q) {
                     uint4 v4 = make_uint4(0u, 0u, 0u, 0u);
@@ -1957,15 +1876,7 @@ __device__ __forceinline__ void residual_tile(const MapView &map, const KpView &
             rec32[0] = (uint32_t) cnt_n | (cnt_raw & TIE_FLAG);
             resolve_ties(map, kp, my_kp, fetch_rec, rec32, tie, lane, prm.max_nb);      // rare: see TIE_FLAG
             res_n = (ablate & 4) ? 0 : min((int) rec32[0], KMAX);
-            int gat_n = ((res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr) ? res_n : 0;
-            if (have_sums) {
-                const double2 *sp = reinterpret_cast<const double2 *>(kp.sums + (size_t) my_kp * 12);
-                const double2 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
-                res_S = Vec3{s0.x, s0.y, s1.x};
-                res_SS = Sym3{s1.y, s2.x, s2.y, s3.x, s3.y, s4.x};
-                res_q = Vec3{s4.y, s5.x, s5.y};
-                gat_n = 0;
-            }
+            const int gat_n = ((res_n >= prm.min_nb && res_n >= 5) || dbg.n_nb != nullptr) ? res_n : 0;
             // mean / covariance sums over the kept neighbours in the reference's order: its neighbour vector is
             // farthest-first (map.h:508-513) and ComputeNeighborhood sums it front to back (neighborhood.h:236-240) — the
             // record is nearest-first, so it is walked from entry n - 1 down to entry 0. Sums strictly in order, products and sums
