@@ -810,6 +810,16 @@ __device__ __forceinline__ int row_select(RL &R, int Ln, int k, int sub, int row
 // ---- keypoints whose candidates (nearly) tie: the reference's queue decides, so it is replayed — by the kernels that CONSUME the
 // neighbour records (k_residual_reduce, k_robust_prepare), not by the search kernel, whose registers and instruction stream stay as
 // they are (an inlined replay cost the search kernel 4 % on the B2 sweep). The search kernel only sets TIE_FLAG in the record's count.
+// The distances the searches carry from one iteration to the next (KpView::kth) are BOUNDS: a k-th neighbour's distance rounded up, a pool's
+// completeness radius rounded down. They used to be taken with a double-precision square root (a ~30-instruction sequence, twice per hand-over
+// and per pool check: profiles/r06_search_kernel_isa_budget.txt); one v_sqrt_f32 (1 ulp) of the directed float and two float ulps of margin
+// bound the same quantity. Any valid bound leaves the k nearest — and every result — unchanged.
+__device__ __forceinline__ float sqrt_bound_up(double x) {
+    return __int_as_float(__float_as_int(__builtin_amdgcn_sqrtf(__double2float_ru(x))) + 2);
+}
+__device__ __forceinline__ float sqrt_bound_down(double x) {
+    return __int_as_float(max(__float_as_int(__builtin_amdgcn_sqrtf(__double2float_rd(x))) - 2, 0));
+}
 constexpr uint32_t TIE_FLAG = 0x80000000u;
 constexpr uint32_t REC_N_MASK = 63u;           // record word 0: bits 0-5 neighbours kept (n), bits 8-13 pool size (m >= n), bit 31 TIE_FLAG
 constexpr int POOL_REFILL = 4;                 // a keypoint whose pool check fails is searched up to its (k + POOL_REFILL)-th pool member
@@ -1070,7 +1080,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         if (flagged != rec_cur.hdr) o[0] = flagged;
                         kp.cnt[kp_r] = flagged;
                         kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
-                        kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
+                        kp.kth[2 * kp_r + 1] = sqrt_bound_up(need2);
                         W.todo[src] = 0;
                     }
 #pragma unroll
@@ -1574,10 +1584,10 @@ CTGN_BATCH_UNROLL
                                 // everything the selections dropped lies at or beyond the last pool member. Inside the smaller of the two
                                 // the pool is complete.
                                 const double r2 = admitted > kpool ? fmin(kth_d2, R.d2[kpool - 1]) : kth_d2;
-                                kthv = __double2float_rd(sqrt(r2) * (1.0 - 1e-12));
+                                kthv = sqrt_bound_down(r2);
                             }
                             kp.kth[2 * kp_r] = kthv;
-                            kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(sorted && n >= k ? R.d2[k - 1] : map.r2thr) * (1.0 + 1e-12));
+                            kp.kth[2 * kp_r + 1] = sqrt_bound_up(sorted && n >= k ? R.d2[k - 1] : map.r2thr);
                         }
                     }
 #pragma unroll
@@ -1779,7 +1789,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_pool_check(MapView map, KpVi
                             if (flagged != rec_cur.hdr) o[0] = flagged;
                             kp.cnt[kp_r] = flagged;
                             kp.kth[2 * kp_r] = __int_as_float(max(__float_as_int(sqrtf(rr2)) - 2, 0));          // rounded down
-                            kp.kth[2 * kp_r + 1] = __double2float_ru(sqrt(need2) * (1.0 + 1e-12));
+                            kp.kth[2 * kp_r + 1] = sqrt_bound_up(need2);
                             W.todo[src] = 0;
                         }
 #pragma unroll
