@@ -77,6 +77,7 @@ struct Tuning {
     double frame_timing = 0;        // host-clock marks of the frame pipeline on stderr
     double frame_no_direct = 0;     // always stage page-locked scan arrays
     double frame_defer_update = 1;  // ctgn_frame_update_map without an insert mask returns once the update is enqueued (0: waits for it)
+    double stop_poll = 1;           // the host watches the solve's stop flag and does not enqueue the launches behind it (0: enqueues all num_iters_icp iterations)
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
@@ -85,7 +86,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
 #define CTGN_TUNING_KEY(name) if (key == #name) return &t.name;
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
-    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update)
+    CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update) CTGN_TUNING_KEY(stop_poll)
     CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
@@ -211,6 +212,11 @@ struct ctgn_context {
     bool fail_reset_pending = true;     // a new solve began: its first split launch zeroes both counters and starts from slot 0 (a solve that
                                         // stops early leaves the slot its last EXECUTED launch counted in non-zero: the launches behind the stop
                                         // test return before they zero anything, while the host keeps toggling the slot)
+    // the host enqueues a solve's iterations ahead of the device; the solve kernel publishes "iteration i done / stopped" in host memory it can
+    // write, the host polls two iterations behind and stops enqueueing launches that would only find the stop flag set (launch_stop_poll)
+    unsigned int *h_stop = nullptr, *d_stop = nullptr;     // 64 words, page-locked + mapped
+    unsigned int stop_epoch = 0;
+    bool stop_poll_broken = false;      // a poll timed out once (the mapping is not coherent here?): the handle stops polling
     bool gn_active = false;
     std::chrono::steady_clock::time_point gn_t0;
     double init_ms = 0.0;               // host time from the call to the first launch (ICPSummary::duration_init)
@@ -955,17 +961,48 @@ ctgn_status launch_persistent(ctgn_handle h, const MapView &mv, int iters, bool 
     return mv.nb == 1 ? launch(k_gn_persistent<1>, persistent_kernel_smem<1>()) : launch(k_gn_persistent<2>, persistent_kernel_smem<2>());
 }
 
-ctgn_status launch_reduce_solve(ctgn_handle h, int mode) {
+ctgn_status launch_reduce_solve(ctgn_handle h, int mode, int stop_slot = -1) {
     // (a 4-wave block for <= 128 partial columns was measured slower on the B1 frame — 0.0425 vs 0.0404 ms per iteration: the reduce is one
     // trip to 96 freshly written lines, and four waves have a quarter of the loads in flight — and removed)
     {
         ctgn_status fs = flush_state_init(h);
         if (fs != CTGN_OK) return fs;
     }
+    unsigned int *flag = (stop_slot >= 0 && h->d_stop) ? h->d_stop + (stop_slot & 63) : nullptr;
     hipLaunchKernelGGL(k_reduce_solve<SOLVE_BLOCK>, dim3(1), dim3(SOLVE_BLOCK), 0, h->stream, h->d_partials, h->last_grid, h->d_sys, h->d_state,
-                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED, h->xr_last);
+                       h->prm, mode, CTGN_MIN_KEYPOINTS_USED, h->xr_last, flag, h->stop_epoch << 2);
     HIPCHK(h, hipGetLastError());
     return CTGN_OK;
+}
+
+// The three-launch GN loop of a solve: iterations enqueued ahead of the device, with the stop flag watched from the host. A solve that
+// converges after two of five iterations (the driving profile's threshold: ||x|| < 0.1) used to enqueue the other nine launches all the
+// same — each returns at once on the device, and each still costs a dispatch (profiles/r06_register_hip_api_trace.txt: ~30 us of a
+// 140 us Register). Before enqueueing iteration i (i >= 2) the host reads what the solve kernel of iteration i - 2 published: the device is
+// at least one whole iteration behind the host at that point, so the wait is short and the queue never runs dry.
+ctgn_status launch_gn_iterations(ctgn_handle h, const MapView &mv, int iterations) {
+    const bool poll = tuning().stop_poll != 0 && !h->stop_poll_broken && h->d_stop != nullptr && !h->profiling;
+    if (poll) {
+        h->stop_epoch = (h->stop_epoch + 1u) & 0x3fffffffu;
+        if (h->stop_epoch == 0u) h->stop_epoch = 1u;
+    }
+    ctgn_status st = CTGN_OK;
+    for (int it = 0; st == CTGN_OK && it < iterations; ++it) {                  // ct_icp.cpp:745
+        if (poll && it >= 2) {
+            const volatile unsigned int *f = h->h_stop + ((it - 2) & 63);
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned int v;
+            int spins = 0;
+            while (((v = __atomic_load_n(f, __ATOMIC_ACQUIRE)) >> 2) != h->stop_epoch) {
+                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { h->stop_poll_broken = true; break; }
+                __builtin_ia32_pause();
+            }
+            if (!h->stop_poll_broken && (v & 3u) == 2u) break;                  // stopped (converged or failed): nothing left to enqueue
+        }
+        st = launch_accumulate(h, mv, it == 0);
+        if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0, poll ? it : -1); }
+    }
+    return st;
 }
 
 void fill_params(ctgn_handle h, const ctgn_options *o, const ctgn_motion_prior *p) {
@@ -1082,6 +1119,20 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
              hipMemsetAsync(h->d_state, 0, sizeof(GnState), h->stream) == hipSuccess &&
              hipMemsetAsync(h->d_sys_own, 0, SYS_N * sizeof(double), h->stream) == hipSuccess;
         h->d_sys = h->d_sys_own;
+        // the stop words the solve kernel publishes for the host (launch_gn_iterations): mapped, coherent host memory; without it (an
+        // allocation or mapping the runtime refuses) the loop simply enqueues every iteration as before
+        if (ok) {
+            void *dp = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void **>(&h->h_stop), 64 * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                hipHostGetDevicePointer(&dp, h->h_stop, 0) == hipSuccess) {
+                std::memset(h->h_stop, 0, 64 * sizeof(unsigned int));
+                h->d_stop = static_cast<unsigned int *>(dp);
+            } else {
+                if (h->h_stop) (void) hipHostFree(h->h_stop);
+                h->h_stop = nullptr;
+                (void) hipGetLastError();
+            }
+        }
         // the kernels use up to ~37 KB of dynamic LDS (rows) / 62 KB (lane): allow it explicitly
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate_lane),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lane_kernel_smem()) == hipSuccess;
@@ -1145,6 +1196,7 @@ void ctgn_destroy(ctgn_handle h) {
         if (h->d_partials) hipFree(h->d_partials);
         if (h->d_pose_in) hipFree(h->d_pose_in);
         if (h->h_pose_in) hipHostFree(h->h_pose_in);
+        if (h->h_stop) hipHostFree(h->h_stop);
         if (h->d_counters) hipFree(h->d_counters);
         if (h->d_bar) hipFree(h->d_bar);
         if (h->d_prof) hipFree(h->d_prof);
@@ -1748,10 +1800,8 @@ ctgn_status ctgn_solve(ctgn_handle h, double pose_io[14], const double tbe[2], c
         // a small frame (the reference's own keypoint count): state init, all iterations and the final re-transform in ONE launch
         const bool merged = h->prefetch_world && h->n_kp > 0;
         st = launch_persistent(h, mv, opts->num_iters_icp, true, merged ? h->d_kp + 7 * (size_t) h->kp_stride + 16 : nullptr);
-    } else
-    for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {       // ct_icp.cpp:745
-        st = launch_accumulate(h, mv, it == 0);
-        if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
+    } else if (st == CTGN_OK) {
+        st = launch_gn_iterations(h, mv, opts->num_iters_icp);
     }
     if (st != CTGN_OK) {
         h->gn_active = false;
@@ -2576,10 +2626,8 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         if (st == CTGN_OK) st = make_map_view(h, -1.0, &mv);
         if (st == CTGN_OK && opts->num_iters_icp > 0 && persistent_ok(h, mv)) {
             st = launch_persistent(h, mv, opts->num_iters_icp, false, nullptr);        // the keypoints' world points are not an output here
-        } else
-        for (int it = 0; st == CTGN_OK && it < opts->num_iters_icp; ++it) {           // ct_icp.cpp:745
-            st = launch_accumulate(h, mv, it == 0);
-            if (st == CTGN_OK) { h->launched_iters++; st = launch_reduce_solve(h, 0); }
+        } else if (st == CTGN_OK) {
+            st = launch_gn_iterations(h, mv, opts->num_iters_icp);
         }
         if (st == CTGN_OK) st = flush_state_init(h);                                 // num_iters_icp 0: the state is still to be written
         if (st != CTGN_OK) {

@@ -2377,9 +2377,13 @@ __device__ __forceinline__ void solve_wave0(SolveScratch &S, GnState *st, const 
 // BLKS = 1024 (16 waves, three 128-block spans in flight per pass) for the thousands of partial columns of a large scan; BLKS = 256
 // (4 waves, 24 entries each, one span) when a small frame leaves at most 128 columns: a quarter of the waves to dispatch and to meet
 // at the barrier before the solve can start.
+// stop_flag (host memory the device can write, or nullptr) / stop_word: when the solve of this launch is done, lane 0 publishes
+// stop_word | (stopped ? 2 : 1) there — the host, which enqueues iterations ahead of the device, polls it two iterations behind and
+// stops enqueueing launches that would only find the stop flag set (ctgn_solve).
 template <int BLKS>
 __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, int nblocks, double *sys, GnState *st,
-                                                       GnParams prm, int mode, int min_used, XcdReduce xr) {
+                                                       GnParams prm, int mode, int min_used, XcdReduce xr, unsigned int *stop_flag = nullptr,
+                                                       unsigned int stop_word = 0u) {
     __shared__ SolveScratch S;
     __shared__ double s_tmp[(BLKS / SYS_N) * SYS_N];
     if (st->done) return;
@@ -2416,6 +2420,8 @@ __global__ __launch_bounds__(BLKS) void k_reduce_solve(const double *partials, i
     __syncthreads();
     if (mode == 1 || wave != 0) return;
     solve_wave0(S, st, prm, min_used, lane, tc0, wall0);
+    if (stop_flag != nullptr && lane == 0)
+        __hip_atomic_store(stop_flag, stop_word | (st->done ? 2u : 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #undef WSYNC

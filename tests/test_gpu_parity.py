@@ -931,6 +931,40 @@ def test_sequence_of_frames_end_to_end(street_case):
     assert np.array_equal(_sorted_rows(gm.MapAsPointCloud(0)), _sorted_rows(om.export(0)))
 
 
+def test_stop_poll_changes_nothing_but_the_launches(street_case):
+    """The host watches the solve's stop flag (k_reduce_solve publishes it in mapped host memory) and does not enqueue the iterations behind
+    it: a registration that converges early returns the same poses, world points and summary — bit for bit — whether the host polls
+    (tuning stop_poll=1, the default) or enqueues all num_iters_icp iterations (0); one that never converges runs its full budget either way."""
+    from ct_icp_amd import _lib as L
+    case = street_case
+    gm = cia.GpuVoxelMap(cia.GpuVoxelMapOptions(resolutions=[cia.ResolutionParam(*r) for r in case["resolutions"]],
+                                                default_radius=case["default_radius"]))
+    for j in range(7):
+        gm.InsertPointCloud(case["scans"][j].world_gt)
+    sc = case["scans"][7]
+    sel = syn.grid_sample_indices(sc.raw, 0.5)
+    pose0 = syn.perturb_pose(sc.pose_gt, 0.003, 0.03, seed=8)
+    world0 = se3.ct_transform(pose0, sc.t_begin_end, sc.t[sel], sc.raw[sel])
+    results = {}
+    try:
+        for poll in (1, 0, 1):
+            L.lib().ctgn_set_tuning(b"stop_poll", float(poll))
+            for thr, iters in ((0.1, 12), (0.0, 6)):
+                kps = np.zeros(len(sel), dtype=cia.WPOINT3D_DTYPE)
+                kps["raw_point"], kps["t"], kps["world_point"] = sc.raw[sel], sc.t[sel], world0
+                frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+                summ = cia.CT_ICP_Registration(_opts(num_iters_icp=iters, threshold_orientation_norm=thr)).Register(gm, kps, frame)
+                got = (frame.pose14().copy(), kps["world_point"].copy(), summ.num_iters, summ.num_residuals_used, summ.success)
+                if (thr, iters) in results:
+                    want = results[(thr, iters)]
+                    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]) and want[2:] == got[2:], (poll, thr)
+                results[(thr, iters)] = got
+    finally:
+        L.lib().ctgn_set_tuning(b"stop_poll", 1.0)
+    assert results[(0.1, 12)][2] < 12 and results[(0.1, 12)][4]          # converged early ...
+    assert results[(0.0, 6)][2] == 6                                       # ... and a threshold of zero never stops
+
+
 def test_device_shuffle_is_a_keyed_permutation_and_equals_that_order_passed_by_the_caller(street_case):
     """ctgn_frame_options::shuffle_seed: the processing order made on the device is a permutation of 0..n-1 (every index once), depends on
     the seed and nothing else, looks like a shuffle (no correlation with the scan order, displacements spread like a uniform permutation's),
