@@ -556,6 +556,17 @@ def measure_workload(W, args, cia, torch, dist, sharded, steps, warmup, clock_wa
     if "upload_h2d_bytes" in W:
         out["sharded_upload"] = {"h2d_bytes_this_rank": int(W["upload_h2d_bytes"]), "h2d_bytes_whole_scan_7_arrays": 56 * int(total_kp),
                                  "note": "per rank: 24 B x scan (world points: the home-voxel order every rank must agree on) + 56 B x chunk"}
+    if R.sh is not None and not args.torch_collective:
+        # what a sharded iteration costs before it does any work, so that a scaling record explains itself: the bare 768-byte all-reduce and
+        # the chain of the iteration's five launches with nothing to do (collective: every rank measures)
+        try:
+            ar_us, chain_us = R.solver.dist_overheads(1000)
+            out["sharded_overheads"] = {"allreduce_us": ar_us, "five_launch_overhead_us": chain_us, "iteration_us": dt / steps * 1e6,
+                                        "what": "allreduce_us = one ncclAllReduce(sum, 96 f64) on the handle's stream, mean of 1000 back to back; "
+                                                "five_launch_overhead_us = one sharded iteration (search, residual, reduce, all-reduce, solve) whose "
+                                                "kernels return at once; iteration_us = the timed iteration of this line"}
+        except Exception as e:        # noqa: BLE001 — a measurement nicety: never fail the bench over it
+            out["sharded_overheads"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # ---- steady state: ONE running loop (round 2's headline): every search after the first is bounded, the pose has converged
     steady = None
     if want_steady and not args.inner:
@@ -872,7 +883,7 @@ def main():
             "frames_per_sec_equiv": res["frames_per_sec_equiv"],
             "roofline": res["roofline"],
         }
-        for k in ("parity_m_rad", "parity", "sharded_upload"):
+        for k in ("parity_m_rad", "parity", "sharded_upload", "sharded_overheads"):
             if k in res:
                 result[k] = res[k]
         inp = W["inp"]
@@ -1076,6 +1087,8 @@ def compact_line(result) -> str:
     for k in ("parity_m_rad", "gpu_over_cpu", "first_iteration_ms", "later_iteration_ms", "strong_scaling_efficiency"):
         if k in result:
             line[k] = result[k]
+    if isinstance(result.get("sharded_overheads"), dict):
+        line["sharded_overheads"] = _pick(result["sharded_overheads"], "allreduce_us", "five_launch_overhead_us", "iteration_us", "error")
     if isinstance(result.get("frames_per_sec"), dict):
         line["frames_per_sec"] = _pick(result["frames_per_sec"], "value", "ms_per_frame", "keypoints")
     if isinstance(result.get("robust_route"), dict):

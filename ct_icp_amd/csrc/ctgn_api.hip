@@ -59,8 +59,16 @@ static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState i
 // The A/B switches of the measurement sessions in ONE place (round 5: they used to be 18 getenv calls scattered over this file). Process-wide,
 // like the function-local statics they replace; set through ctgn_set_tuning (ctgn_internal.h) or, for a session script that cannot call into
 // the library, ONE environment variable read once: CTGN_TUNING="key=value,key=value". Defaults = what the A/B sessions adopted. None of them
-// changes a result; the switches whose A/B is closed (hipGraph capture of the loop, 512-thread residual blocks, the 4-wave solve block, the
-// unfused frame call) are gone together with their code paths.
+// changes WHICH neighbours a keypoint gets, which keypoints pass the gates, or any per-keypoint quantity; four of them select another
+// (still fixed) ORDER in which the packed sums are added and therefore move a pose in its last bits (1e-12 relative on the system):
+// order (position order instead of index order), xcd_reduce (per-XCD group sums), fuse_small (per-wave sums of the fused small-frame kernel),
+// robust_fuse (the robust route's one-block evaluation — which ctgn_solve_robust also switches by size at 1 024 keypoints). With xcd_reduce
+// the fall-back to the per-block sums depends on where the dispatcher placed the workgroups, so two runs of one process agree bit for bit
+// only as long as the placement does (tests/test_gpu_parity.py::test_per_xcd_presums_change_nothing_but_the_summation_order pins the
+// two sums to 1e-12 of each other). The switches whose A/B is closed (hipGraph capture of the loop, 512-thread residual blocks, the
+// 4-wave solve block, the unfused frame call) are gone together with their code paths.
+// Not synchronised: ctgn_set_tuning is for a measurement script or a test that owns the process, between calls — not for threads that
+// are solving meanwhile. host_threads is latched by the first scan-sized frame call (the pool is sized then): setting it later is refused.
 struct Tuning {
     double host_threads = 3;        // helper threads of the host-side staging loops (0 = none)
     double order = -1;              // home-voxel ordering when ctgn_set_ordering left it automatic: -1 = cost model, 0 / 1 = never / always
@@ -118,8 +126,10 @@ static Tuning &tuning() {
 }
 
 // how many helpers: tuning().host_threads (0 = none, default 3); never more than the CPUs this process may run on minus the caller's
+static bool g_host_threads_latched = false;
 static int host_helpers_wanted() {
     static const int n = [] {
+        g_host_threads_latched = true;
         int want = (int) tuning().host_threads;
         cpu_set_t set;
         int cpus = 1;
@@ -1956,6 +1966,50 @@ ctgn_status ctgn_set_keypoints_sharded(ctgn_handle h, ctgn_view raw, ctgn_view w
 // A rank that cannot go on (its gn_begin failed: a timestamp of ITS shard outside the frame; a launch or a map view failed mid-loop) while
 // its peers, whose shards are fine, wait in the all-reduce: it still takes part in every remaining exchange, with a poisoned count — every
 // rank's solve kernel sees the negative sum, stops before the pose changes and reports GN_FAILED_PEER. All ranks fail together.
+ctgn_status ctgn_dist_overheads(ctgn_handle h, int32_t reps, double out_us[2]) {
+    NEED_DEVICE(h);
+    if (!out_us || reps < 1) return CTGN_ERR_INVALID_ARGUMENT;
+    if (!h->comm) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "ctgn_dist_init was not called");
+    out_us[0] = out_us[1] = 0.0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double *scratch = h->d_partials;                   // any 96 doubles nobody reads between solves
+    for (int pass = 0; pass < 2; ++pass) {             // pass 0 warms the communicator's channels up
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) {
+            const ncclResult_t r = rccl_api().AllReduce(scratch, scratch, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream);
+            if (r != ncclSuccess) return fail(h, CTGN_ERR_HIP, std::string("[RCCL] ncclAllReduce: ") + rccl_api().GetErrorString(r));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        out_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    // the chain of a sharded iteration with the stop flag set: every kernel returns at once, the all-reduce runs
+    int one = 1, zero = 0;
+    int *d_done = reinterpret_cast<int *>(reinterpret_cast<char *>(h->d_state) + offsetof(GnState, done));
+    HIPCHK(h, hipMemcpyAsync(d_done, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->n_kp > 0) {
+        MapView mv;
+        ctgn_status st = make_map_view(h, -1.0, &mv);
+        if (st != CTGN_OK) return st;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps && st == CTGN_OK; ++i) {
+            h->init_pending = false;
+            st = launch_accumulate(h, mv, false);
+            if (st == CTGN_OK) st = launch_reduce_solve(h, 1);
+            if (st == CTGN_OK && rccl_api().AllReduce(h->d_sys, h->d_sys, CTGN_SYSTEM_DOUBLES, ncclDouble, ncclSum, h->comm, h->stream) != ncclSuccess)
+                st = fail(h, CTGN_ERR_HIP, "[RCCL] ncclAllReduce");
+            if (st == CTGN_OK) st = launch_reduce_solve(h, 2);
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (st != CTGN_OK) return st;
+        out_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    HIPCHK(h, hipMemcpyAsync(d_done, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->kth_fresh = false;
+    return CTGN_OK;
+}
+
 static void join_remaining_exchanges_poisoned(ctgn_handle h, int remaining) {
     if (remaining <= 0 || !h->d_sys || !h->comm) return;
     double poison[CTGN_SYSTEM_DOUBLES] = {0.0};
@@ -3467,6 +3521,7 @@ ctgn_status ctgn_set_tuning(const char *key, double value) {
     if (!key) return CTGN_ERR_INVALID_ARGUMENT;
     double *slot = tuning_slot(tuning(), key);
     if (!slot) return CTGN_ERR_INVALID_ARGUMENT;
+    if (slot == &tuning().host_threads && g_host_threads_latched && *slot != value) return CTGN_ERR_UNSUPPORTED;     // the pool has been sized
     *slot = value;
     return CTGN_OK;
 }

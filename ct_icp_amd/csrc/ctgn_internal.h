@@ -71,9 +71,12 @@ ctgn_status ctgn_set_variant(ctgn_handle h, int32_t variant);
 ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double out_gbs[3]);
 
 /* The A/B switches of the measurement sessions, one table (ctgn_api.hip, struct Tuning: host_threads, order, pool_min, res_small, res_grid_cap,
- * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct, tile_chunk,
- * xcd_reduce, robust_fuse). Process-wide; none of
- * them changes a result. A session script that cannot call into the library sets CTGN_TUNING="key=value,key=value" instead (read once). */
+ * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct, frame_defer_update,
+ * stop_poll, tile_chunk, xcd_reduce, robust_fuse). Process-wide and NOT synchronised: for a script or a test that owns the process, between
+ * calls. None of them changes a neighbour set, a gate decision or a per-keypoint quantity; order, xcd_reduce, fuse_small and robust_fuse
+ * select another fixed order of the packed sums (poses move in their last bits; see the table's comment). CTGN_ERR_UNSUPPORTED: host_threads
+ * after the helper pool was sized by the first scan-sized frame call. A session script that cannot call into the library sets
+ * CTGN_TUNING="key=value,key=value" instead (read once). */
 ctgn_status ctgn_set_tuning(const char *key, double value);
 
 /* Has the size-dependent reduction path run (tests assert that the path they mean to cover did)? out[0] = residual launches of this handle
@@ -92,6 +95,12 @@ ctgn_status ctgn_last_upload_bytes(ctgn_handle h, uint64_t *bytes);
 ctgn_status ctgn_test_sort_pairs(ctgn_handle h, const uint64_t *keys, size_t n, int32_t key_bits, int32_t key_bytes, uint32_t *order_out);
 ctgn_status ctgn_test_compact(ctgn_handle h, const uint8_t *flags, size_t n, uint32_t *out_indices, size_t *out_count);
 
+/* What a sharded iteration costs before it does any work (round 6; bench.py puts both into the N > 1 line so that a scaling record explains
+ * itself): out_us[0] = one ncclAllReduce(sum) of the 96-double packed system on the handle's stream, mean of `reps` back-to-back calls
+ * (the collective of ctgn_solve_sharded, bare); out_us[1] = one iteration of that loop when its four kernels have nothing to do and return
+ * at once (search, residual, reduce, all-reduce, solve: the launch and dependency overhead of the chain, all-reduce included). Collective:
+ * every rank of the communicator must call it. Needs ctgn_dist_init. */
+ctgn_status ctgn_dist_overheads(ctgn_handle h, int32_t reps, double out_us[2]);
 #ifdef __cplusplus
 }
 #endif

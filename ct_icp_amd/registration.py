@@ -481,6 +481,13 @@ class GnSolver:
     def dist_shutdown(self):
         L.check(self._h, L.lib().ctgn_dist_shutdown(self._h))
 
+    def dist_overheads(self, reps: int = 1000):
+        """(microseconds of one bare ncclAllReduce of the packed system, microseconds of one sharded iteration whose kernels have nothing to
+        do) — ctgn_dist_overheads (ctgn_internal.h); collective."""
+        out = (C.c_double * 2)()
+        L.check(self._h, L.lib().ctgn_dist_overheads(self._h, int(reps), out))
+        return float(out[0]), float(out[1])
+
     def solve_sharded(self, pose14, t_begin_end, options: CTICPOptions, motion_model=None):
         """The sharded GN loop on this rank's resident keypoints; one ncclAllReduce of the packed system per iteration, issued in C."""
         pose = np.ascontiguousarray(pose14, dtype=np.float64).copy()

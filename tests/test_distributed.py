@@ -1,4 +1,4 @@
-"""world_size-2 tests of the keypoint-sharded mode's exchange step on CPU (gloo backend).
+"""world_size 2 / 4 / 8 tests of the keypoint-sharded mode's exchange step on CPU (gloo backend).
 
 On GPUs each rank runs libctgn's accumulate kernel on its shard and the packed system (96 doubles) is all-reduced over
 RCCL (ct_icp_amd/distributed.py). Here the per-shard systems come from the CPU oracle (the checker), so the test pins the
@@ -80,13 +80,18 @@ def test_pack_unpack_roundtrip():
 
 
 @pytest.mark.timeout(300)
-def test_allreduce_of_packed_system_world_size_2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_allreduce_of_packed_system(tmp_path, world):
+    """World sizes 2, 4 and 8 — the ones the driver's scaling run uses: the shards cover the scan, their packed systems sum to the whole
+    scan's, every rank derives the same pose from the reduced system."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    res = [np.load(tmp_path / f"ok_{r}.npy") for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"ok_{r}.npy") for r in range(world)]
     assert all(r[0] == 1 and r[1] == 1 for r in res), res
-    assert res[0][3] == res[1][3] > 100
+    assert len({int(r[3]) for r in res}) == 1 and res[0][3] > 100
+    sizes = [int(r[2]) for r in res]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) > 1000
 
 
 # ------------------------------------------------------------------------------------------------- config E: sequences per rank

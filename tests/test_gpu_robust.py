@@ -136,6 +136,33 @@ def test_register_robust_matches_oracle(case_name, voxel, loss, prior, request):
         assert tr_gt < 0.5 * tr0 and tr_gt < 0.02, (tr_gt, tr0)
 
 
+def test_fused_evaluation_and_step_changes_the_summation_order_only(box_case, street_case):
+    """tuning robust_fuse: the inner solver's evaluation + step as ONE launch of one block (k_robust_eval_step; the default up to 1 024
+    keypoints) against the two-kernel form (k_robust_eval over many blocks + k_robust_step). Same residual blocks, same weights, same
+    accepted steps and iteration counts; the normal equations are summed in another fixed order, so the poses agree to rounding, not bit
+    for bit — on a frame below the size switch and on one above it."""
+    from ct_icp_amd import _lib as L
+    try:
+        for case, voxel in ((box_case, 0.5), (street_case, 0.45)):
+            om, gm, sc, raw, t, pose0 = _setup(case, 5, voxel)
+            o = _opts(num_iters_icp=6, ls_max_num_iters=4, loss_function="CAUCHY", threshold_orientation_norm=1e-5, threshold_translation_norm=1e-6)
+            got = []
+            for fuse in (0, 1):
+                L.lib().ctgn_set_tuning(b"robust_fuse", float(fuse))
+                kp = np.zeros(len(t), dtype=cia.WPOINT3D_DTYPE)
+                kp["raw_point"], kp["t"] = raw, t
+                frame = cia.TrajectoryFrame.from_pose14(pose0, *sc.t_begin_end)
+                summ = cia.CT_ICP_Registration(o).Register(gm, kp, frame, None)
+                got.append((frame.pose14().copy(), kp["world_point"].copy(), summ))
+            (pa, wa, sa), (pb, wb, sb) = got
+            assert sa.success and sb.success and sa.num_iters == sb.num_iters and sa.num_residuals_used == sb.num_residuals_used, (len(t), sa, sb)
+            tr, rot = se3.pose_error(pa, pb)
+            assert tr < 1e-9 and rot < 1e-9, (len(t), tr, rot)
+            assert np.abs(wa - wb).max() < 1e-8
+    finally:
+        L.lib().ctgn_set_tuning(b"robust_fuse", -1.0)
+
+
 def test_residual_cap_and_several_closest_neighbors(box_case):
     case = box_case
     om, gm, sc, raw, t, pose0 = _setup(case, 5, 0.4)
