@@ -558,13 +558,12 @@ __device__ __forceinline__ double axis_gap(double q, int vox, double res) {
 // keypoint has no search or when the whole voxel lies farther from the query than r2bound — the radius, or the tighter
 // bound on the k-th neighbour's distance carried over from the previous search (exact: no point of such a voxel can be
 // among the k nearest within the radius, map.h:491-493; a 1e-8 relative slack covers the rounding of the voxel boundaries).
-// v_given >= 0: the lane's sweep voxel is given (255 = none) instead of the it-th batch's entry of the nearest-first order (compact batches)
 template <int NB>
 __device__ __forceinline__ bool batch_reach(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
                                             double qx, double qy, double qz, int &v_out, int &vx, int &vy, int &vz, int ablate, double r2bound,
-                                            uint32_t mreach, int v_given = -1) {
+                                            uint32_t mreach) {
     constexpr int S = 2 * NB + 1;
-    const int v = v_given >= 0 ? v_given : ((NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub]);
+    const int v = (NB == 1) ? (int) c_sweep1.v[it * 16 + sub] : (int) c_sweep2.v[it * 16 + sub];
     v_out = v;
     const int vv = (v == 255) ? 0 : v;
     const int ox = vv / (S * S) - NB, oy = (vv / S) % S - NB, oz = vv % S - NB;
@@ -581,28 +580,10 @@ __device__ __forceinline__ bool batch_reach(const MapView &m, int it, int sub, b
 }
 template <int NB>
 __device__ __forceinline__ Probe issue_batch(const MapView &m, int it, int sub, bool searching, int kx, int ky, int kz,
-                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound, uint32_t mreach, int v_given = -1) {
+                                             double qx, double qy, double qz, int &v_out, int ablate, double r2bound, uint32_t mreach) {
     int vx, vy, vz;
-    const bool reachable = batch_reach<NB>(m, it, sub, searching, kx, ky, kz, qx, qy, qz, v_out, vx, vy, vz, ablate, r2bound, mreach, v_given);
+    const bool reachable = batch_reach<NB>(m, it, sub, searching, kx, ky, kz, qx, qy, qz, v_out, vx, vy, vz, ablate, r2bound, mreach);
     return probe_issue(m, reachable && !(ablate & 16), vx, vy, vz);
-}
-
-// 27-voxel sweep, compact probe batch (round 6). The sweep is probed in two batches of 16 lanes — the voxels nearest first — and each batch
-// costs its reach tests, its hash arithmetic and its chunk-list pass whether the row's bound admits one voxel or all of them
-// (profiles/r06_search_kernel_isa_budget.txt: 51 + 23 wave-instructions per keypoint on a bounded search that probes 2.6 voxels). The row's
-// slab mask (W.mr: per axis, which offsets -1 .. +1 reach inside the bound) names the candidates: the product of the three 3-bit sets is
-// a 27-bit mask; when no searching row of the round has more than 16 bits set, lane i of the row takes the i-th set bit and the round runs ONE
-// batch. The visit index of a candidate is its sweep voxel's own (x-major) index either way, so lists and ties are what they were.
-// Returns the lane's voxel (255: none); n_row = the row's number of candidates.
-__device__ __forceinline__ int compact_sweep_voxel(uint32_t mr, bool searching, int sub, uint8_t *pos, int &n_row) {
-    const uint32_t mx = (mr >> 1) & 7u, my = (mr >> 6) & 7u, mz = (mr >> 11) & 7u;           // offsets -1 .. +1 of x | y | z
-    const uint32_t plane = ((my & 1u) ? mz : 0u) | ((my & 2u) ? mz << 3 : 0u) | ((my & 4u) ? mz << 6 : 0u);
-    const uint32_t m27 = searching ? (((mx & 1u) ? plane : 0u) | ((mx & 2u) ? plane << 9 : 0u) | ((mx & 4u) ? plane << 18 : 0u)) : 0u;   // bit v = 9 ox + 3 oy + oz
-    n_row = __popc(m27);
-    const int b0 = sub, b1 = sub + 16;
-    if ((m27 >> b0) & 1u) { const int rk = __popc(m27 & ((1u << b0) - 1u)); if (rk < 16) pos[rk] = (uint8_t) b0; }
-    if (b1 < 27 && ((m27 >> b1) & 1u)) { const int rk = __popc(m27 & ((1u << b1) - 1u)); if (rk < 16) pos[rk] = (uint8_t) b1; }
-    return sub < min(n_row, 16) ? (int) pos[sub] : 255;
 }
 
 // the 16 ballot bits of DPP row `row`
@@ -1391,19 +1372,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     }
                 }
             }
-            // 27-voxel sweep: ONE compact batch when no searching row of the round has more than 16 candidate voxels (compact_sweep_voxel);
-            // bit 30 of the ablation mask: always the two nearest-first batches (A/B)
-            bool one_batch = false;
-            int v_compact = -1;
-            if constexpr (NB == 1) {
-                if (!(ablate & (1 << 30))) {
-                    int n_row;
-                    const int vc = compact_sweep_voxel(mreach, searching, sub, reinterpret_cast<uint8_t *>(R.hist), n_row);
-                    one_batch = !any64(n_row > 16);
-                    if (one_batch) v_compact = vc;
-                }
-            }
-            if (!shared2 && nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach, v_compact);
+            if (!shared2 && nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
             //   streams the chunks (a voxel's x | y | z runs are contiguous, so a chunk is three 128-byte reads), with the
@@ -1418,10 +1387,9 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             if constexpr (NB == 2) {
                 if (!(ablate & (1 << 26)) && !any64(searching && (mreach & 0x4631u) != 0u)) vit_run = 2;
             }
-            if (NB == 1 && one_batch) vit_run = 1;
 CTGN_BATCH_UNROLL
             for (int it = 0; it < VIT; ++it) {
-                if (it >= vit_run) continue;                 // (not `break`: the loop stays unrolled)
+                if (NB == 2 && it >= vit_run) continue;      // (not `break`: the loop stays unrolled)
                 // the probe batch issued one step earlier is consumed now; the next batch (same keypoint, or the first
                 // batch of the next round's keypoint) is issued before the chunk streaming so its latency is covered
                 Probe cur = nxt;
@@ -1443,16 +1411,8 @@ CTGN_BATCH_UNROLL
                     const int slot2 = slot_of(r + 1, row);
                     const int src2 = slot2 == 255 ? row * 16 : slot2;
                     const int kx2 = slot2 == 255 ? INT_MIN : W.kx[src2];
-                    int v2 = -1;
-                    if constexpr (NB == 1) {               // the next round's own decision, made here as it will be made there (same inputs)
-                        if (!(ablate & (1 << 30))) {
-                            int n_row2;
-                            const int vc2 = compact_sweep_voxel((uint32_t) W.mr[src2], kx2 != INT_MIN, sub, reinterpret_cast<uint8_t *>(R.hist), n_row2);
-                            if (!any64(n_row2 > 16)) v2 = vc2;
-                        }
-                    }
                     nxt = issue_batch<NB>(map, 0, sub, kx2 != INT_MIN, kx2, W.ky[src2], W.kz[src2], W.px[src2], W.py[src2], W.pz[src2], nxt_v, ablate,
-                                          fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2], v2);
+                                          fmin(map.r2thr, (double) W.kb[src2]), (uint32_t) W.mr[src2]);
                     nxt_round = r + 1;
                 }
                 if (PROF && !shared2) pc[10] += (unsigned long long) __popcll(ballot64(cur.active));
