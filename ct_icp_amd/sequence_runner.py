@@ -55,13 +55,17 @@ def constant_velocity_guess(prev_pose14: np.ndarray, prev_prev_pose14: np.ndarra
 def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sample_voxel_size: float = 1.5,
                  max_distance: float = 100.0, init_poses=None, init_frames: int = 1, options: CTICPOptions = None,
                  use_motion_model: bool = None, resolutions=((0.8, 0.1, 30),), default_radius: float = 0.75, frame_period: float = 0.1,
-                 orders=None, init_num_frames: int = 20, init_voxel_size: float = 0.2, init_sample_voxel_size: float = 1.0, init_num_iters: int = 15):
+                 orders=None, init_num_frames: int = 20, init_voxel_size: float = 0.2, init_sample_voxel_size: float = 1.0, init_num_iters: int = 15,
+                 shuffle_seed: int = 5489):
     """scans: iterable of (raw (N, 3), t (N,), (t_begin, t_end)). The first `init_frames` frames enter the map with `init_poses[j]`
     (ground truth / identity) and no registration; every later frame is registered from the constant-velocity guess and inserted if
     the registration succeeded. Without `init_poses` the sequence starts from the identity like the reference's Odometry, and the first
     `init_num_frames` frames run its start-up regime (odometry.cpp:340-342, 533-534, 552-556: a 0.2 m frame grid and a 1.0 m keypoint grid
     instead of 0.5 / 1.5 m, at least 15 ICP iterations) — one frame sampled at 0.5 m leaves 2-4 points per 0.8 m map voxel, too few for any
-    20-point neighbourhood. Returns dict(poses (F, 14), success (F,), seconds, frames, keypoints, sampled, map_points)."""
+    20-point neighbourhood. The reference shuffles every scan before it samples it (odometry.cpp:349: WHICH point of a voxel survives is a
+    random choice, not the first in firing order); here the shuffle is made on the device (ctgn_frame_options::shuffle_seed, a keyed
+    permutation per frame: `shuffle_seed` + the frame number; 0 = scan order, as rounds 2-5 ran) unless the caller passes `orders`.
+    Returns dict(poses (F, 14), success (F,), seconds, frames, keypoints, sampled, map_points)."""
     gm = GpuVoxelMap(GpuVoxelMapOptions(resolutions=[ResolutionParam(*r) for r in resolutions], default_radius=default_radius,
                                         device=device, device_updates=True))
     fp = FramePipeline(gm, frame_voxel_size=voxel_size, sample_voxel_size=sample_voxel_size)
@@ -83,6 +87,7 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
     startup_options.num_iters_icp = max(options.num_iters_icp, init_num_iters)
     for j, (raw, t, tbe) in enumerate(scans):
         order = None if orders is None else orders[j]
+        seed = 0 if (order is not None or not shuffle_seed) else (int(shuffle_seed) * 0x9E3779B97F4A7C15 + j + 1) & 0xFFFFFFFFFFFFFFFF
         startup = init_poses is None and j < init_num_frames
         fp.frame_voxel_size = init_voxel_size if startup else voxel_size
         fp.sample_voxel_size = init_sample_voxel_size if startup else sample_voxel_size
@@ -92,7 +97,7 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
         override = float(tbe[1]) if (j <= 1 and init_poses is None) else None
         if j < init_frames:
             pose0 = np.asarray(init_poses[j], dtype=np.float64) if init_poses is not None else se3.identity_pose14()
-            r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, override_timestamp=override, want_all=False)
+            r = fp.frame(raw, t, pose0, tbe, no_registration, max_distance, order=order, override_timestamp=override, want_all=False, shuffle_seed=seed)
         else:
             # odometry.cpp:293-300: the frame right after the bootstrap starts at the previous end pose; later ones extrapolate both ends
             # (frame index 2 uses T_end(0), :296-300; a frame right after a ground-truth bootstrap keeps starting at the previous end pose)
@@ -100,7 +105,7 @@ def run_sequence(scans, device: int = 0, solver=GN, voxel_size: float = 0.5, sam
             guess = constant_velocity_guess(prev, prev2 if use_prev2 else None, third_frame=(j == 2))
             mm.previous_frame = TrajectoryFrame.from_pose14(prev, tbe[0] - frame_period, tbe[0])
             r = fp.frame(raw, t, guess, tbe, startup_options if startup else options, max_distance, motion_model=mm if use_motion_model else None, order=order,
-                         override_timestamp=override, want_all=False)
+                         override_timestamp=override, want_all=False, shuffle_seed=seed)
         poses.append(r["pose"])
         success.append(bool(r["summary"].success))
         n_kp.append(len(r["keypoint_indices"]))

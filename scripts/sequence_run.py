@@ -316,6 +316,8 @@ def run_config_e(scale: int = 10, azimuth_steps: int = None, device: int = 0, in
                     err_tr_max=max(r["err_tr_max"] for r in rs), lengths=lengths, scale=f"KITTI lengths / {scale}", solver=route,
                     bootstrap=f"the first {init_frames} frames of a sequence enter the map with their ground-truth poses",
                     scan_arrays="page-locked host memory, read in place" if page_locked else "pageable host memory, staged",
+                    processing_order="every scan shuffled on the device before it is sampled (ctgn_frame_options::shuffle_seed; the reference shuffles "
+                                     "with its std::mt19937_64, odometry.cpp:349); rounds 2-5 sampled in firing order",
                     per_sequence=rs)
     out = block(routes[0])
     out["scan_generation_seconds"] = t_gen
