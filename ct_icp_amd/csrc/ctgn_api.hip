@@ -287,11 +287,11 @@ struct ctgn_context {
         bool direct_in = false;         // ... read in place from page-locked caller arrays (h_scan holds no records then)
         double tmin = 0, tmax = 0;      // timestamp range of the staged scan
         double frame_voxel = 0, kp_voxel = 0;   // voxel sizes the two samplers last ran with (d_sel1 / d_sel2 belong to them)
-        std::vector<uint32_t> order;    // the caller's processing order (empty: scan order)
         // device-side shuffle (ctgn_frame_options::shuffle_seed)
         double *d_scan_in = nullptr;    // n records in scan order, as uploaded; k_frame_permute writes d_scan from them
         uint32_t *d_order = nullptr;    // order[j] = scan index of the point at processing position j
-        uint32_t *h_order = nullptr;    // pinned copy (valid after the frame's first synchronisation)
+        uint32_t *h_order = nullptr;    // pinned staging of a caller's order on its way to the device
+        uint32_t *d_selx = nullptr;     // [2][cap] the sampled / keypoint positions translated to the caller's point numbers (k_frame_translate)
         bool device_shuffled = false;
         bool permuted = false;          // d_scan holds the records in another order than the caller's: d_order[j] = caller index of position j
         bool prestaged = false;         // ctgn_frame_stage uploaded a scan (scan order, d_scan_in) that ctgn_frame_begin has yet to take
@@ -1177,6 +1177,7 @@ static void frame_scratch_free(ctgn_handle h) {
     if (F.d_scan_in) hipFree(F.d_scan_in);
     if (F.d_order) hipFree(F.d_order);
     if (F.h_order) hipHostFree(F.h_order);
+    if (F.d_selx) hipFree(F.d_selx);
     F = ctgn_context::FrameScratch{};
 }
 
@@ -2385,8 +2386,7 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     if (phase == 2) {
         if (!F.prestaged || n != F.n) return fail(h, CTGN_ERR_INVALID_ARGUMENT, "no scan of this size was staged (ctgn_frame_stage)");
         F.prestaged = false;
-        F.order.clear();
-        const bool dev_shuffle = n > 1 && !order && fo->shuffle_seed != 0;
+            const bool dev_shuffle = n > 1 && !order && fo->shuffle_seed != 0;
         F.device_shuffled = dev_shuffle;
         if (n && !(tbe[0] <= F.tmin && F.tmax <= tbe[1])) {
             hipStreamSynchronize(h->stream);
@@ -2411,7 +2411,6 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
                            order ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr, F.d_order, (int) n, half_bits,
                            (unsigned long long) fo->shuffle_seed, reinterpret_cast<unsigned int *>(h->dm.idx), F.d_counts + 2);
         HIPCHK(h, hipGetLastError());
-        if (dev_shuffle) HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         F.permuted = true;
         return CTGN_OK;
     }
@@ -2427,7 +2426,6 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
     const size_t c = std::min((n + 63) & ~(size_t) 63, F.cap);                      // plane stride of the undistorted outputs
     F.valid = false;
     F.staged = false;
-    F.order.clear();
     F.stride = c; F.n = n; F.n1 = 0; F.n2 = 0;
     // a processing order — the caller's `order`, or the shuffle made on the device (ctgn_frame_options::shuffle_seed) — is applied ON THE
     // DEVICE: the scan travels in scan order (staged by sequential reads; gathering 132 k records through a shuffled index on the host
@@ -2439,6 +2437,7 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_scan_in), 4 * F.cap * sizeof(double)));
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_order), F.cap * sizeof(uint32_t)));
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&F.h_order), F.cap * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&F.d_selx), 2 * F.cap * sizeof(uint32_t)));
     }
     double *d_recs_up = permute ? F.d_scan_in : F.d_scan + 16;                       // where the uploaded records go
     for (int k = 0; k < 14; ++k) F.h_scan[k] = pose_io[k];
@@ -2557,7 +2556,6 @@ static ctgn_status frame_stage(ctgn_handle h, ctgn_view raw, ctgn_view ts, size_
                            order ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr, F.d_order, (int) n, half_bits,
                            (unsigned long long) fo->shuffle_seed, reinterpret_cast<unsigned int *>(h->dm.idx), F.d_counts + 2);
         HIPCHK(h, hipGetLastError());
-        if (dev_shuffle) HIPCHK(h, hipMemcpyAsync(F.h_order, F.d_order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));   // on the host by the first sync
     }
     F.permuted = permute;
     if (has_nan) tmax = NAN;
@@ -2610,7 +2608,6 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
         ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose_io, tbe);
         if (ss != CTGN_OK) return ss;
     }
-    if (F.device_shuffled) order = F.h_order;          // (read after the counts' synchronisation only)
     const size_t c = F.stride;                                                      // plane stride of the undistorted outputs
     const double *hs = F.h_scan + 16;
     const double *d_recs = F.d_scan + 16;
@@ -2646,7 +2643,7 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     }
     h->t_min = tmin; h->t_max = tmax;
     h->kp_coherent = false;
-    if (n2 >= 32768 && !F.device_shuffled) {
+    if (n2 >= 32768 && !F.permuted) {                   // (under a processing order the staged records are in scan order: a shuffle is incoherent)
         // spatial coherence of the keypoint order (see ctgn_set_keypoints), probed on the staged raw points — a rigid motion keeps
         // neighbours neighbours: pairs one keypoint spacing apart in processing order
         int map_id, nb;
@@ -2705,6 +2702,14 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     const bool all_rows = want_all && out->all_world_dtype == CTGN_F64 && out->all_world_stride_bytes == 3 * sizeof(double);
     if (want_all) hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n)), dim3(256), 0, h->stream, d_recs, F.d_world, (int) n, (size_t) 1, d_pose,
                                      tbe[0], tbe[1], (const uint32_t *) nullptr, c, (size_t) 4, 1, F.permuted ? (const uint32_t *) F.d_order : (const uint32_t *) nullptr);
+    // the indices this call reports are the caller's point numbers: under a processing order the positions are translated on the device
+    // (the host never needs the order — a device-made shuffle never leaves the device)
+    const uint32_t *d_idx1 = F.d_sel1, *d_idx2 = F.d_sel2;
+    if (F.permuted) {
+        if (out && out->sampled_indices && n1) { hipLaunchKernelGGL(k_frame_translate, dim3(grid_for(n1)), dim3(256), 0, h->stream, (const uint32_t *) F.d_sel1, (const uint32_t *) F.d_order, (int) n1, F.d_selx); d_idx1 = F.d_selx; }
+        if (out && out->keypoint_indices && n2) { hipLaunchKernelGGL(k_frame_translate, dim3(grid_for(n2)), dim3(256), 0, h->stream, (const uint32_t *) F.d_sel2, (const uint32_t *) F.d_order, (int) n2, F.d_selx + F.cap); d_idx2 = F.d_selx + F.cap; }
+        HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipGetLastError());
     const bool fuse = fused_max_distance != nullptr && !robust && h->update_mode == 1;
     hipStream_t s_out = h->stream;
@@ -2724,9 +2729,9 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
     if (out && out->sampled_world_base && n1)
         HIPCHK(h, hipMemcpyAsync(F.h_out + 3 * c, F.d_corr, (2 * c + n1) * sizeof(double), hipMemcpyDeviceToHost, s_out));
     if (out && out->sampled_indices && n1)
-        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
+        HIPCHK(h, hipMemcpyAsync(F.h_sel, d_idx1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
     if (out && out->keypoint_indices && n2)
-        HIPCHK(h, hipMemcpyAsync(F.h_sel + c, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
+        HIPCHK(h, hipMemcpyAsync(F.h_sel + c, d_idx2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s_out));
     bool update_pending = false;
     if (fuse) {
         // odometry.cpp:936-952 on the device's own copy of the new pose: eviction round its end translation, then the sampled frame —
@@ -2778,10 +2783,8 @@ static ctgn_status frame_register_body(ctgn_handle h, ctgn_view raw, ctgn_view t
             for (size_t k = 0; k < n1; ++k)
                 write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
                             F.h_out[4 * c + k], F.h_out[5 * c + k]);
-        if (out->sampled_indices)
-            for (size_t k = 0; k < n1; ++k) out->sampled_indices[k] = order ? order[F.h_sel[k]] : F.h_sel[k];
-        if (out->keypoint_indices)
-            for (size_t k = 0; k < n2; ++k) out->keypoint_indices[k] = order ? order[F.h_sel[c + k]] : F.h_sel[c + k];
+        if (out->sampled_indices) std::memcpy(out->sampled_indices, F.h_sel, n1 * sizeof(uint32_t));
+        if (out->keypoint_indices) std::memcpy(out->keypoint_indices, F.h_sel + c, n2 * sizeof(uint32_t));
     }
     F.valid = true;
     if (update_pending) {                             // (the hand-over above ran beside it)
@@ -2910,15 +2913,20 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
         ctgn_status ss = frame_stage(h, raw, ts, n, order, fo, pose, tbe, prestaged ? 2 : 0);
         if (ss != CTGN_OK) return ss;
     }
-    if (order) F.order.assign(order, order + n);
     {
         ctgn_status ss = frame_sample(h, fo->frame_voxel_size, fo->sample_voxel_size);
         if (ss != CTGN_OK) return ss;
     }
-    if (F.device_shuffled) { order = F.h_order; F.order.assign(order, order + n); }
     const size_t c = F.stride, n1 = F.n1;
-    if (out && out->sampled_indices && n1)
-        HIPCHK(h, hipMemcpyAsync(F.h_sel, F.d_sel1, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out && out->sampled_indices && n1) {
+        const uint32_t *d_idx = F.d_sel1;
+        if (F.permuted) {                              // positions -> the caller's point numbers, on the device
+            hipLaunchKernelGGL(k_frame_translate, dim3(grid_for(n1)), dim3(256), 0, h->stream, (const uint32_t *) F.d_sel1, (const uint32_t *) F.d_order, (int) n1, F.d_selx);
+            HIPCHK(h, hipGetLastError());
+            d_idx = F.d_selx;
+        }
+        HIPCHK(h, hipMemcpyAsync(F.h_sel, d_idx, n1 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
     if (out && out->sampled_world_base && n1) {      // the sampled frame under the initial estimate (odometry.cpp:371-375)
         hipLaunchKernelGGL(k_transform_points, dim3(grid_for(n1)), dim3(256), 0, h->stream, F.d_scan + 16, F.d_corr, (int) n1, (size_t) 1,
                            (const double *) F.d_scan, tbe[0], tbe[1], (const uint32_t *) F.d_sel1, c, (size_t) 4);
@@ -2930,8 +2938,7 @@ static ctgn_status frame_begin_body(ctgn_handle h, ctgn_view raw, ctgn_view ts, 
         out->num_sampled = n1;
         out->num_keypoints = fo->max_num_keypoints > 0 ? std::min<size_t>(F.n2, (size_t) fo->max_num_keypoints) : F.n2;
         out->num_keypoint_candidates = F.n2;
-        if (out->sampled_indices)
-            for (size_t k = 0; k < n1; ++k) out->sampled_indices[k] = order ? order[F.h_sel[k]] : F.h_sel[k];
+        if (out->sampled_indices) std::memcpy(out->sampled_indices, F.h_sel, n1 * sizeof(uint32_t));
         if (out->sampled_world_base)
             for (size_t k = 0; k < n1; ++k)
                 write_point(out->sampled_world_base, out->sampled_world_stride_bytes, out->sampled_world_dtype, k, F.h_out[3 * c + k],
@@ -3028,10 +3035,15 @@ ctgn_status ctgn_frame_try_register(ctgn_handle h, const ctgn_frame_options *fo,
     if (st != CTGN_OK) return st;
     if (want_world) scatter_world_from_staging(h, out->keypoint_world_base, out->keypoint_world_stride_bytes, out->keypoint_world_dtype, n2);
     if (out && out->keypoint_indices && n2) {
-        HIPCHK(h, hipMemcpyAsync(F.h_sel + F.stride, F.d_sel2, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        const uint32_t *d_idx = F.d_sel2;
+        if (F.permuted) {
+            hipLaunchKernelGGL(k_frame_translate, dim3(grid_for(n2)), dim3(256), 0, h->stream, (const uint32_t *) F.d_sel2, (const uint32_t *) F.d_order, (int) n2, F.d_selx + F.cap);
+            HIPCHK(h, hipGetLastError());
+            d_idx = F.d_selx + F.cap;
+        }
+        HIPCHK(h, hipMemcpyAsync(F.h_sel + F.stride, d_idx, n2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const uint32_t *order = F.order.empty() ? nullptr : F.order.data();
-        for (size_t k = 0; k < n2; ++k) out->keypoint_indices[k] = order ? order[F.h_sel[F.stride + k]] : F.h_sel[F.stride + k];
+        std::memcpy(out->keypoint_indices, F.h_sel + F.stride, n2 * sizeof(uint32_t));
     }
     if (out) { out->num_keypoints = n2; out->num_keypoint_candidates = F.n2; }
     return CTGN_OK;

@@ -2711,6 +2711,11 @@ __global__ __launch_bounds__(256) void k_frame_permute(const double *rec_in, dou
     }
 }
 
+// positions in processing order -> the caller's point numbers (order[j] = caller index of the point at position j)
+__global__ __launch_bounds__(256) void k_frame_translate(const uint32_t *sel, const uint32_t *order, int n, uint32_t *out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = order[sel[i]];
+}
+
 __global__ __launch_bounds__(256) void k_frame_keypoints(const double *scan, const uint32_t *sel, int n, double *kp, size_t c) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double *q = scan + (size_t) sel[i] * 4;
