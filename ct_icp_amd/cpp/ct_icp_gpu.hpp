@@ -442,6 +442,7 @@ struct FrameOptions {
     double sample_voxel_size = 1.5;          // OdometryOptions::sample_voxel_size (grid_sampling); <= 0: sampling NONE
     int max_num_keypoints = -1;
     const std::vector<uint32_t> *order = nullptr;    // the caller's shuffle of the scan (odometry.cpp:349), or scan order
+    uint64_t shuffle_seed = 0;               // != 0 (and no `order`): the shuffle is made on the device (ctgn_frame_options::shuffle_seed)
 };
 inline ICPSummary RegisterFrame(GpuVoxelMap &voxel_map, const CTICPOptions &options, const FrameOptions &frame_options,
                                 const std::vector<WPoint3D> &scan, TrajectoryFrame &trajectory_frame,
@@ -469,6 +470,7 @@ inline ICPSummary RegisterFrame(GpuVoxelMap &voxel_map, const CTICPOptions &opti
     fo.frame_voxel_size = frame_options.voxel_size;
     fo.sample_voxel_size = frame_options.sample_voxel_size;
     fo.max_num_keypoints = frame_options.max_num_keypoints;
+    fo.shuffle_seed = frame_options.shuffle_seed;
     double pose[14];
     std::memcpy(pose, trajectory_frame.begin_pose.pose.quat, 32);
     std::memcpy(pose + 4, trajectory_frame.begin_pose.pose.tr, 24);
