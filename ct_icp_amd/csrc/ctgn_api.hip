@@ -87,6 +87,7 @@ struct Tuning {
     double frame_defer_update = 1;  // ctgn_frame_update_map without an insert mask returns once the update is enqueued (0: waits for it)
     double stop_poll = 1;           // the host watches the solve's stop flag and does not enqueue the launches behind it (0: enqueues all num_iters_icp iterations)
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
+    double stage_lds = 0;           // 1: the 125-voxel sweep streams a home-voxel group's candidates from LDS (GroupStage; prototype, use with tile_chunk 4-16)
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
 };
@@ -95,7 +96,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
     CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update) CTGN_TUNING_KEY(stop_poll)
-    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
+    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(stage_lds) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
 }
@@ -217,6 +218,7 @@ struct ctgn_context {
     int fail_slot = 0;                  // which of the two fail-list counters the next split launch counts in (the other one is zeroed by it)
     uint64_t last_upload_bytes = 0;     // host-to-device bytes of the last ctgn_set_keypoints_sharded call on this rank (bench detail)
     int rb_split_search[2] = {0, 0};    // resident blocks of the split path's search launch (27- / 125-voxel instantiation)
+    bool stage_ok = false;            // the GroupStage instantiation of the search kernel got its 80 KB of dynamic LDS
     int rb_rows[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident blocks of k_accumulate_rows by (sweep, variant)
     int rb_check = 0, rb_fused[2] = {0, 0}, per_cu_persist[2] = {0, 0};   // the other occupancy queries, cached per handle (= per device) too
     bool fail_reset_pending = true;     // a new solve began: its first split launch zeroes both counters and starts from slot 0 (a solve that
@@ -816,8 +818,9 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                            h->d_state, h->prm, h->d_partials, dv, first_iter ? 1 : 0);
     } else {
         // one instantiation per (sweep half-width, selection flavour, instrumentation, waves per SIMD)
+        int rb_slot = (mv.nb == 1 ? 0 : 8) + (h->variant & 7);
         auto launch = [&](auto kernel, size_t smem, unsigned long long *prof) {
-            int &rb = h->rb_rows[(mv.nb == 1 ? 0 : 8) + (h->variant & 7)];        // one occupancy query per handle and instantiation (it used to run on every launch)
+            int &rb = h->rb_rows[rb_slot];        // one occupancy query per handle and instantiation (it used to run on every launch)
             if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
             const int rounds = pick_rounds(h->n_kp, rb * ROW_WAVES);
             const int ntiles = (h->n_kp + 4 * rounds - 1) / (4 * rounds);
@@ -904,6 +907,10 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             const size_t sm = rows_kernel_smem<2>();
             if (h->variant == 2) launch(k_accumulate_rows<2, false, false, 3, false, false>, sm, nullptr);
             else if (h->variant == 3) launch(k_accumulate_rows<2, true, true, 3>, sm, h->d_prof);
+            else if (h->variant == 0 && tuning().stage_lds != 0 && h->stage_ok) {
+                rb_slot = 8 + 6;           // (its own occupancy entry)
+                launch(k_accumulate_rows<2, true, false, 2, false, true, true>, sm + ROW_WAVES * sizeof(GroupStage), h->d_prof);
+            }
             else launch(k_accumulate_rows<2, true, false, 3>, sm, nullptr);
         }
     }
@@ -1152,6 +1159,9 @@ ctgn_status ctgn_create(const ctgn_map_options *opts, ctgn_handle *out) {
                                        (int) persistent_kernel_smem<1>()) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gn_persistent<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) persistent_kernel_smem<2>()) == hipSuccess;
+        h->stage_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_accumulate_rows<2, true, false, 2, false, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int) (rows_kernel_smem<2>() + ROW_WAVES * sizeof(GroupStage))) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_robust_eval_step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) sizeof(FuseScratch)) == hipSuccess;
         if (!ok) { ctgn_destroy(h); return CTGN_ERR_HIP; }

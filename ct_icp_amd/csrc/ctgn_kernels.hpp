@@ -215,8 +215,13 @@ __device__ __forceinline__ bool sweep_in_short_range(int k, int nb) {
 //   NORMALS_FAST    the fast solver only (rounds 1-3).
 // GnParams::normals selects the mode (ctgn_set_normals, ct_icp_amd/csrc/ctgn_internal.h); bits 16-17 of the ablation mask override it (A/B).
 constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
-#ifndef CTGN_SHARED2_DEFAULT_OFF
-#define CTGN_SHARED2_DEFAULT_OFF 0   // 0: the 125-voxel sweep probes a round's shared home voxel once per wave (rows_tiles, shared2); bit 22 of the ablation mask flips it
+// Wave-shared probes of the 125-voxel sweep (rows_tiles, shared2): 0 = off unless bit 22 of the ablation mask is set, 1 = on unless it is.
+// OFF by default — and it always was: round 4 shipped the switch with its sense inverted (the macro was called ..._DEFAULT_OFF and compared
+// with `!=`), so the "-2 %" of that round's A/B (D 0.857 -> 0.839 ms) was the gain of NOT sharing the probes, and rounds 4-5 measured every
+// D number without them. Measured again in round 6 with the sense known (profiles/r06_ab_group_stage.txt, same box): D 0.6166 ms off,
+// 0.6287 on (+2 %); C 0.0412 / 0.0411. Off stays.
+#ifndef CTGN_SHARED2_DEFAULT_ON
+#define CTGN_SHARED2_DEFAULT_ON 0
 #endif
 // Stream loop of the generic path: keep the next chunk's loads IN FRONT of the current chunk's test in the instruction stream. Left to
 // itself the scheduler starts the test (whose first instructions wait for the current chunk) before it has issued the next chunk's
@@ -650,6 +655,21 @@ struct WaveScratch {
     };
 };
 
+// Home-voxel-group stage of the 125-voxel sweep (round 6, prototype behind the tuning key `stage_lds`; template flag STAGE of rows_tiles).
+// On an upload sorted by home voxel (config D: ~100 keypoints per 0.5 m voxel) consecutive rounds of a chunked tile (KpView::chunk) search
+// the same handful of voxels. The wave copies the points of the home voxel's INNER neighbourhood (the <= 27 voxels within +-1 per axis
+// that some keypoint of the group can reach) into LDS once — flat, nearest voxels first, each point with its visit index — and every row
+// of every round of the group then streams that table: no reach tests, no chunk lists, no global loads and no address arithmetic in the
+// stream loop, and all four rows run the same number of steps. A point of a voxel a row's bound does not reach fails `d2 <= bound` like
+// any other (the reach test is a superset test of exactly that), so the admitted set — and every result — is the generic path's.
+// 7.3 KB per wave on top of WaveScratch's 12.9: two blocks per CU instead of three (the instantiation is compiled for 2 waves per SIMD).
+constexpr int GCAP = 272;                    // points the table holds; a group that needs more takes the generic path
+struct GroupStage {
+    double x[GCAP], y[GCAP], z[GCAP];
+    uint16_t vis[GCAP];                      // (sweep voxel index << 6) | slot, as RowList::vis
+    uint2 vinfo[28];                         // inner voxel i (nearest first): .x = byte offset of its block, .y = (sweep index << 20) | (flat start << 8) | points
+};
+
 // k nearest of the row's list (d2, vis)[0..Ln) under the total order (d2, vis); winners are written back
 // sorted ascending at [0..min(Ln,k)). HIST: first cut the list with a 16-bin histogram of d2 over [0, hi]
 // (one bin per lane): only the bins up to the one in which the running count reaches k can hold winners.
@@ -901,7 +921,7 @@ __device__ __forceinline__ bool rows_share_home(int kx, int ky, int kz) {
 // The tile loop of the row search: the body of k_accumulate_rows, and — with `after_tile`, called by the whole wave when a tile's
 // rounds are done, while W.id[] still names the tile's keypoints — of the persistent small-frame kernel (k_gn_persistent), which runs
 // the residual part for the same keypoints right there.
-template <int NB, bool HIST, bool PROF, bool SHARED, bool POOLS, typename AfterTile>
+template <int NB, bool HIST, bool PROF, bool SHARED, bool POOLS, bool STAGE = false, typename AfterTile>
 __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp, const GnState *st, const GnParams &prm, const DebugView &dbg,
                                            int first_iter, int rounds, unsigned long long *prof, int ablate, char *smem, int tile_first, int tile_end,
                                            int tile_step, AfterTile after_tile) {
@@ -939,6 +959,14 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
     // form) it was probed for; a later round with the same home voxel that needs no more than that takes the table as it is (round 5)
     int s2_hx = INT_MIN, s2_hy = 0, s2_hz = 0;
     uint32_t s2_mask = 0u;
+    // STAGE: the home voxel whose inner neighbourhood sits in the wave's GroupStage, the slab-mask product it was filled for, its points;
+    // g3_no_*: the last home voxel whose group did not fit the table (not tried again while the rounds stay there)
+    GroupStage *const G3 = STAGE ? reinterpret_cast<GroupStage *>(smem + sizeof(WaveScratch<OCC>) * ROW_WAVES) + wave : nullptr;
+    int g3_hx = INT_MIN, g3_hy = 0, g3_hz = 0, g3_P = 0;
+    uint32_t g3_mask = 0u;
+    int g3_no_hx = INT_MIN, g3_no_hy = 0, g3_no_hz = 0;
+    int g3_rounds = 0, g3_fills = 0, g3_all_rounds = 0;     // STAGE statistics: rounds that streamed the table, table fills, search rounds
+    int g3_over = 0, g3_points = 0, g3_eligible = 0;        // ... fills given up (more points than GCAP), points copied, rounds with an inner reach in one home voxel
     for (int tile = tile_first; tile < tile_end; tile += tile_step) {
         // ---------------- phase A: lane (row, sub < rounds) owns keypoint (sub * ntiles + tile) * 4 + row: round r of a
         // tile works on four CONSECUTIVE keypoints (neighbours in the scan usually share their home voxel), while the
@@ -1198,6 +1226,7 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             const uint32_t *occ_tab = RP.occ;     // where B4 finds a candidate's voxel block
             bool tie_seen = false;                // some selection of this round met candidates whose distances (nearly) tie
             if (PROF) pc[9] += 1;
+            if (STAGE) ++g3_all_rounds;
 
             if (uniform_home) {
                 // ===== fast path: shared, flattened neighbourhood =====
@@ -1332,7 +1361,9 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
             // 16 per row (into a table far larger than the caches a first search spends 44 % of its wave time there); the rows then take
             // their sweep voxels from the wave's table, each with its own reach test against its own current bound, as before.
             bool shared2 = false;
-            if (NB == 2 && (((ablate >> 22) & 1) != CTGN_SHARED2_DEFAULT_OFF)) {
+            bool staged3 = false;                 // STAGE: this round streams the wave's GroupStage
+            const bool share_on = ((ablate >> 22) & 1) != CTGN_SHARED2_DEFAULT_ON;
+            if (NB == 2 && (STAGE || share_on)) {
                 int hx = INT_MIN, hy = 0, hz = 0;
                 bool same = true;
 #pragma unroll
@@ -1354,11 +1385,11 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                     const uint32_t m2 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 32);
                     const uint32_t m3 = (uint32_t) __builtin_amdgcn_readlane((int) (searching ? mreach : 0u), 48);
                     const uint32_t mu = m0 | m1 | m2 | m3;
-                    const bool staged = !(ablate & (1 << 27)) && hx == s2_hx && hy == s2_hy && hz == s2_hz && (mu & ~s2_mask) == 0u;
-                    if (!staged) {
+                    // the wave's probes of the home voxel's sweep for the slab-mask product `mask`, two voxels per lane, into W.socc
+                    auto probe_home = [&](uint32_t mask) {
                         auto wanted = [&](int v) {
                             const int ox = v / (S * S), oy = (v / S) % S, oz = v % S;            // offsets + NB: bit positions 0 .. 4
-                            return v < V && ((mu >> ox) & (mu >> (5 + oy)) & (mu >> (10 + oz)) & 1u) != 0u;
+                            return v < V && ((mask >> ox) & (mask >> (5 + oy)) & (mask >> (10 + oz)) & 1u) != 0u;
                         };
                         const int v0 = lane, v1 = lane + 64;
                         const bool w0 = wanted(v0) && !(ablate & 16), w1 = wanted(v1) && !(ablate & 16);
@@ -1368,10 +1399,119 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
                         const uint32_t b0 = probe_resolve(map, p0), b1 = probe_resolve(map, p1);
                         W.socc[v0] = b0;
                         W.socc[v1] = b1;
-                        s2_hx = hx; s2_hy = hy; s2_hz = hz; s2_mask = mu;
+                        s2_hx = hx; s2_hy = hy; s2_hz = hz; s2_mask = mask;
+                    };
+                    if constexpr (STAGE) {
+                        // no row of the round reaches beyond the voxels next to the home voxel (no +-2 bit in any slab mask): the round can
+                        // stream the group's table — the one in LDS if it covers the round's mask, else it is filled now
+                        if ((mu & 0x4631u) == 0u && !(ablate & (1 << 28))) {
+                            ++g3_eligible;
+                            bool have = hx == g3_hx && hy == g3_hy && hz == g3_hz && (mu & ~g3_mask) == 0u;
+                            if (!have && !(hx == g3_no_hx && hy == g3_no_hy && hz == g3_no_hz)) {
+                                // the mask of the GROUP: every keypoint of the tile that is still to be searched in this home voxel with an
+                                // inner reach (W.mr, phase A2) — with chunked tiles (KpView::chunk) those are the following rounds
+                                const bool mine = W.todo[lane] == 1 && W.kx[lane] == hx && W.ky[lane] == hy && W.kz[lane] == hz &&
+                                                  ((uint32_t) W.mr[lane] & 0x4631u) == 0u;
+                                uint32_t mg = mine ? (uint32_t) W.mr[lane] : 0u;
+                                mg |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) mg, 0xB1, 0xf, 0xf, false);
+                                mg |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) mg, 0x4E, 0xf, 0xf, false);
+                                mg |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) mg, 0x141, 0xf, 0xf, false);
+                                mg |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) mg, 0x140, 0xf, 0xf, false);
+                                mg = mu | (uint32_t) (__builtin_amdgcn_readlane((int) mg, 0) | __builtin_amdgcn_readlane((int) mg, 16) |
+                                                      __builtin_amdgcn_readlane((int) mg, 32) | __builtin_amdgcn_readlane((int) mg, 48));
+                                auto stage_group = [&](uint32_t mask) -> bool {
+                                    probe_home(mask);
+                                    GroupStage &G = *G3;
+                                    // lane i < 27 takes the i-th NEAREST inner voxel (the first 27 entries of the nearest-first order are the
+                                    // +-1 cube): the table starts with the home voxel's points
+                                    const int sv = lane < 27 ? (int) c_sweep2.v[lane] : 0;
+                                    const uint32_t bc = lane < 27 ? W.socc[sv] : 0u;
+                                    const int cnt = (int) (bc & 127u);
+                                    const int inc = row_scan_i32(cnt);
+                                    const int tot0 = __builtin_amdgcn_readlane(inc, 15), tot1 = __builtin_amdgcn_readlane(inc, 31);
+                                    g3_hx = INT_MIN;
+                                    if (tot0 + tot1 > GCAP) { ++g3_over; return false; }
+                                    const int pre = inc - cnt + (row == 1 ? tot0 : 0);           // flat position of this voxel's first point
+                                    if (lane < 28) G.vinfo[lane] = make_uint2((bc >> 7) * stride3, ((uint32_t) sv << 20) | ((uint32_t) pre << 8) | (uint32_t) cnt);
+                                    // copy: 16 points of four voxels per step (one voxel per row), every load of a pass in flight together
+                                    for (int hh = 0; hh < 4; ++hh) {
+                                        if (!ballot64(cnt > 16 * hh)) break;
+                                        double cx[7], cy[7], cz[7];
+                                        uint2 vi[7];
+#pragma unroll
+                                        for (int g = 0; g < 7; ++g) {
+                                            vi[g] = G.vinfo[4 * g + row];
+                                            const bool ok = sub < (int) (vi[g].y & 127u) - 16 * hh;
+                                            load_point(pbase, vi[g].x + (ok ? (uint32_t) (16 * hh + sub) * POINT_BYTES : 0u), cx[g], cy[g], cz[g]);
+                                        }
+#pragma unroll
+                                        for (int g = 0; g < 7; ++g) {
+                                            if (sub < (int) (vi[g].y & 127u) - 16 * hh) {
+                                                const int d = (int) ((vi[g].y >> 8) & 0xfffu) + 16 * hh + sub;
+                                                G.x[d] = cx[g]; G.y[d] = cy[g]; G.z[d] = cz[g];
+                                                G.vis[d] = (uint16_t) (((vi[g].y >> 20) << 6) | (uint32_t) (16 * hh + sub));
+                                            }
+                                        }
+                                    }
+                                    if (PROF) pc[11] += (unsigned long long) (tot0 + tot1);
+                                    g3_hx = hx; g3_hy = hy; g3_hz = hz; g3_mask = mask; g3_P = tot0 + tot1;
+                                    ++g3_fills;
+                                    g3_points += tot0 + tot1;
+                                    return true;
+                                };
+                                have = stage_group(mg) || (mg != mu && stage_group(mu));
+                                if (!have) { g3_no_hx = hx; g3_no_hy = hy; g3_no_hz = hz; }
+                            }
+                            staged3 = have;
+                        }
+                    }
+                    if (!staged3 && !share_on) {
+                        shared2 = false;          // STAGE without the wave-shared probes: a round the table does not serve probes per row
+                    } else {
+                        const bool staged = staged3 || (!(ablate & (1 << 27)) && hx == s2_hx && hy == s2_hy && hz == s2_hz && (mu & ~s2_mask) == 0u);
+                        if (!staged) probe_home(mu);
                     }
                 }
             }
+            if (STAGE && staged3) {
+                // ===== the round streams the group's table: 16 candidates per row and step, the same ones for the four rows (LDS broadcast
+                // reads), each tested against its row's own query and bound; lists, cuts and everything behind them as on the generic path
+                occ_tab = W.socc;
+                const GroupStage &G = *G3;
+                const int P = g3_P;
+                ++g3_rounds;
+                CTGN_TICK(1)
+                auto test3 = [&](double x, double y, double z, uint32_t vis, bool valid) {
+                    const double dx = x - qx, dy = y - qy, dz = z - qz;
+                    const double d2 = sq_norm3(dx, dy, dz);
+                    const bool pass = valid && d2 <= kth_d2;
+                    const uint32_t pm = row_bits(ballot64(pass), row);
+                    if (pass) {
+                        const int pos = Ln + __popc(pm & lt_mask);
+                        R.d2[pos] = d2;
+                        R.vis[pos] = vis;
+                    }
+                    Ln += __popc(pm);
+                };
+                for (int s0 = 0; s0 < P; s0 += 32) {
+                    const int ia = s0 + sub, ib = ia + 16;
+                    const int ca = min(ia, GCAP - 1), cb = min(ib, GCAP - 1);
+                    const double xa = G.x[ca], ya = G.y[ca], za = G.z[ca];
+                    const uint32_t va = G.vis[ca];
+                    const double xb = G.x[cb], yb = G.y[cb], zb = G.z[cb];
+                    const uint32_t vb = G.vis[cb];
+                    if (PROF) pc[11] += (unsigned long long) min(32, P - s0);
+                    test3(xa, ya, za, va, searching && ia < P);
+                    test3(xb, yb, zb, vb, searching && ib < P);
+                    if (any64(Ln > LCAP - 32)) {
+                        CTGN_TICK(2)
+                        Ln = row_select<HIST>(R, Ln, kpool, sub, row, kth_d2, tie_seen);
+                        if (Ln >= kpool) kth_d2 = kth_bound(R.d2[kpool - 1], map.r2thr);
+                        CTGN_TICK(3)
+                    }
+                }
+                CTGN_TICK(2)
+            } else {
             if (!shared2 && nxt_round != r) nxt = issue_batch<NB>(map, 0, sub, searching, kx, ky, kz, qx, qy, qz, nxt_v, ablate, r2bound, mreach);
             // B1 + B2, interleaved per batch of 16 sweep voxels (nearest voxels first):
             //   probe 16 voxels (one per lane) -> RP.occ[v] -> one chunk per 16 points of each occupied voxel -> the row
@@ -1524,6 +1664,7 @@ CTGN_BATCH_UNROLL
                 }
             }
             }
+            }
             // the next round's shared probes go out now, so their latency hides behind this round's selection and sums
             if (SHARED && NB == 1 && blk <= 32 && r + 1 < search_rounds) {
                 const int slot2 = slot_of(r + 1, row);
@@ -1607,6 +1748,14 @@ CTGN_BATCH_UNROLL
         }
         after_tile(tile);
     }
+    if (STAGE && !PROF && prof && lane == 0) {      // how often the prototype's path ran (ctgn_phase_cycles slots 7 .. 9)
+        atomicAdd(&prof[7], (unsigned long long) g3_fills);
+        atomicAdd(&prof[8], (unsigned long long) g3_rounds);
+        atomicAdd(&prof[9], (unsigned long long) g3_all_rounds);
+        atomicAdd(&prof[4], (unsigned long long) g3_eligible);
+        atomicAdd(&prof[5], (unsigned long long) g3_points);
+        atomicAdd(&prof[6], (unsigned long long) g3_over);
+    }
     if (PROF && lane == 0) {
         unsigned long long tot_ = 0;
         for (int q = 0; q < 10; ++q) { atomicAdd(&prof[q], pc[q]); if (q < 7) tot_ += pc[q]; }
@@ -1624,7 +1773,7 @@ CTGN_BATCH_UNROLL
 // NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles; POOLS = compile the
 // pool check (phase V) in: off for the A/B instantiations and the small-frame persistent kernel, which never see a frame large enough
 // to use it and would only carry its registers.
-template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true>
+template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true, bool STAGE = false>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
                                                                unsigned long long *prof = nullptr, int ablate = 0) {
@@ -1653,7 +1802,7 @@ __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map,
         tile_end = min(ntiles, (x + 1) * per);
         tile_step = blocks_on_x * ROW_WAVES;
     }
-    rows_tiles<NB, HIST, PROF, SHARED, POOLS>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
+    rows_tiles<NB, HIST, PROF, SHARED, POOLS, STAGE>(map, kp, st, prm, dbg, first_iter, rounds, prof, ablate, smem, tile_first, tile_end, tile_step, [](int) {});
 }
 
 // ================================================================================================
@@ -2106,7 +2255,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 2) void k_search_residual(MapView map, K
     const int ntiles = (kp.n + 4 * rounds - 1) / (4 * rounds);
     d4_t accm = {0.0, 0.0, 0.0, 0.0};
     int n_used_wave = 0;
-    rows_tiles<NB, true, false, false, false>(map, kp, st, prm, dbg, first_iter, rounds, nullptr, 0, smem, blockIdx.x * ROW_WAVES + wave, ntiles,
+    rows_tiles<NB, true, false, false, false, false>(map, kp, st, prm, dbg, first_iter, rounds, nullptr, 0, smem, blockIdx.x * ROW_WAVES + wave, ntiles,
                                        gridDim.x * ROW_WAVES, [&](int) {
         const int id = W.id[lane];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2
@@ -2512,7 +2661,7 @@ __global__ __launch_bounds__(ROW_BLOCK, 2) void k_gn_persistent(MapView map, KpV
         WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> &W =
             reinterpret_cast<WaveScratch<((2 * NB + 1) * (2 * NB + 1) * (2 * NB + 1) + 3) & ~3> *>(smem)[wave];
         // search of a tile, then — same wave, keypoints still named by W.id — its residual part: lane l takes keypoint W.id[l]
-        rows_tiles<NB, true, false, false, false>(map, kv, &P.state, prm, dbg, (iters_before + it) == 0 ? 1 : 0, rounds, nullptr, 0, smem,
+        rows_tiles<NB, true, false, false, false, false>(map, kv, &P.state, prm, dbg, (iters_before + it) == 0 ? 1 : 0, rounds, nullptr, 0, smem,
                                            b * ROW_WAVES + wave, ntiles, nblk * ROW_WAVES, [&](int) {
             const int id = W.id[lane];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wave's own records and world points have left for L2

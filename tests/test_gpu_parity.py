@@ -555,13 +555,16 @@ def test_sharded_loop_single_rank_equals_fused(box_case):
 
 
 def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
-    """Round 4: on the 125-voxel sweep a round whose (active) keypoints live in one home voxel probes its 125 voxels once per wave
+    """Round 4: on the 125-voxel sweep a round whose (active) keypoints live in one home voxel can probe its 125 voxels once per wave
     (rows_tiles, shared2) instead of eight dependent batches per row. Dense keypoints (every return of the scan) worked through in
     home-voxel order make that the rule; with pools on and off, four iterations: counts, farthest neighbours, gates and packed system
-    are the ones of the per-row probes (bit 22 of the ablation mask switches the shared stage off) after every iteration, and the first
-    accumulation's neighbour sets are the oracle's. Round 5: the same against the batch loop run to its end (bit 26: no early stop
-    after the batches some row can reach), against a probe table that is never reused (bit 27), and with tiles of four consecutive
-    rounds (tuning tile_chunk: consecutive rounds share their home voxel, so the table IS reused)."""
+    of the per-row probes and of the shared ones (bit 22 of the ablation mask switches them ON: they are off by default, see
+    CTGN_SHARED2_DEFAULT_ON in ctgn_kernels.hpp) are equal after every iteration, and the first accumulation's neighbour sets are the
+    oracle's. Round 5: the same against the batch loop run to its end (bit 26: no early stop after the batches some row can reach),
+    against a shared probe table that is never reused (bit 27), and with tiles of four consecutive rounds (tuning tile_chunk:
+    consecutive rounds share their home voxel, so the table IS reused). Round 6: the same with the home-voxel-group stage (tuning
+    stage_lds: the candidates of a group streamed from LDS, rows_tiles STAGE), alone, with chunked tiles, and over the shared probes."""
+    S2 = 1 << 22
     case = nclt_case
     om, gm = build_maps(case, 8, with_gpu=True)
     sc = case["scans"][8]
@@ -571,10 +574,13 @@ def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
     o = _opts(num_iters_icp=4, min_number_neighbors=10, threshold_orientation_norm=0.0)
     for pools in (0, 1):
         runs = []
-        for mask, chunk in ((0, 0), (1 << 22, 0), (1 << 26, 0), (1 << 27, 0), (0, 4)):
+        for mask, chunk, stage in ((0, 0, 0), (S2, 0, 0), (1 << 26, 0, 0), (S2 | (1 << 26), 0, 0), (S2 | (1 << 27), 0, 0), (S2, 4, 0), (0, 4, 0),
+                                   (0, 0, 1), (0, 4, 1), (S2, 16, 1)):
             L.lib().ctgn_set_tuning(b"tile_chunk", float(chunk))
+            L.lib().ctgn_set_tuning(b"stage_lds", float(stage))
             try:
                 s = cia.GnSolver(gm)
+                s.phase_cycles(reset=True)
                 s.set_ordering(1)
                 s.set_pools(pools)
                 s.set_ablation(mask)
@@ -587,8 +593,16 @@ def test_wave_shared_probes_of_the_125_voxel_sweep(nclt_case):
                     d = s.get_debug()
                     per_iter.append((s.get_system(), d["n_neighbors"].copy(), d["farthest"].copy(), d["used"].copy(), d["a2d"].copy()))
                 pose, summ, _ = s.gn_end()
+                if stage:
+                    # the prototype's path did run: a good part of the search rounds streamed a staged table (the others reach beyond the
+                    # inner voxels, mix home voxels, or their group holds more points than the table)
+                    fills, staged_rounds, all_rounds = (int(v) for v in s.phase_cycles()[7:10])
+                    assert all_rounds > 1000 and staged_rounds > 0.25 * all_rounds and 0 < fills <= staged_rounds, (fills, staged_rounds, all_rounds)
+                    if chunk:
+                        assert fills < staged_rounds, (fills, staged_rounds)       # consecutive rounds of a chunk share a table
             finally:
                 L.lib().ctgn_set_tuning(b"tile_chunk", 0.0)
+                L.lib().ctgn_set_tuning(b"stage_lds", 0.0)
             runs.append((pose, per_iter))
         for other in runs[1:]:
             assert np.array_equal(runs[0][0], other[0])
