@@ -69,6 +69,9 @@ static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState i
 // 4-wave solve block, the unfused frame call) are gone together with their code paths.
 // Not synchronised: ctgn_set_tuning is for a measurement script or a test that owns the process, between calls — not for threads that
 // are solving meanwhile. host_threads is latched by the first scan-sized frame call (the pool is sized then): setting it later is refused.
+#ifndef CTGN_ROWS_WPS
+#define CTGN_ROWS_WPS 3            // waves per SIMD the default search-kernel instantiations are compiled for (A/B builds: 4 with CTGN_LCAP=80)
+#endif
 struct Tuning {
     double host_threads = 3;        // helper threads of the host-side staging loops (0 = none)
     double order = -1;              // home-voxel ordering when ctgn_set_ordering left it automatic: -1 = cost model, 0 / 1 = never / always
@@ -886,8 +889,8 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 hipLaunchKernelGGL(kernel, dim3(rb), dim3(ROW_BLOCK), smem, h->stream, mv, ks, h->d_state, h->prm, h->d_partials, dv, 0, 1,
                                    (unsigned long long *) nullptr, h->ablate);
             };
-            if (mv.nb == 1) search(k_accumulate_rows<1, true, false, 3>, rows_kernel_smem<1>());
-            else search(k_accumulate_rows<2, true, false, 3>, rows_kernel_smem<2>());
+            if (mv.nb == 1) search(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<1>());
+            else search(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<2>());
             h->kth_fresh = true;
             if (ev) (void) hipEventRecord(ev->stop, h->stream);
             ev = nullptr;
@@ -901,7 +904,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 case 3: launch(k_accumulate_rows<1, true, true, 3>, sm, h->d_prof); break;
                 case 4: launch(k_accumulate_rows<1, true, false, 4, false, false>, sm, nullptr); break;
                 case 5: launch(k_accumulate_rows<1, true, false, 3, true, false>, sm, nullptr); break;      // with the shared-home-voxel path (A/B hook)
-                default: launch(k_accumulate_rows<1, true, false, 3>, sm, nullptr); break;
+                default: launch(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, sm, nullptr); break;
             }
         } else {
             const size_t sm = rows_kernel_smem<2>();
@@ -911,7 +914,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 rb_slot = 8 + 6;           // (its own occupancy entry)
                 launch(k_accumulate_rows<2, true, false, 2, false, true, true>, sm + ROW_WAVES * sizeof(GroupStage), h->d_prof);
             }
-            else launch(k_accumulate_rows<2, true, false, 3>, sm, nullptr);
+            else launch(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS>, sm, nullptr);
         }
     }
     HIPCHK(h, hipGetLastError());

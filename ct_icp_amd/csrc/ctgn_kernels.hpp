@@ -480,7 +480,10 @@ inline size_t lane_kernel_smem() {
 // ================================================================================================
 constexpr int ROW_WAVES = 4;                 // waves per block
 constexpr int ROW_BLOCK = ROW_WAVES * 64;
-constexpr int LCAP = 96;                     // per-row candidate list capacity (>= KMAX + 2*16)
+#ifndef CTGN_LCAP
+#define CTGN_LCAP 96
+#endif
+constexpr int LCAP = CTGN_LCAP;               // per-row candidate list capacity (>= KMAX + 2*16)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
