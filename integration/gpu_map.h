@@ -9,6 +9,8 @@
 #ifndef CT_ICP_GPU_MAP_H
 #define CT_ICP_GPU_MAP_H
 
+#include <atomic>
+#include <type_traits>
 #include <cstdint>
 #include <vector>
 
@@ -33,6 +35,24 @@ namespace ct_icp {
             out->dtype = v.src_property_type == slam::FLOAT64 ? CTGN_F64 : CTGN_F32;
             out->_pad = 0;
             return true;
+        }
+
+        // ... and a typed slam::View<float / double> (view.h:20-62) is the same triple with the type fixed
+        template<typename T>
+        inline bool view_of(const slam::View<T> &v, ctgn_view *out) {
+            if (!std::is_same<T, double>::value && !std::is_same<T, float>::value) return false;
+            out->base = v.item_buffer.view_data_ptr + v.offset_in_item;
+            out->stride_bytes = (size_t) v.item_size;
+            out->dtype = std::is_same<T, double>::value ? CTGN_F64 : CTGN_F32;
+            out->_pad = 0;
+            return true;
+        }
+
+        // how many GpuVoxelMaps with `frame_pipeline` are alive in the process: the one arm that has no Odometry to ask
+        // (GpuFrameTimeRange, odometry_gpu_arm.h — called from a file-scope lambda of odometry.cpp) stands down at zero
+        inline std::atomic<int> &frame_pipeline_maps() {
+            static std::atomic<int> count{0};
+            return count;
         }
     }
 
@@ -76,9 +96,11 @@ namespace ct_icp {
             const ctgn_status st = ctgn_create(&mo, &handle_);
             SLAM_CHECK_STREAM(st == CTGN_OK, "libctgn: " << ctgn_status_string(st));
             if (options.device_updates) ctgn_map_set_update_mode(handle_, 1);
+            if (options.frame_pipeline && options.device_updates) ctgn_glue::frame_pipeline_maps()++;
         }
 
         ~GpuVoxelMap() override {
+            if (options_.frame_pipeline && options_.device_updates) ctgn_glue::frame_pipeline_maps()--;
             if (session_.rows) ctgn_host_free(handle_, session_.rows);
             ctgn_destroy(handle_);
         }

@@ -17,6 +17,11 @@
 //           return;
 //       }
 //
+// and, optionally, a FIFTH in the file-scope lambda compute_frame_info (:186-197), in front of its std::minmax_element:
+//       if (GpuFrameTimeRange(timestamps, frame_info.begin_timestamp, frame_info.end_timestamp)) return frame_info;
+//   (the same minimum and maximum read through the strided view the arms upload from: 0.03 ms for a 133 k-point scan instead of the 0.42 ms
+//    the proxy iterators take — a third of what is left of an armed frame. No device work: it only spares the host a type switch per element.)
+//
 // Everything else of Odometry is untouched and keeps deciding: InitializeMotion, the startup regimen, AssessRegistration (:604-684), the
 // robust retry loop (:780-852, it calls TryRegister — i.e. the arm — once per attempt on the same resident sampled frame), the insertion
 // policy of UpdateMap (:855-934), the trajectory. Every arm returns "not mine" (std::nullopt / false) and the reference's own code runs
@@ -79,6 +84,26 @@ namespace ct_icp {
             return v.dtype == CTGN_F64 ? *reinterpret_cast<const double *>(p) : (double) *reinterpret_cast<const float *>(p);
         }
 
+        // smallest and largest element of a FLOAT32 / FLOAT64 view (std::minmax_element's VALUES: which of several equal elements it points
+        // at does not matter to compute_frame_info, which dereferences both at once)
+        inline void minmax_of(const ctgn_view &v, size_t n, double &lo, double &hi) {
+            lo = hi = scalar_of(v, 0);
+            if (v.dtype == CTGN_F64) {
+                const char *p = static_cast<const char *>(v.base);
+                for (size_t i = 1; i < n; ++i) {
+                    const double x = *reinterpret_cast<const double *>(p + i * v.stride_bytes);
+                    lo = x < lo ? x : lo;
+                    hi = x < hi ? hi : x;          // (minmax_element keeps the LAST of equal maxima: `!(x < hi)` moves on)
+                }
+            } else {
+                for (size_t i = 1; i < n; ++i) {
+                    const double x = scalar_of(v, i);
+                    lo = x < lo ? x : lo;
+                    hi = x < hi ? hi : x;
+                }
+            }
+        }
+
         inline double ms_since(std::chrono::steady_clock::time_point t0) {
             return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -103,6 +128,18 @@ namespace ct_icp {
             fatal_unless_ok(ctgn_frame_undistort(gpu_map.handle(), pose, tbe, &out), gpu_map.handle());
             session.world_initialised = true;
         }
+    }
+
+    // compute_frame_info (odometry.cpp:186-197), optional fifth statement: first and last timestamp of the scan without the proxy iterators.
+    // "Not mine" when no GpuVoxelMap with `frame_pipeline` is alive in the process (the lambda has no Odometry to ask) or when the
+    // timestamps are not FLOAT32 / FLOAT64 — the reference's std::minmax_element then runs as before.
+    template<typename TimestampsView>
+    inline bool GpuFrameTimeRange(const TimestampsView &timestamps, double &begin_timestamp, double &end_timestamp) {
+        if (ctgn_glue::frame_pipeline_maps().load(std::memory_order_relaxed) <= 0 || timestamps.empty()) return false;
+        ctgn_view ts;
+        if (!ctgn_glue::view_of(timestamps, &ts)) return false;
+        ctgn_glue::minmax_of(ts, timestamps.size(), begin_timestamp, end_timestamp);
+        return true;
     }
 
     // InitializeFrame (odometry.cpp:333-382): shuffle, sub_sample_frame, timestamps of the first two frames, initial transform.

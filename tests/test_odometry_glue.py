@@ -61,15 +61,15 @@ def test_library_builds_and_the_gpu_map_refuses_without_a_device():
 
 def test_the_armed_source_carries_exactly_the_documented_insertions():
     """oracle/Makefile's GLUE_PATCH2 / GLUE_PATCH3 (what the armed library's odometry.cpp and map.cpp were compiled from) against the reference's
-    files: every line of the reference survives in order, and the inserted lines are the include, the four arm statements with the block they
-    open closed again, and the factory line — nothing else."""
+    files: every line of the reference survives in order, and the inserted lines are the include, the five arm statements with the block one of them
+    opens closed again, and the factory line — nothing else."""
     import difflib
     import subprocess
     if not os.path.isdir(os.path.join(ro.REFERENCE_ROOT, "src", "ct_icp")):
         pytest.skip("/root/reference absent: the patched stream is made from it at build time")
     oracle_dir = os.path.dirname(os.path.abspath(ro.__file__))
     for target, ref_file, want in (("glue-print2", "src/ct_icp/odometry.cpp",
-                                    ["#include <ct_icp/odometry_gpu_arm.h>", "GpuInitializeFrame(", "GpuUndistortFrame(", "}", "GpuTryRegister(", "GpuUpdateMap("]),
+                                    ["#include <ct_icp/odometry_gpu_arm.h>", "GpuFrameTimeRange(", "GpuInitializeFrame(", "GpuUndistortFrame(", "}", "GpuTryRegister(", "GpuUpdateMap("]),
                                    ("glue-print3", "src/ct_icp/map.cpp", ["#include <ct_icp/gpu_map.h>", "gpu_map_options_from_yaml(node)"])):
         patched = subprocess.check_output(["make", "-s", "-C", oracle_dir, target], text=True).splitlines()
         original = open(os.path.join(ro.REFERENCE_ROOT, ref_file)).read().splitlines()
