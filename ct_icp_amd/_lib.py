@@ -191,6 +191,7 @@ SYMBOLS = {
     "ctgn_last_upload_bytes": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "ctgn_set_tuning": (C.c_int, [C.c_char_p, C.c_double]),
     "ctgn_path_counters": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "ctgn_debug_pool_state": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_size_t]),
     "ctgn_dist_overheads": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_double)]),
     "ctgn_measure_hbm": (C.c_int, [_H, C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
     "ctgn_wave_timeline": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),

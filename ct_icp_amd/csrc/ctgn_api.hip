@@ -3551,6 +3551,18 @@ ctgn_status ctgn_set_tuning(const char *key, double value) {
     return CTGN_OK;
 }
 
+// measurement hook (scripts/pool_probe.py): the per-keypoint state the searches carry from one iteration to the next, in working order —
+// kth[2 n] (pool completeness radius | k-th neighbour's distance, KpView::kth) and the record's count word (n | pool size << 8 | TIE_FLAG)
+ctgn_status ctgn_debug_pool_state(ctgn_handle h, float *kth_out, uint32_t *cnt_out, size_t n) {
+    NEED_DEVICE(h);
+    if (n > (size_t) h->n_kp || (n && (!kth_out || !cnt_out))) return CTGN_ERR_INVALID_ARGUMENT;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const KpView kv = kp_view(h, false);
+    HIPCHK(h, hipMemcpy(kth_out, kv.kth, 2 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(cnt_out, kv.cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CTGN_OK;
+}
+
 ctgn_status ctgn_path_counters(ctgn_handle h, uint64_t out[2]) {
     if (!h || !out) return CTGN_ERR_INVALID_ARGUMENT;
     if (h->device >= 0 && h->d_partials) {           // did the last solve launch sum the per-XCD group records? (drains the stream)

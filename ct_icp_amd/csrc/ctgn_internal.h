@@ -84,6 +84,9 @@ ctgn_status ctgn_set_tuning(const char *key, double value);
  * rather than the block records (the placement check held). Drains the stream. */
 ctgn_status ctgn_path_counters(ctgn_handle h, uint64_t out[2]);
 
+/* Measurement hook: the carried per-keypoint search state (KpView::kth pairs, record count words), in working order. */
+ctgn_status ctgn_debug_pool_state(ctgn_handle h, float *kth_out, uint32_t *cnt_out, size_t n);
+
 /* Host-to-device bytes the last ctgn_set_keypoints_sharded call moved on this rank (host views): 56 B per keypoint of the scan with one rank,
  * 24 B per keypoint of the scan (world points, for the order every rank must agree on) + 56 B per keypoint of the rank's chunk otherwise. */
 ctgn_status ctgn_last_upload_bytes(ctgn_handle h, uint64_t *bytes);

@@ -845,7 +845,10 @@ __device__ __forceinline__ float sqrt_bound_down(double x) {
 }
 constexpr uint32_t TIE_FLAG = 0x80000000u;
 constexpr uint32_t REC_N_MASK = 63u;           // record word 0: bits 0-5 neighbours kept (n), bits 8-13 pool size (m >= n), bit 31 TIE_FLAG
-constexpr int POOL_REFILL = 4;                 // a keypoint whose pool check fails is searched up to its (k + POOL_REFILL)-th pool member
+#ifndef CTGN_POOL_REFILL
+#define CTGN_POOL_REFILL 4
+#endif
+constexpr int POOL_REFILL = CTGN_POOL_REFILL;                 // a keypoint whose pool check fails is searched up to its (k + POOL_REFILL)-th pool member
 constexpr int POOL_EXTRA = 8;                  // spare pool members behind the k neighbours (k + POOL_EXTRA <= KMAX or as many as fit)
 struct TieScratch {            // one per wave: the queue of the lane being replayed (keys, their squares, payload = point byte offset)
     double d[KMAX], s[KMAX];
