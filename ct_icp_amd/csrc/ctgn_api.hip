@@ -69,6 +69,9 @@ static_assert(sizeof(GnState) % 8 == 0 && sizeof(GnState) / 8 <= 256, "GnState i
 // 4-wave solve block, the unfused frame call) are gone together with their code paths.
 // Not synchronised: ctgn_set_tuning is for a measurement script or a test that owns the process, between calls — not for threads that
 // are solving meanwhile. host_threads is latched by the first scan-sized frame call (the pool is sized then): setting it later is refused.
+#ifndef CTGN_ROWS_ABL
+#define CTGN_ROWS_ABL false        // the search kernel of a solve without an ablation mask is compiled without the mask's tests (true: as rounds 1-5, one instantiation)
+#endif
 #ifndef CTGN_ROWS_WPS
 #define CTGN_ROWS_WPS 3            // waves per SIMD the default search-kernel instantiations are compiled for (A/B builds: 4 with CTGN_LCAP=80)
 #endif
@@ -889,8 +892,12 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 hipLaunchKernelGGL(kernel, dim3(rb), dim3(ROW_BLOCK), smem, h->stream, mv, ks, h->d_state, h->prm, h->d_partials, dv, 0, 1,
                                    (unsigned long long *) nullptr, h->ablate);
             };
-            if (mv.nb == 1) search(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<1>());
-            else search(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<2>());
+            if (h->ablate != 0) {                 // (bits above the low sixteen: the mask is honoured)
+                if (mv.nb == 1) search(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<1>());
+                else search(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<2>());
+            }
+            else if (mv.nb == 1) search(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS, false, true, false, CTGN_ROWS_ABL>, rows_kernel_smem<1>());
+            else search(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS, false, true, false, CTGN_ROWS_ABL>, rows_kernel_smem<2>());
             h->kth_fresh = true;
             if (ev) (void) hipEventRecord(ev->stop, h->stream);
             ev = nullptr;
@@ -904,7 +911,10 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 case 3: launch(k_accumulate_rows<1, true, true, 3>, sm, h->d_prof); break;
                 case 4: launch(k_accumulate_rows<1, true, false, 4, false, false>, sm, nullptr); break;
                 case 5: launch(k_accumulate_rows<1, true, false, 3, true, false>, sm, nullptr); break;      // with the shared-home-voxel path (A/B hook)
-                default: launch(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, sm, nullptr); break;
+                default:
+                    if (h->ablate == 0) { rb_slot = 6; launch(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS, false, true, false, CTGN_ROWS_ABL>, sm, nullptr); }
+                    else launch(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, sm, nullptr);
+                    break;
             }
         } else {
             const size_t sm = rows_kernel_smem<2>();
@@ -914,6 +924,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 rb_slot = 8 + 6;           // (its own occupancy entry)
                 launch(k_accumulate_rows<2, true, false, 2, false, true, true>, sm + ROW_WAVES * sizeof(GroupStage), h->d_prof);
             }
+            else if (h->ablate == 0 && h->variant == 0) { rb_slot = 8 + 7; launch(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS, false, true, false, CTGN_ROWS_ABL>, sm, nullptr); }
             else launch(k_accumulate_rows<2, true, false, CTGN_ROWS_WPS>, sm, nullptr);
         }
     }

@@ -1779,10 +1779,13 @@ CTGN_BATCH_UNROLL
 // NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles; POOLS = compile the
 // pool check (phase V) in: off for the A/B instantiations and the small-frame persistent kernel, which never see a frame large enough
 // to use it and would only carry its registers.
-template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true, bool STAGE = false>
+// ABL = the ablation mask is honoured (measurement launches); false = the mask is compiled out as 0 (what a solve without a mask runs: the
+// two dozen `ablate & bit` tests of the hot loops and their scalar registers are gone from the instruction stream).
+template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true, bool STAGE = false, bool ABL = true>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
-                                                               unsigned long long *prof = nullptr, int ablate = 0) {
+                                                               unsigned long long *prof = nullptr, int ablate_arg = 0) {
+    const int ablate = ABL ? ablate_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (st->done && !(ablate & 0xffff)) return;       // an ablated run starves the solve: keep timing the search anyway
     if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
