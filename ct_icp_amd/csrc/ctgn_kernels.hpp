@@ -230,6 +230,9 @@ constexpr int NORMALS_EXACT = 1, NORMALS_HYBRID = 2, NORMALS_FAST = 3;
 #ifndef CTGN_BATCH_UNROLL
 #define CTGN_BATCH_UNROLL _Pragma("unroll")
 #endif
+#ifndef CTGN_GUESS_PASSES
+#define CTGN_GUESS_PASSES 2          // passes of a guessed first search: the guess, then the radius (3: twice the guessed distance in between — measured)
+#endif
 #ifndef CTGN_STREAM_DEPTH
 #define CTGN_STREAM_DEPTH 2          // register sets of the stream loop. 3 (two chunks in flight) fits the registers without spills and
                                      // was measured: B2 0.1250 -> 0.1273 ms per iteration (the bounded searches stream 2-4 chunks per
@@ -1137,12 +1140,15 @@ __device__ __forceinline__ void rows_tiles(const MapView &map, const KpView &kp,
         // Two passes at most: pass 0 = the tile's rounds; pass 1 (only after a guessed bound, KpView::guess2) = the keypoints whose guess admitted
         // fewer than k candidates — or whose k-th lies within rounding of the guess —, compacted into rounds and searched on the radius.
 #pragma nounroll
-        for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
+        for (int pass = 0; pass < CTGN_GUESS_PASSES; ++pass) {
+        if (pass >= 1) {
             const bool again = W.todo[lane] == 2;
             if (!any64(again)) break;
             W.todo[lane] = again ? 1 : 0;
-            if (again) { W.kb[lane] = __int_as_float(0x7f800000); W.gs[lane] = 0; }
+            // (CTGN_GUESS_PASSES 3: a keypoint its guess failed is searched within twice the guessed distance before it is searched on the radius)
+            const float g4 = kp.guess2 * 4.f;
+            const bool wider = CTGN_GUESS_PASSES > 2 && pass == 1 && (double) g4 < 0.8 * map.r2thr;
+            if (again) { W.kb[lane] = wider ? g4 : __int_as_float(0x7f800000); W.gs[lane] = wider ? 1 : 0; }
             compact = true;
         }
         // ---------------- phase A2: the keypoints that are searched
