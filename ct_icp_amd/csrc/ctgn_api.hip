@@ -93,6 +93,7 @@ struct Tuning {
     double frame_defer_update = 1;  // ctgn_frame_update_map without an insert mask returns once the update is enqueued (0: waits for it)
     double stop_poll = 1;           // the host watches the solve's stop flag and does not enqueue the launches behind it (0: enqueues all num_iters_icp iterations)
     double robust_fuse = -1;        // robust route: evaluation + step in one launch (k_robust_eval_step): -1 = up to 1 024 keypoints, 0 / 1 = never / always
+    double state_init_fused = 1;    // the solve's first search launch writes the GnState itself (0: k_state_init in front of it, as rounds 1-5)
     double stage_lds = 0;           // 1: the 125-voxel sweep streams a home-voxel group's candidates from LDS (GroupStage; prototype, use with tile_chunk 4-16)
     double tile_chunk = 0;          // consecutive rounds of a search tile that take consecutive positions: 0 = the default (1: rounds strided over the scan), else that many
     double xcd_reduce = -1;         // per-XCD pre-sums of the residual kernel's block records: -1 = automatic (from 128 block records on), 0 / 1 = never / always (1: from 32 on)
@@ -102,7 +103,7 @@ static double *tuning_slot(Tuning &t, const std::string &key) {
     CTGN_TUNING_KEY(host_threads) CTGN_TUNING_KEY(order) CTGN_TUNING_KEY(pool_min) CTGN_TUNING_KEY(res_small) CTGN_TUNING_KEY(res_grid_cap)
     CTGN_TUNING_KEY(guess_factor) CTGN_TUNING_KEY(guess_maxfrac) CTGN_TUNING_KEY(split) CTGN_TUNING_KEY(xcd_split) CTGN_TUNING_KEY(fuse_small)
     CTGN_TUNING_KEY(persistent) CTGN_TUNING_KEY(persist_times) CTGN_TUNING_KEY(frame_timing) CTGN_TUNING_KEY(frame_no_direct) CTGN_TUNING_KEY(frame_defer_update) CTGN_TUNING_KEY(stop_poll)
-    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(stage_lds) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
+    CTGN_TUNING_KEY(tile_chunk) CTGN_TUNING_KEY(stage_lds) CTGN_TUNING_KEY(state_init_fused) CTGN_TUNING_KEY(xcd_reduce) CTGN_TUNING_KEY(robust_fuse)
 #undef CTGN_TUNING_KEY
     return nullptr;
 }
@@ -751,7 +752,14 @@ int launch_residual(ctgn_handle h, const MapView &mv, const KpView &kv, const De
 ctgn_status flush_state_init(ctgn_handle h);
 
 ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter, bool search_only = false) {
-    {
+    // The state initialisation gn_begin deferred rides INSIDE the solve's first search launch when that is the row kernel (StateInit,
+    // ctgn_kernels.hpp: the first search reads nothing of the state); every other first launch gets k_state_init in front of it.
+    StateInit state_init{nullptr, 0.0, 0.0};
+    if (h->init_pending && first_iter && !search_only && h->variant != 1 && (mv.nb == 1 || mv.nb == 2) && mv.blk <= 64 &&
+        (int) tuning().fuse_small != 1 && tuning().state_init_fused != 0) {
+        state_init = StateInit{h->init_pose, h->init_tbe[0], h->init_tbe[1]};
+        h->init_pending = false;
+    } else {
         ctgn_status fs = flush_state_init(h);
         if (fs != CTGN_OK) return fs;
     }
@@ -836,7 +844,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
             // varies along the sort key (the eighths then differ in work: B2 over the 270 MB map 0.145 -> 0.215 ms) -> incoherent uploads only
             kv.xcd_split = (env_xcd >= 0 ? env_xcd != 0 : ((h->order_valid && !h->kp_coherent) || h->kp_presorted)) && g1 >= 64 ? 1 : 0;
             hipLaunchKernelGGL(kernel, dim3(g1), dim3(ROW_BLOCK), smem, h->stream, mv, kv, h->d_state, h->prm, h->d_partials,
-                               dv, first_iter ? 1 : 0, rounds, prof, h->ablate);
+                               dv, first_iter ? 1 : 0, rounds, prof, h->ablate, state_init);
             h->kth_fresh = true;
             if (ev) (void) hipEventRecord(ev->stop, h->stream);        // the HIP-event pair brackets the neighbour-search kernel
             ev = nullptr;
@@ -890,7 +898,7 @@ ctgn_status launch_accumulate(ctgn_handle h, const MapView &mv, bool first_iter,
                 int &rb = h->rb_split_search[mv.nb == 1 ? 0 : 1];                 // one occupancy query per handle and instantiation
                 if (rb == 0) rb = std::min(resident_blocks(h, kernel, ROW_BLOCK, smem), MAX_PARTIAL_BLOCKS);
                 hipLaunchKernelGGL(kernel, dim3(rb), dim3(ROW_BLOCK), smem, h->stream, mv, ks, h->d_state, h->prm, h->d_partials, dv, 0, 1,
-                                   (unsigned long long *) nullptr, h->ablate);
+                                   (unsigned long long *) nullptr, h->ablate, StateInit{nullptr, 0.0, 0.0});
             };
             if (h->ablate != 0) {                 // (bits above the low sixteen: the mask is honoured)
                 if (mv.nb == 1) search(k_accumulate_rows<1, true, false, CTGN_ROWS_WPS>, rows_kernel_smem<1>());

@@ -72,7 +72,7 @@ ctgn_status ctgn_measure_hbm(ctgn_handle h, uint64_t bytes, int32_t reps, double
 
 /* The A/B switches of the measurement sessions, one table (ctgn_api.hip, struct Tuning: host_threads, order, pool_min, res_small, res_grid_cap,
  * guess_factor, guess_maxfrac, split, xcd_split, fuse_small, persistent, persist_times, frame_timing, frame_no_direct, frame_defer_update,
- * stop_poll, tile_chunk, stage_lds, xcd_reduce, robust_fuse). Process-wide and NOT synchronised: for a script or a test that owns the process, between
+ * stop_poll, tile_chunk, stage_lds, state_init_fused, xcd_reduce, robust_fuse). Process-wide and NOT synchronised: for a script or a test that owns the process, between
  * calls. None of them changes a neighbour set, a gate decision or a per-keypoint quantity; order, xcd_reduce, fuse_small and robust_fuse
  * select another fixed order of the packed sums (poses move in their last bits; see the table's comment). CTGN_ERR_UNSUPPORTED: host_threads
  * after the helper pool was sized by the first scan-sized frame call. A session script that cannot call into the library sets

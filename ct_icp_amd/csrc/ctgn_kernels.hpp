@@ -1785,15 +1785,40 @@ CTGN_BATCH_UNROLL
 // NB = sweep half-width (1 -> 27 voxels, 2 -> 125); HIST = histogram-assisted selection; PROF / SHARED: see rows_tiles; POOLS = compile the
 // pool check (phase V) in: off for the A/B instantiations and the small-frame persistent kernel, which never see a frame large enough
 // to use it and would only carry its registers.
+// What k_state_init writes (below), for the kernels that do it on their way: the solve's first search launch (StateInit) — the first
+// search of a solve works on the uploaded world points and reads nothing of the state, so one thread of its first block writes the state
+// while the others search, and the launch in front of it (4 us + a launch boundary per solve) is gone.
+struct StateInit {
+    const double *pose_in;      // nullptr: the state is initialised already
+    double tb, te;
+};
+__device__ __forceinline__ void state_init_body(GnState *st, const double *pose_in, double tb, double te) {
+    Quat qb = quat_normalized(Quat{pose_in[0], pose_in[1], pose_in[2], pose_in[3]});
+    Quat qe = quat_normalized(Quat{pose_in[7], pose_in[8], pose_in[9], pose_in[10]});
+    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
+    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
+    for (int c = 0; c < 3; ++c) { st->pose[4 + c] = pose_in[4 + c]; st->pose[11 + c] = pose_in[11 + c]; }
+    st->tbe[0] = tb; st->tbe[1] = te;
+    SlerpPair sp = slerp_prepare(qb, qe);
+    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
+    for (int i = 0; i < 12; ++i) st->x[i] = 0.0;
+    st->step_norm = 0.0;
+    st->iter = 0; st->done = 0; st->failed = 0; st->n_used = 0;
+    st->clk_iter_start = 0ull; st->ticks_neighborhood = 0ull; st->ticks_solve = 0ull; st->ticks_iter = 0ull;
+}
+
 // ABL = the ablation mask is honoured (measurement launches); false = the mask is compiled out as 0 (what a solve without a mask runs: the
 // two dozen `ablate & bit` tests of the hot loops and their scalar registers are gone from the instruction stream).
 template <int NB, bool HIST, bool PROF = false, int WPS = 4, bool SHARED = false, bool POOLS = true, bool STAGE = false, bool ABL = true>
 __global__ __launch_bounds__(ROW_BLOCK, WPS) void k_accumulate_rows(MapView map, KpView kp, const GnState *st, GnParams prm,
                                                                double *partials, DebugView dbg, int first_iter, int rounds,
-                                                               unsigned long long *prof = nullptr, int ablate_arg = 0) {
+                                                               unsigned long long *prof = nullptr, int ablate_arg = 0,
+                                                               StateInit init = StateInit{nullptr, 0.0, 0.0}) {
     const int ablate = ABL ? ablate_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (st->done && !(ablate & 0xffff)) return;       // an ablated run starves the solve: keep timing the search anyway
+    if (init.pose_in) {                                // the solve's first launch: the state is written here (and not read by this launch)
+        if (blockIdx.x == 0 && threadIdx.x == 0) state_init_body(const_cast<GnState *>(st), init.pose_in, init.tb, init.te);
+    } else if (st->done && !(ablate & 0xffff)) return;       // an ablated run starves the solve: keep timing the search anyway
     if (blockIdx.x == 0 && threadIdx.x == 0 && kp.clk_iter_start) *kp.clk_iter_start = wall_clock64();
     const int wave = threadIdx.x >> 6;
     if (kp.n_dev) {
@@ -2897,18 +2922,7 @@ __global__ __launch_bounds__(256) void k_frame_keypoints(const double *scan, con
 // GnState initialisation on the device (pose normalisation :716-717 + slerp constants).
 __global__ void k_state_init(GnState *st, const double *pose_in, double tb, double te) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Quat qb = quat_normalized(Quat{pose_in[0], pose_in[1], pose_in[2], pose_in[3]});
-    Quat qe = quat_normalized(Quat{pose_in[7], pose_in[8], pose_in[9], pose_in[10]});
-    st->pose[0] = qb.x; st->pose[1] = qb.y; st->pose[2] = qb.z; st->pose[3] = qb.w;
-    st->pose[7] = qe.x; st->pose[8] = qe.y; st->pose[9] = qe.z; st->pose[10] = qe.w;
-    for (int c = 0; c < 3; ++c) { st->pose[4 + c] = pose_in[4 + c]; st->pose[11 + c] = pose_in[11 + c]; }
-    st->tbe[0] = tb; st->tbe[1] = te;
-    SlerpPair sp = slerp_prepare(qb, qe);
-    st->slerp_theta = sp.theta; st->slerp_sin = sp.sin_theta; st->slerp_linear = sp.linear; st->slerp_negate = sp.negate;
-    for (int i = 0; i < 12; ++i) st->x[i] = 0.0;
-    st->step_norm = 0.0;
-    st->iter = 0; st->done = 0; st->failed = 0; st->n_used = 0;
-    st->clk_iter_start = 0ull; st->ticks_neighborhood = 0ull; st->ticks_solve = 0ull; st->ticks_iter = 0ull;
+    state_init_body(st, pose_in, tb, te);
 }
 
 // ================================================================================================
